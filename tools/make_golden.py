@@ -1,0 +1,344 @@
+#!/usr/bin/env python3
+"""
+Capture golden input/output vectors from the reference implementation.
+
+Runs ONLY in the build container (needs /root/reference).  The reference is
+imported unmodified; the one private scipy symbol it needs and that scipy
+1.15 dropped (`_aslinearoperator_with_dtype`, arpack.py:4-10) is injected at
+run time.  Output: small .npz fixtures in tests/golden/.
+A fixture holds data only (matrices, vectors, scalars, index sets).
+
+Every case runs in a fresh interpreter: ARPACK draws its start vector from
+SAVEd state that advances per call, so only the first IRAM solve of a process
+is reproducible.
+
+usage:  python tools/make_golden.py            # all cases
+        python tools/make_golden.py --case g4  # one case, in-process
+"""
+
+import argparse
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+
+def import_reference():
+    am = importlib.import_module("scipy.sparse.linalg._eigen.arpack.arpack")
+    from scipy.sparse.linalg import aslinearoperator
+
+    if not hasattr(am, "_aslinearoperator_with_dtype"):
+        am._aslinearoperator_with_dtype = lambda m: aslinearoperator(m)
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "examples"))
+    import eigd
+
+    return eigd
+
+
+def csr_fields(prefix, M):
+    M = M.tocsr()
+    M.sort_indices()
+    return {
+        prefix + "_indptr": M.indptr.astype(np.int32),
+        prefix + "_indices": M.indices.astype(np.int32),
+        prefix + "_data": M.data.astype(np.float64),
+        prefix + "_shape": np.array(M.shape, dtype=np.int64),
+    }
+
+
+def corr_fields(prefix, data):
+    """dict {i: [(j, xi, eta), ...]} -> flat arrays (order preserved)"""
+    rows = [(i, j, xi, eta) for i in sorted(data) for (j, xi, eta) in data[i]]
+    arr = np.array(rows, dtype=float).reshape(-1, 4)
+    return {
+        prefix + "_i": arr[:, 0].astype(np.int64),
+        prefix + "_j": arr[:, 1].astype(np.int64),
+        prefix + "_xi": arr[:, 2],
+        prefix + "_eta": arr[:, 3],
+    }
+
+
+def save(name, **fields):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **fields)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
+def solver_fields(prefix, s, basic):
+    f = {}
+    if basic:
+        f.update(
+            {
+                prefix + "lam": s.lam0,
+                prefix + "Phi": s.Phi,
+                prefix + "alpha": s.alpha,
+                prefix + "beta": s.beta,
+                prefix + "m": np.int64(s.m),
+                prefix + "N": np.int64(s.N),
+                prefix + "theta": s.theta,
+                prefix + "indices": np.asarray(s.indices, dtype=np.int64),
+                prefix + "V": s.V[:, : s.m],
+                prefix + "Y": s.Y,
+                prefix + "T": s.T,
+                prefix + "eig_res": s.eig_res,
+            }
+        )
+    else:
+        f.update(
+            {
+                prefix + "lam": s.lam,
+                prefix + "Phi": s.Phi,
+                prefix + "theta": s.theta,
+                prefix + "indices": np.asarray(s.indices, dtype=np.int64),
+                prefix + "V": s.V,
+                prefix + "Y": s.Y,
+                prefix + "T": s.T,
+                prefix + "m": np.int64(s.m),
+            }
+        )
+    return f
+
+
+# ---------------------------------------------------------------- G1 -------
+def case_g1(solver_type):
+    """C1: 50x50 buckling column, N=6, sigma=3, tanh eigenvector aggregate."""
+    import_reference()
+    import buckling
+
+    np.random.seed(0)
+    topo = buckling.make_model(
+        nx=50, ny=50, Lx=1.0, Ly=1.0, N=6, sigma=3.0, solver_type=solver_type,
+        adjoint_method="sibk",
+        adjoint_options={"lanczos_guess": True, "update_guess": False, "bs_target": 1},
+        deriv_type="tensor",
+    )
+    d = topo.test_eigenvector_aggregate_derivatives(mode="tanh", rho=100.0)
+    # test_* re-initialises at perturbed points; redo the base point for capture
+    topo.initialize(store=True)
+    topo.initialize_adjoint()
+    topo.add_eigenvector_aggregate_derivative(1.0, 100.0, (8 + 1) * 16 + 16, mode="tanh")
+    Qrb = topo.Qrb.copy()
+    lamb = topo.lamb.copy()
+    topo.finalize_adjoint()
+    s = topo.eig_solver
+    f = {}
+    f.update(csr_fields("K", topo.Kr))
+    f.update(csr_fields("G", topo.Gr))
+    f.update(solver_fields("", s, solver_type == "BasicLanczos"))
+    f.update(corr_fields("corr", topo.profile["adjoint correction data"]))
+    f.update(
+        sigma=np.float64(topo.sigma), Qrb=Qrb, lamb=lamb, psir=topo.psir, BLF=topo.BLF,
+        ans=np.float64(d["ans"]), cd=np.float64(d["cd"]), cd_err=np.float64(d["cd_err"]),
+        adjoint_residuals=np.array(topo.profile["adjoint residuals"]),
+        count_adjoint=np.int64(topo.profile["adjoint preconditioner count"]),
+    )
+    if "cs" in d:
+        f.update(cs=np.float64(d["cs"]), cs_err=np.float64(d["cs_err"]))
+    save("g1_buckling50_" + solver_type.lower(), **f)
+
+
+# ---------------------------------------------------------------- G2 -------
+def case_g2(solver_type):
+    """normal mode: small free-free plate, MinFreqOpt KS function."""
+    import_reference()
+    import natural_frequency as nf
+
+    np.random.seed(0)
+    topo = nf.make_model(
+        nx=32, ny=16, Lx=2.0, Ly=1.0, N=10, solver_type=solver_type, adjoint_method="sibk",
+        adjoint_options={"lanczos_guess": True, "update_guess": False, "bs_target": 1},
+    )
+    opt = nf.MinFreqOpt(topo)
+    opt.initialize(store=True)
+    opt.initialize_adjoint()
+    opt.finalize_adjoint()
+    res = topo.add_check_adjoint_residual(b_ortho=True)
+    s = topo.eig_solver
+    Q0b = np.zeros((topo.nvars, 3 + topo.N))
+    Q0b[:, 3:] = topo.Qb
+    lamb0 = np.zeros(3 + topo.N)
+    lamb0[3:] = topo.lamb
+    f = {}
+    f.update(csr_fields("K", topo.K))
+    f.update(csr_fields("M", topo.M))
+    f.update(solver_fields("", s, solver_type == "BasicLanczos"))
+    f.update(corr_fields("corr", topo.profile["adjoint correction data"]))
+    f.update(
+        sigma=np.float64(topo.sigma), Q0b=Q0b, lamb0=lamb0, psi=topo.psi, rhoEb=topo.rhoEb,
+        res_bortho=np.asarray(res), adjoint_residuals=np.array(topo.profile["adjoint residuals"]),
+    )
+    save("g2_natfreq32x16_" + solver_type.lower(), **f)
+
+
+# ---------------------------------------------------------------- G3 -------
+def case_g3(solver_type, epsilon, tag):
+    """repeated-eigenvalue branch on the (nearly) square thermal problem."""
+    import_reference()
+    import thermal
+
+    np.random.seed(0)
+    topo = thermal.make_opt_model(
+        nx=32, rfact=4.0, N=8, m=60, p=3, epsilon=epsilon, solver_type=solver_type,
+        adjoint_method="sibk",
+        adjoint_options={"lanczos_guess": True, "update_guess": False, "bs_target": 1},
+        element_sets={}, eig_atol=1e-5, rtol=1e-12, deriv_type="tensor",
+    )
+    vec = np.random.uniform(size=topo.nnodes)
+    d = topo.test_compliance_derivatives(vec=vec, dh_cs=1e-20)
+    topo.initialize(store=True)
+    topo.initialize_adjoint()
+    topo.add_thermal_compliance_derivative(1.0, vec)
+    topo.finalize_adjoint()
+    res, ortho = topo.eig_solver.eval_adjoint_residual_norm(topo.Qb, topo.psi, b_ortho=True)
+    s = topo.eig_solver
+    f = {}
+    f.update(csr_fields("K", topo.K))
+    f.update(csr_fields("M", topo.M))
+    f.update(solver_fields("", s, solver_type == "BasicLanczos"))
+    f.update(corr_fields("corr", topo.profile["adjoint correction data"]))
+    f.update(
+        sigma=np.float64(topo.sigma), Qb=topo.Qb, lamb=topo.lamb, psi=topo.psi, rhoEb=topo.rhoEb,
+        vec=vec, epsilon=np.float64(epsilon), res_bortho=res, ortho_bortho=ortho,
+        ans=np.float64(d["ans"]), cd=np.float64(d["cd"]), cd_err=np.float64(d["cd_err"]),
+        conn=topo.conn.astype(np.int32), X=topo.X, rhoE=topo.rhoE,
+    )
+    save(f"g3_thermal32_{tag}_{solver_type.lower()}", **f)
+
+
+# ---------------------------------------------------------------- G4 -------
+def laplacian_pair(nside=30, seed=3):
+    from scipy import sparse
+
+    I = sparse.identity(nside)
+    T = sparse.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(nside, nside))
+    K = (sparse.kron(I, T) + sparse.kron(T, I)).tocsr()
+    rng = np.random.default_rng(seed)
+    M = sparse.diags(rng.uniform(0.5, 1.5, size=nside * nside)).tocsr()
+    return K, M
+
+
+def case_g4(solver_type):
+    """method matrix on a 900-dof Laplacian / random-diagonal pair."""
+    eigd = import_reference()
+    K, M = laplacian_pair()
+    sigma, N = -0.1, 6
+    n = K.shape[0]
+    rng = np.random.default_rng(7)
+    Phib = rng.uniform(size=(n, N))
+    lamb = rng.uniform(size=N)
+    f = {}
+    f.update(csr_fields("K", K))
+    f.update(csr_fields("M", M))
+    for mode in ("normal", "buckling"):
+        # buckling convention: (B + lam A) phi = 0 with A = -0.005 M (a negative definite "G"), B = K;
+        # lam_1 ~ 4.2 and the shift 3.0 keeps B + sigma A positive definite (as buckling.py:1421)
+        A, B = (K, M) if mode == "normal" else ((-0.005 * M).tocsr(), K)
+        sig = sigma if mode == "normal" else 3.0
+        mat = (A - sig * B) if mode == "normal" else (B + sig * A)
+        factor = eigd.SpLuOperator(mat.tocsc())
+        if solver_type == "BasicLanczos":
+            s = eigd.BasicLanczos(N=N, m=60, mode=mode)
+        else:
+            s = eigd.IRAM(N=N, m=40, mode=mode)
+        s.solve(A, B, factor, sig)
+        p = mode + "_"
+        f.update(solver_fields(p, s, solver_type == "BasicLanczos"))
+        f[p + "sigma"] = np.float64(sig)
+        methods = ["laa", "sibk", "pcpg", "pgmres"] + (["dl"] if solver_type == "BasicLanczos" else [])
+        for method in methods:
+            factor.count = 0
+            kw = {}
+            if method == "sibk":
+                kw = {"update_guess": False, "bs_target": 1}
+            psi, data = s.solve_adjoint(Phib.copy(), method=method, rtol=1e-12, **kw)
+            f[p + method + "_psi"] = psi
+            f[p + method + "_count"] = np.int64(factor.count)
+            f.update(corr_fields(p + method + "_corr", data))
+            res, ortho = s.eval_adjoint_residual_norm(Phib, psi, b_ortho=False)
+            f[p + method + "_res"] = res
+        # extra sibk variants: block size 2 and update_guess
+        for tag, kw in (("sibk_bs2", {"bs_target": 2}), ("sibk_ug", {"update_guess": True})):
+            psi, data = s.solve_adjoint(Phib.copy(), method="sibk", rtol=1e-12, **kw)
+            f[p + tag + "_psi"] = psi
+    f.update(Phib=Phib, lamb=lamb)
+    save("g4_laplace900_" + solver_type.lower(), **f)
+
+
+# ---------------------------------------------------------------- G5 -------
+def case_g5():
+    """unit vectors for the small deterministic helpers."""
+    eigd = import_reference()
+    import eigd.eigenvector_derivatives as ed
+
+    rng = np.random.default_rng(11)
+    n, N, ndv = 40, 5, 7
+    f = {}
+    U, V, X = rng.normal(size=(n, N)), rng.normal(size=(n, N)), rng.normal(size=(n, 3))
+    f.update(proj_U=U, proj_V=V, proj_X=X, proj_out=ed._project(U, V, X.copy()))
+    x1 = rng.normal(size=n)
+    f.update(proj_x1=x1, proj_out1=ed._project(U, V, x1.copy()))
+
+    Phi = rng.normal(size=(n, N))
+    Phib = rng.normal(size=(n, N))
+    lamb = rng.normal(size=N)
+    Ca, Cb = rng.normal(size=(n, ndv)), rng.normal(size=(n, ndv))
+
+    def mk(C):
+        def cb(w, v):
+            if w.ndim == 1:
+                return C.T @ (w * v)
+            return C.T @ np.sum(w * v, axis=1)
+        return cb
+
+    f.update(Phi=Phi, Phib=Phib, lamb=lamb, Ca=Ca, Cb=Cb)
+    for tag, lam in (("distinct", np.array([1.0, 2.0, 3.5, 4.0, 7.0])),
+                     ("repeated", np.array([1.0, 1.0 + 2e-6, 3.5, 4.0, 4.0 + 5e-6]))):
+        f[tag + "_lam"] = lam
+        f[tag + "_repeated"] = np.bool_(eigd.are_eigenvalues_repeated(lam))
+        for mode in ("normal", "buckling"):
+            psi = rng.normal(size=(n, N))
+            p = f"{tag}_{mode}_"
+            f[p + "psi_in"] = psi.copy()
+            data = eigd.generate_adjoint_correction(lam, Phi, psi, Phib=Phib, mode=mode)
+            f[p + "psi_out"] = psi.copy()
+            f.update(corr_fields(p + "corr", data))
+            for dt in ("vector", "tensor"):
+                dfdx = eigd.add_eig_total_derivative(
+                    lam, Phi, lamb, Phib, psi, mk(Ca), mk(Cb), np.zeros(ndv),
+                    adj_corr_data=data, mode=mode, deriv_type=dt)
+                f[p + "dfdx_" + dt] = dfdx
+    save("g5_units", **f)
+
+
+CASES = {
+    "g1_basic": lambda: case_g1("BasicLanczos"),
+    "g1_iram": lambda: case_g1("IRAM"),
+    "g2_basic": lambda: case_g2("BasicLanczos"),
+    "g2_iram": lambda: case_g2("IRAM"),
+    "g3_eps1e-1_basic": lambda: case_g3("BasicLanczos", 0.1, "eps1e-1"),
+    "g3_eps1e-8_basic": lambda: case_g3("BasicLanczos", 1e-8, "eps1e-8"),
+    "g3_eps1e-8_iram": lambda: case_g3("IRAM", 1e-8, "eps1e-8"),
+    "g4_basic": lambda: case_g4("BasicLanczos"),
+    "g4_iram": lambda: case_g4("IRAM"),
+    "g5": case_g5,
+}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default=None)
+    args = ap.parse_args()
+    if args.case is not None:
+        CASES[args.case]()
+    else:
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg")
+        for name in CASES:
+            print("==", name, flush=True)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True, env=env)
