@@ -1,0 +1,118 @@
+"""
+ctypes binding of libeigd_hip.so (C ABI: include/eigd_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a HIP call fails
+the error is raised to the caller.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libeigd_hip.so")
+
+EIGD_E_INVALID, EIGD_E_HIP, EIGD_E_NOTSPD, EIGD_E_INTERNAL = -1, -2, -3, -4
+
+
+class EigdHipError(RuntimeError):
+    """HIP runtime / device failure inside libeigd_hip.so."""
+
+
+class NotPositiveDefiniteError(np.linalg.LinAlgError):
+    """The shifted matrix handed to SpLuOperator is not positive definite."""
+
+
+_lib = None
+
+c_int, c_i64, c_dbl, c_sz, c_vp = C.c_int, C.c_int64, C.c_double, C.c_size_t, C.c_void_p
+P = C.POINTER
+
+# name -> argtypes ; every function returns int unless listed in _RESTYPE
+_SIGNATURES = {
+    "eigd_version": [],
+    "eigd_device_count": [P(c_int)],
+    "eigd_ctx_create": [c_int, P(c_vp)],
+    "eigd_ctx_destroy": [c_vp],
+    "eigd_sync": [c_vp],
+    "eigd_malloc": [c_vp, c_sz, P(c_vp)],
+    "eigd_free": [c_vp, c_vp],
+    "eigd_memset": [c_vp, c_vp, c_int, c_sz],
+    "eigd_h2d": [c_vp, c_vp, c_vp, c_sz],
+    "eigd_d2h": [c_vp, c_vp, c_vp, c_sz],
+    "eigd_d2d": [c_vp, c_vp, c_vp, c_sz],
+    "eigd_mem_info": [c_vp, P(c_sz), P(c_sz)],
+    "eigd_timer_start": [c_vp],
+    "eigd_timer_stop_ms": [c_vp, P(c_dbl)],
+    "eigd_csr_upload": [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, P(c_vp)],
+    "eigd_csr_update_values": [c_vp, c_vp],
+    "eigd_mat_free": [c_vp],
+    "eigd_spmm": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_dbl],
+    "eigd_symbolic_create": [c_int, c_vp, c_vp, c_int, c_int, P(c_vp)],
+    "eigd_symbolic_free": [c_vp],
+    "eigd_symbolic_sizes": [c_vp, c_vp, c_int],
+    "eigd_symbolic_get_i32": [c_vp, C.c_char_p, c_vp, c_i64],
+    "eigd_symbolic_get_i64": [c_vp, C.c_char_p, c_vp, c_i64],
+    "eigd_factor_create": [c_vp, c_vp, c_vp, P(c_vp)],
+    "eigd_factor_refactor": [c_vp, c_vp],
+    "eigd_factor_free": [c_vp],
+    "eigd_factor_solve": [c_vp, c_vp, c_int, c_int, c_dbl],
+    "eigd_factor_stats": [c_vp, c_vp, c_int],
+    "eigd_factor_solve_bytes": [c_vp, c_int, P(c_dbl)],
+    "eigd_gemm_tn": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_int, c_vp],
+    "eigd_gemm_nn": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_dbl, c_dbl],
+    "eigd_project": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int],
+    "eigd_coldot": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp],
+    "eigd_lincomb": [c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp],
+    "eigd_stack_dot": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_int, c_vp],
+    "eigd_stack_axpy": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_int, c_dbl],
+    "eigd_copy_block": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
+    "eigd_gather_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
+    "eigd_scatter_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
+}
+EXPORTED = sorted(list(_SIGNATURES) + ["eigd_last_error"])
+
+
+def lib():
+    """Load (once) and return the shared library; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EigdHipError(
+                f"{LIB_PATH} not found: build it with `make -C eigd_amd/csrc` "
+                "(or __graft_entry__.build()); eigd_amd has no CPU fallback"
+            )
+        L = C.CDLL(LIB_PATH)
+        L.eigd_last_error.restype = C.c_char_p
+        L.eigd_last_error.argtypes = []
+        for name, args in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = c_int
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().eigd_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == EIGD_E_INVALID:
+        raise ValueError(msg)
+    if rc == EIGD_E_NOTSPD:
+        raise NotPositiveDefiniteError(msg)
+    raise EigdHipError(f"libeigd_hip error {rc}: {msg}")
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args))
+
+
+def hptr(a):
+    """host pointer of a C-contiguous numpy array"""
+    return a.ctypes.data_as(c_vp)

@@ -1,0 +1,478 @@
+// Tall-skinny panel kernels for gfx950: the BLAS-1/2/3 work numpy does for the reference
+// (inner products, Gram-Schmidt sweeps, oblique projections, V@Y / Z@y products).
+//
+// All blocks are n x k row-major (numpy C order), n ~ 1e6, k <= 64.  Every kernel is a
+// single streaming pass over its operands (HBM bound); cross-workgroup sums go through a
+// partial-sum slab that a second small kernel adds in a FIXED order, so results do not
+// depend on scheduling (bitwise reproducible, also between 1-GPU and mode-sharded runs).
+#include <algorithm>
+
+#include "common.h"
+
+namespace eigd {
+
+constexpr int kRB = 64;        // rows staged per LDS tile in the gemm kernels
+constexpr int kMaxBlocks = 1024;
+
+static inline int grid_for_rows(int n, int rows_per_block) {
+  int64_t need = (static_cast<int64_t>(n) + rows_per_block - 1) / rows_per_block;
+  return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(need, kMaxBlocks)));
+}
+
+// out[o] = sum_g partial[g * nout + o], g ascending
+__global__ void reduce_partials_kernel(const double* __restrict__ partial, int nblocks, int nout,
+                                       double* __restrict__ out) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= nout) return;
+  double s = 0.0;
+  for (int g = 0; g < nblocks; ++g) s += partial[static_cast<int64_t>(g) * nout + o];
+  out[o] = s;
+}
+
+// ---------------------------------------------------------------------------
+// column-wise dot products
+// ---------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(kThreads) void coldot_kernel(int n, int k, const double* __restrict__ X, int ldx,
+                                                         const double* __restrict__ Y, int ldy,
+                                                         double* __restrict__ partial) {
+  constexpr int RP = kThreads / KP;
+  __shared__ double red[kThreads];
+  const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
+  double s = 0.0;
+  if (c < k)
+    for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP)
+      s += X[r * ldx + c] * Y[r * ldy + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rr == 0 && c < k) {
+    double t = 0.0;
+    for (int q = 0; q < RP; ++q) t += red[q * KP + c];
+    partial[static_cast<int64_t>(blockIdx.x) * k + c] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// stack_dot: H[j][c] = sum_r S_j[r][c] * T[r][c] for JB slabs per launch
+// ---------------------------------------------------------------------------
+template <int KP, int JB>
+__global__ __launch_bounds__(kThreads) void stack_dot_kernel(int n, int k, int nj, const double* __restrict__ S,
+                                                            int64_t slab, const double* __restrict__ T, int ldt,
+                                                            double* __restrict__ partial) {
+  constexpr int RP = kThreads / KP;
+  __shared__ double red[kThreads];
+  const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
+  double acc[JB];
+#pragma unroll
+  for (int j = 0; j < JB; ++j) acc[j] = 0.0;
+  if (c < k)
+    for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
+      const double t = T[r * ldt + c];
+      const double* sp = S + r * k + c;
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+        if (j < nj) acc[j] += sp[j * slab] * t;
+    }
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    red[threadIdx.x] = acc[j];
+    __syncthreads();
+    if (rr == 0 && c < k && j < nj) {
+      double t = 0.0;
+      for (int q = 0; q < RP; ++q) t += red[q * KP + c];
+      partial[(static_cast<int64_t>(blockIdx.x) * nj + j) * k + c] = t;
+    }
+    __syncthreads();
+  }
+}
+
+// T[r][c] += alpha * sum_j S_j[r][c] * H[j][c]   (H on the device, ns x k)
+template <int KP>
+__global__ __launch_bounds__(kThreads) void stack_axpy_kernel(int n, int k, int ns, const double* __restrict__ S,
+                                                             int64_t slab, const double* __restrict__ H,
+                                                             double* __restrict__ T, int ldt, double alpha) {
+  constexpr int RP = kThreads / KP;
+  extern __shared__ double Hs[];  // ns * k
+  for (int q = threadIdx.x; q < ns * k; q += kThreads) Hs[q] = H[q];
+  __syncthreads();
+  const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
+  if (c >= k) return;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
+    const double* sp = S + r * k + c;
+    double s = 0.0;
+    for (int j = 0; j < ns; ++j) s += sp[j * slab] * Hs[j * k + c];
+    T[r * ldt + c] += alpha * s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// lincomb
+// ---------------------------------------------------------------------------
+struct LinArgs {
+  const double* x[4];
+  int ld[4];
+  double coef[4][kMaxK];
+};
+
+template <int KP>
+__global__ __launch_bounds__(kThreads) void lincomb_kernel(int n, int k, double* out, int ldo, int nterms,
+                                                          LinArgs a) {
+  constexpr int RP = kThreads / KP;
+  const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
+  if (c >= k) return;
+  double cf[4];
+  for (int t = 0; t < 4; ++t) cf[t] = (t < nterms) ? a.coef[t][c] : 0.0;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
+    double s = 0.0;
+    for (int t = 0; t < nterms; ++t) s += cf[t] * a.x[t][r * a.ld[t] + c];
+    out[r * ldo + c] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// C = U^T X  (partials per workgroup), U(r,a) = U[r*rsu + a*csu]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void gemm_tn_kernel(int n, int ku, int kx, const double* __restrict__ U,
+                                                          int64_t rsu, int64_t csu, const double* __restrict__ X,
+                                                          int ldx, double* __restrict__ partial) {
+  __shared__ double Us[kRB][kMaxK + 1];
+  __shared__ double Xs[kRB][kMaxK + 1];
+  const int tid = threadIdx.x;
+  const int a0 = (tid / 16) * 4, b0 = (tid % 16) * 4;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  // zero the padding columns once
+  for (int q = tid; q < kRB * (kMaxK + 1); q += kThreads) {
+    (&Us[0][0])[q] = 0.0;
+    (&Xs[0][0])[q] = 0.0;
+  }
+  __syncthreads();
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kRB; base < n; base += static_cast<int64_t>(gridDim.x) * kRB) {
+    const int rows = static_cast<int>((n - base) < kRB ? (n - base) : kRB);
+    if (rsu == 1) {
+      for (int q = tid; q < kRB * ku; q += kThreads) {
+        const int r = q % kRB, a = q / kRB;
+        Us[r][a] = (r < rows) ? U[(base + r) + a * csu] : 0.0;
+      }
+    } else {
+      for (int q = tid; q < kRB * ku; q += kThreads) {
+        const int a = q % ku, r = q / ku;
+        Us[r][a] = (r < rows) ? U[(base + r) * rsu + a * csu] : 0.0;
+      }
+    }
+    for (int q = tid; q < kRB * kx; q += kThreads) {
+      const int b = q % kx, r = q / kx;
+      Xs[r][b] = (r < rows) ? X[(base + r) * ldx + b] : 0.0;
+    }
+    __syncthreads();
+    if (a0 < ku && b0 < kx) {
+      for (int r = 0; r < kRB; ++r) {
+        double u[4], x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = Us[r][a0 + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = Xs[r][b0 + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += u[i] * x[j];
+      }
+    }
+    __syncthreads();
+  }
+  double* p = partial + static_cast<int64_t>(blockIdx.x) * ku * kx;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (a0 + i < ku && b0 + j < kx) p[(a0 + i) * kx + b0 + j] = acc[i][j];
+}
+
+// X[r][b] = beta * X[r][b] + alpha * sum_a U(r,a) C[a][b], C on the device (ku x kx)
+__global__ __launch_bounds__(kThreads) void gemm_nn_kernel(int n, int ku, int kx, const double* __restrict__ U,
+                                                          int64_t rsu, int64_t csu, const double* __restrict__ C,
+                                                          double* __restrict__ X, int ldx, double alpha, double beta) {
+  __shared__ double Us[kRB][kMaxK + 1];
+  extern __shared__ double Cs[];  // ku * kx
+  const int tid = threadIdx.x;
+  for (int q = tid; q < ku * kx; q += kThreads) Cs[q] = C[q];
+  const int cpt = (kx + 3) / 4;          // columns per thread (<= 16)
+  const int r = tid / 4, b0 = (tid % 4) * cpt;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kRB; base < n; base += static_cast<int64_t>(gridDim.x) * kRB) {
+    const int rows = static_cast<int>((n - base) < kRB ? (n - base) : kRB);
+    __syncthreads();
+    if (rsu == 1) {
+      for (int q = tid; q < kRB * ku; q += kThreads) {
+        const int rr = q % kRB, a = q / kRB;
+        Us[rr][a] = (rr < rows) ? U[(base + rr) + a * csu] : 0.0;
+      }
+    } else {
+      for (int q = tid; q < kRB * ku; q += kThreads) {
+        const int a = q % ku, rr = q / ku;
+        Us[rr][a] = (rr < rows) ? U[(base + rr) * rsu + a * csu] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (r < rows) {
+      double acc[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+      for (int a = 0; a < ku; ++a) {
+        const double u = Us[r][a];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (j < cpt && b0 + j < kx) acc[j] += u * Cs[a * kx + b0 + j];
+      }
+      double* xp = X + (base + r) * ldx;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < cpt && b0 + j < kx) xp[b0 + j] = (beta == 0.0) ? alpha * acc[j] : beta * xp[b0 + j] + alpha * acc[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// block copies / column gather-scatter
+// ---------------------------------------------------------------------------
+struct ColMap {
+  int32_t cols[kMaxK];
+};
+
+// mode 0: Dst[r][j] = Src[r][j] ; mode 1: Dst[r][j] = Src[r][map[j]] ; mode 2: Dst[r][map[j]] = Src[r][j]
+template <int KP>
+__global__ __launch_bounds__(kThreads) void copy_cols_kernel(int n, int k, const double* __restrict__ src, int lds,
+                                                            double* __restrict__ dst, int ldd, int mode, ColMap m) {
+  constexpr int RP = kThreads / KP;
+  const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
+  if (c >= k) return;
+  const int cs = (mode == 1) ? m.cols[c] : c;
+  const int cd = (mode == 2) ? m.cols[c] : c;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP)
+    dst[r * ldd + cd] = src[r * lds + cs];
+}
+
+template <typename F>
+static int dispatch_kp(int k, F&& f) {
+  const int kp = next_pow2(std::max(1, k));
+  switch (kp) {
+    case 1: f(std::integral_constant<int, 1>()); break;
+    case 2: f(std::integral_constant<int, 2>()); break;
+    case 4: f(std::integral_constant<int, 4>()); break;
+    case 8: f(std::integral_constant<int, 8>()); break;
+    case 16: f(std::integral_constant<int, 16>()); break;
+    case 32: f(std::integral_constant<int, 32>()); break;
+    case 64: f(std::integral_constant<int, 64>()); break;
+    default: set_error("block wider than %d columns", kMaxK); return EIGD_E_INVALID;
+  }
+  return EIGD_OK;
+}
+
+static int reduce_to_host(eigd_ctx* ctx, const double* partial, int nblocks, int nout, double* dres, double* hout) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 255) / 256), dim3(256), 0, ctx->stream, partial, nblocks, nout,
+                     dres);
+  EIGD_LAUNCH_CHECK();
+  if (hout) {
+    EIGD_HIP(hipMemcpyAsync(hout, dres, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));
+    EIGD_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return EIGD_OK;
+}
+
+// partial-sum layout in ctx->scratch: [result nout][partials nblocks*nout]
+static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu,
+                          const double* dX, int ldx, double** dres, double* hC) {
+  const int nb = grid_for_rows(n, kRB);
+  const int nout = ku * kx;
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) + 1) * nout);
+  if (rc) return rc;
+  double* res = ctx->scratch;
+  double* partial = ctx->scratch + nout;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, csu, dX, ldx,
+                     partial);
+  EIGD_LAUNCH_CHECK();
+  rc = reduce_to_host(ctx, partial, nb, nout, res, hC);
+  if (rc) return rc;
+  if (dres) *dres = res;
+  return EIGD_OK;
+}
+
+static int gemm_nn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu,
+                          const double* dC, double* dX, int ldx, double alpha, double beta) {
+  const int nb = grid_for_rows(n, kRB);
+  hipLaunchKernelGGL(gemm_nn_kernel, dim3(nb), dim3(kThreads), sizeof(double) * ku * kx, ctx->stream, n, ku, kx, dU, rsu,
+                     csu, dC, dX, ldx, alpha, beta);
+  EIGD_LAUNCH_CHECK();
+  return EIGD_OK;
+}
+
+}  // namespace eigd
+
+using namespace eigd;
+
+extern "C" {
+
+int eigd_gemm_tn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu, const double* dX,
+                 int ldx, double* hC) {
+  EIGD_REQUIRE(ctx && dU && dX && hC, "null argument");
+  EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx, "bad shape n=%d ku=%d kx=%d", n,
+               ku, kx);
+  return gemm_tn_device(ctx, n, ku, kx, dU, rsu, csu, dX, ldx, nullptr, hC);
+}
+
+int eigd_gemm_nn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu, const double* hC,
+                 double* dX, int ldx, double alpha, double beta) {
+  EIGD_REQUIRE(ctx && dU && dX && hC, "null argument");
+  EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx, "bad shape n=%d ku=%d kx=%d", n,
+               ku, kx);
+  int rc = ctx->ensure_coef(sizeof(double) * ku * kx);
+  if (rc) return rc;
+  EIGD_HIP(hipMemcpyAsync(ctx->coef, hC, sizeof(double) * ku * kx, hipMemcpyHostToDevice, ctx->stream));
+  EIGD_HIP(hipStreamSynchronize(ctx->stream));
+  return gemm_nn_device(ctx, n, ku, kx, dU, rsu, csu, ctx->coef, dX, ldx, alpha, beta);
+}
+
+int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv, double* dX,
+                 int ldx) {
+  EIGD_REQUIRE(ctx && dU && dV && dX, "null argument");
+  EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx && ldu >= ku && ldv >= ku,
+               "bad shape n=%d ku=%d kx=%d", n, ku, kx);
+  double* dC = nullptr;
+  int rc = gemm_tn_device(ctx, n, ku, kx, dV, ldv, 1, dX, ldx, &dC, nullptr);
+  if (rc) return rc;
+  return gemm_nn_device(ctx, n, ku, kx, dU, ldu, 1, dC, dX, ldx, -1.0, 1.0);
+}
+
+int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout) {
+  EIGD_REQUIRE(ctx && dX && dY && hout, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldx >= k && ldy >= k, "bad shape n=%d k=%d", n, k);
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 8);
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) + 1) * k);
+  if (rc) return rc;
+  double* res = ctx->scratch;
+  double* partial = ctx->scratch + k;
+  rc = dispatch_kp(k, [&](auto KP) {
+    hipLaunchKernelGGL(coldot_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dX, ldx, dY,
+                       ldy, partial);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  return reduce_to_host(ctx, partial, nb, k, res, hout);
+}
+
+int eigd_lincomb(eigd_ctx* ctx, int n, int k, double* dOut, int ldo, int nterms, const double* const* dXs,
+                 const int* ldxs, const double* hcoef) {
+  EIGD_REQUIRE(ctx && dOut && dXs && ldxs && hcoef, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && nterms >= 1 && nterms <= 4 && ldo >= k, "bad shape n=%d k=%d nterms=%d",
+               n, k, nterms);
+  LinArgs a;
+  for (int t = 0; t < 4; ++t) {
+    a.x[t] = (t < nterms) ? dXs[t] : nullptr;
+    a.ld[t] = (t < nterms) ? ldxs[t] : 0;
+    for (int c = 0; c < kMaxK; ++c) a.coef[t][c] = (t < nterms && c < k) ? hcoef[t * k + c] : 0.0;
+    if (t < nterms) EIGD_REQUIRE(dXs[t] != nullptr && ldxs[t] >= k, "bad term %d", t);
+  }
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 4);
+  int rc = dispatch_kp(k, [&](auto KP) {
+    hipLaunchKernelGGL(lincomb_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dOut, ldo,
+                       nterms, a);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  return EIGD_OK;
+}
+
+int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, const double* dT, int ldt,
+                   double* hH) {
+  EIGD_REQUIRE(ctx && dS && dT && hH, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && slab >= static_cast<int64_t>(n) * k,
+               "bad shape n=%d k=%d ns=%d", n, k, ns);
+  constexpr int JB = 8;
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 8);
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) + 1) * JB * k + sizeof(double) * ns * k);
+  if (rc) return rc;
+  double* res = ctx->scratch;                  // JB * k
+  double* partial = ctx->scratch + JB * k;     // nb * JB * k
+  for (int j0 = 0; j0 < ns; j0 += JB) {
+    const int nj = std::min(JB, ns - j0);
+    rc = dispatch_kp(k, [&](auto KP) {
+      hipLaunchKernelGGL((stack_dot_kernel<decltype(KP)::value, JB>), dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, nj,
+                         dS + j0 * slab, slab, dT, ldt, partial);
+    });
+    if (rc) return rc;
+    EIGD_LAUNCH_CHECK();
+    rc = reduce_to_host(ctx, partial, nb, nj * k, res, hH + static_cast<size_t>(j0) * k);
+    if (rc) return rc;
+  }
+  return EIGD_OK;
+}
+
+int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, const double* hH, double* dT,
+                    int ldt, double alpha) {
+  EIGD_REQUIRE(ctx && dS && dT && hH, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && slab >= static_cast<int64_t>(n) * k,
+               "bad shape n=%d k=%d ns=%d", n, k, ns);
+  EIGD_REQUIRE(static_cast<size_t>(ns) * k * sizeof(double) <= 60 * 1024, "stack too deep for one pass: ns*k=%d", ns * k);
+  int rc = ctx->ensure_coef(sizeof(double) * ns * k);
+  if (rc) return rc;
+  EIGD_HIP(hipMemcpyAsync(ctx->coef, hH, sizeof(double) * ns * k, hipMemcpyHostToDevice, ctx->stream));
+  EIGD_HIP(hipStreamSynchronize(ctx->stream));
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 4);
+  rc = dispatch_kp(k, [&](auto KP) {
+    hipLaunchKernelGGL(stack_axpy_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), sizeof(double) * ns * k,
+                       ctx->stream, n, k, ns, dS, slab, ctx->coef, dT, ldt, alpha);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  return EIGD_OK;
+}
+
+static int copy_cols(eigd_ctx* ctx, int n, int k, const double* dSrc, int lds, double* dDst, int ldd, int mode,
+                     const int32_t* hcols, int maxcol_src, int maxcol_dst) {
+  EIGD_REQUIRE(ctx && dSrc && dDst, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK, "bad shape n=%d k=%d", n, k);
+  ColMap m;
+  for (int c = 0; c < kMaxK; ++c) m.cols[c] = c;
+  if (mode != 0) {
+    EIGD_REQUIRE(hcols != nullptr, "column map is null");
+    for (int c = 0; c < k; ++c) {
+      EIGD_REQUIRE(hcols[c] >= 0 && hcols[c] < (mode == 1 ? maxcol_src : maxcol_dst), "column index %d out of range",
+                   hcols[c]);
+      m.cols[c] = hcols[c];
+    }
+  }
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 4);
+  int rc = dispatch_kp(k, [&](auto KP) {
+    hipLaunchKernelGGL(copy_cols_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dSrc, lds,
+                       dDst, ldd, mode, m);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  return EIGD_OK;
+}
+
+int eigd_copy_block(eigd_ctx* ctx, int n, int k, const double* dSrc, int lds, double* dDst, int ldd) {
+  EIGD_REQUIRE(lds >= k && ldd >= k, "leading dimensions too small");
+  return copy_cols(ctx, n, k, dSrc, lds, dDst, ldd, 0, nullptr, lds, ldd);
+}
+
+int eigd_gather_cols(eigd_ctx* ctx, int n, int kdst, const double* dSrc, int lds, const int32_t* hcols, double* dDst,
+                     int ldd) {
+  EIGD_REQUIRE(ldd >= kdst, "leading dimension too small");
+  return copy_cols(ctx, n, kdst, dSrc, lds, dDst, ldd, 1, hcols, lds, ldd);
+}
+
+int eigd_scatter_cols(eigd_ctx* ctx, int n, int ksrc, const double* dSrc, int lds, const int32_t* hcols, double* dDst,
+                      int ldd) {
+  EIGD_REQUIRE(lds >= ksrc, "leading dimension too small");
+  return copy_cols(ctx, n, ksrc, dSrc, lds, dDst, ldd, 2, hcols, lds, ldd);
+}
+
+}  // extern "C"

@@ -1,0 +1,472 @@
+"""
+Thin Python objects over the C ABI: device context, device arrays (row-major n x k
+blocks and stacks of them), CSR matrices, symbolic analysis and the numeric factor.
+
+Nothing here computes on the host; every method is one call into libeigd_hip.so.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import c_vp, call, hptr
+
+_default_ctx = None
+
+
+class Context:
+    """One device + one stream."""
+
+    def __init__(self, device=0):
+        h = c_vp()
+        call("eigd_ctx_create", int(device), C.byref(h))
+        self.h = h
+        self.device = int(device)
+
+    def sync(self):
+        call("eigd_sync", self.h)
+
+    def mem_info(self):
+        f, t = C.c_size_t(), C.c_size_t()
+        call("eigd_mem_info", self.h, C.byref(f), C.byref(t))
+        return f.value, t.value
+
+    def timer_start(self):
+        call("eigd_timer_start", self.h)
+
+    def timer_stop_ms(self):
+        ms = C.c_double()
+        call("eigd_timer_stop_ms", self.h, C.byref(ms))
+        return ms.value
+
+    def close(self):
+        if self.h is not None and self.h.value:
+            _ffi.lib().eigd_ctx_destroy(self.h)
+            self.h = None
+
+    # -- allocation helpers -------------------------------------------------
+    def empty(self, n, k=1):
+        return DeviceBlock(self, n, k)
+
+    def zeros(self, n, k=1):
+        b = DeviceBlock(self, n, k)
+        b.zero()
+        return b
+
+    def from_host(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.ndim == 1:
+            b = DeviceBlock(self, a.shape[0], 1)
+        elif a.ndim == 2:
+            b = DeviceBlock(self, a.shape[0], a.shape[1])
+        else:
+            raise ValueError("expected a vector or a matrix")
+        b.set(a)
+        return b
+
+    def stack(self, ns, n, k=1):
+        return DeviceStack(self, ns, n, k)
+
+
+def default_context():
+    """Context on the device named by EIGD_DEVICE / LOCAL_RANK (default 0)."""
+    import os
+
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get("EIGD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        cnt = C.c_int()
+        call("eigd_device_count", C.byref(cnt))
+        _default_ctx = Context(dev % max(cnt.value, 1))
+    return _default_ctx
+
+
+class _Buffer:
+    """owning device allocation"""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        p = c_vp()
+        call("eigd_malloc", ctx.h, int(nbytes), C.byref(p))
+        self.ptr = p.value
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None) and self.ctx.h is not None:
+                _ffi.lib().eigd_free(self.ctx.h, c_vp(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class DeviceBlock:
+    """n x k block of doubles, row-major with leading dimension ld (numpy C order)."""
+
+    def __init__(self, ctx, n, k, buf=None, offset=0, ld=None):
+        self.ctx, self.n, self.k = ctx, int(n), int(k)
+        self.ld = self.k if ld is None else int(ld)
+        if buf is None:
+            buf = _Buffer(ctx, 8 * max(self.n * self.ld, 1))
+            offset = 0
+        self.buf = buf
+        self.offset = int(offset)  # in doubles
+
+    @property
+    def ptr(self):
+        return c_vp(self.buf.ptr + 8 * self.offset)
+
+    @property
+    def shape(self):
+        return (self.n, self.k)
+
+    def cols(self, c0, c1):
+        """view of columns [c0, c1) (same rows, same leading dimension)"""
+        return DeviceBlock(self.ctx, self.n, c1 - c0, self.buf, self.offset + c0, self.ld)
+
+    def zero(self):
+        if self.ld == self.k:
+            call("eigd_memset", self.ctx.h, self.ptr, 0, 8 * self.n * self.k)
+        else:
+            self.assign_lincomb([(0.0, self)])
+
+    def set(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(self.n, self.k)
+        if self.ld == self.k:
+            call("eigd_h2d", self.ctx.h, self.ptr, hptr(a), 8 * self.n * self.k)
+        else:
+            tmp = self.ctx.from_host(a)
+            self.copy_from(tmp)
+
+    def get(self):
+        if self.ld == self.k:
+            out = np.empty((self.n, self.k))
+            call("eigd_d2h", self.ctx.h, hptr(out), self.ptr, 8 * self.n * self.k)
+            return out
+        tmp = self.ctx.empty(self.n, self.k)
+        tmp.copy_from(self)
+        return tmp.get()
+
+    def copy_from(self, src):
+        if (src.n, src.k) != (self.n, self.k):
+            raise ValueError("shape mismatch in copy")
+        if src.ld == src.k and self.ld == self.k:
+            call("eigd_d2d", self.ctx.h, self.ptr, src.ptr, 8 * self.n * self.k)
+        else:
+            for c0 in range(0, self.k, 64):
+                c1 = min(self.k, c0 + 64)
+                call("eigd_copy_block", self.ctx.h, self.n, c1 - c0, src.cols(c0, c1).ptr, src.ld,
+                     self.cols(c0, c1).ptr, self.ld)
+        return self
+
+    def copy(self):
+        return self.ctx.empty(self.n, self.k).copy_from(self)
+
+    # ---- panel operations --------------------------------------------------
+    def assign_lincomb(self, terms):
+        """self[:, c] = sum_t coef_t[c] * X_t[:, c]; coef scalar or length-k array; <= 4 terms"""
+        nt = len(terms)
+        k = self.k
+        for c0 in range(0, k, 64):
+            c1 = min(k, c0 + 64)
+            kb = c1 - c0
+            coef = np.empty((nt, kb))
+            ptrs = (c_vp * nt)()
+            lds = (C.c_int * nt)()
+            for t, (cf, X) in enumerate(terms):
+                coef[t, :] = np.broadcast_to(np.asarray(cf, dtype=np.float64), (k,))[c0:c1]
+                ptrs[t] = X.cols(c0, c1).ptr
+                lds[t] = X.ld
+            call("eigd_lincomb", self.ctx.h, self.n, kb, self.cols(c0, c1).ptr, self.ld, nt, ptrs, lds, hptr(coef))
+        return self
+
+    def coldot(self, other):
+        out = np.empty(self.k)
+        for c0 in range(0, self.k, 64):
+            c1 = min(self.k, c0 + 64)
+            tmp = np.empty(c1 - c0)
+            call("eigd_coldot", self.ctx.h, self.n, c1 - c0, self.cols(c0, c1).ptr, self.ld,
+                 other.cols(c0, c1).ptr, other.ld, hptr(tmp))
+            out[c0:c1] = tmp
+        return out
+
+    def colnorms(self):
+        return np.sqrt(self.coldot(self))
+
+    def tdot(self, X):
+        """self^T X  -> host (self.k x X.k)"""
+        out = np.empty((self.k, X.k))
+        for a0 in range(0, self.k, 64):
+            a1 = min(self.k, a0 + 64)
+            for b0 in range(0, X.k, 64):
+                b1 = min(X.k, b0 + 64)
+                tmp = np.empty((a1 - a0, b1 - b0))
+                call("eigd_gemm_tn", self.ctx.h, self.n, a1 - a0, b1 - b0, self.cols(a0, a1).ptr, self.ld, 1,
+                     X.cols(b0, b1).ptr, X.ld, hptr(tmp))
+                out[a0:a1, b0:b1] = tmp
+        return out
+
+    def add_product(self, U, Cmat, alpha=1.0, beta=1.0):
+        """self = beta * self + alpha * U @ C, C on the host (U.k x self.k)"""
+        Cmat = np.ascontiguousarray(Cmat, dtype=np.float64).reshape(U.k, self.k)
+        for b0 in range(0, self.k, 64):
+            b1 = min(self.k, b0 + 64)
+            bb = beta
+            for a0 in range(0, U.k, 64):
+                a1 = min(U.k, a0 + 64)
+                cc = np.ascontiguousarray(Cmat[a0:a1, b0:b1])
+                call("eigd_gemm_nn", self.ctx.h, self.n, a1 - a0, b1 - b0, U.cols(a0, a1).ptr, U.ld, 1, hptr(cc),
+                     self.cols(b0, b1).ptr, self.ld, float(alpha), float(bb))
+                bb = 1.0
+        return self
+
+    def project(self, U, V):
+        """self <- self - U (V^T self)   (reference _project, eigenvector_derivatives.py:26-30)"""
+        if U.k > 64 or self.k > 64:
+            t = V.tdot(self)
+            return self.add_product(U, t, alpha=-1.0, beta=1.0)
+        call("eigd_project", self.ctx.h, self.n, U.k, self.k, U.ptr, U.ld, V.ptr, V.ld, self.ptr, self.ld)
+        return self
+
+    def gather_cols(self, cols):
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        out = self.ctx.empty(self.n, len(cols))
+        for c0 in range(0, len(cols), 64):
+            c1 = min(len(cols), c0 + 64)
+            sub = np.ascontiguousarray(cols[c0:c1])
+            call("eigd_gather_cols", self.ctx.h, self.n, c1 - c0, self.ptr, self.ld, hptr(sub),
+                 out.cols(c0, c1).ptr, out.ld)
+        return out
+
+    def scatter_cols_into(self, dst, cols):
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        for c0 in range(0, len(cols), 64):
+            c1 = min(len(cols), c0 + 64)
+            sub = np.ascontiguousarray(cols[c0:c1])
+            call("eigd_scatter_cols", self.ctx.h, self.n, c1 - c0, self.cols(c0, c1).ptr, self.ld, hptr(sub),
+                 dst.ptr, dst.ld)
+        return dst
+
+
+class DeviceStack:
+    """ns slabs, each an n x k row-major block with ld = k, contiguous in one allocation."""
+
+    def __init__(self, ctx, ns, n, k=1):
+        self.ctx, self.ns, self.n, self.k = ctx, int(ns), int(n), int(k)
+        self.slab = self.n * self.k
+        self.buf = _Buffer(ctx, 8 * max(self.ns * self.slab, 1))
+
+    def __getitem__(self, j):
+        if not 0 <= j < self.ns:
+            raise IndexError(j)
+        return DeviceBlock(self.ctx, self.n, self.k, self.buf, j * self.slab, self.k)
+
+    @property
+    def ptr(self):
+        return c_vp(self.buf.ptr)
+
+    def slab_ptr(self, j):
+        return c_vp(self.buf.ptr + 8 * j * self.slab)
+
+    def dot(self, T, ns=None, j0=0):
+        """H[j, c] = S_j[:, c] . T[:, c]  for j in [j0, j0+ns)"""
+        ns = self.ns - j0 if ns is None else ns
+        H = np.empty((ns, self.k))
+        if ns > 0:
+            call("eigd_stack_dot", self.ctx.h, self.n, self.k, ns, self.slab_ptr(j0), self.slab, T.ptr, T.ld, hptr(H))
+        return H
+
+    def axpy_into(self, T, H, alpha=1.0, j0=0):
+        """T[:, c] += alpha * sum_j S_{j0+j}[:, c] H[j, c]"""
+        H = np.ascontiguousarray(H, dtype=np.float64).reshape(-1, self.k)
+        ns = H.shape[0]
+        step = max(1, (60 * 1024) // (8 * self.k))
+        for a in range(0, ns, step):
+            b = min(ns, a + step)
+            call("eigd_stack_axpy", self.ctx.h, self.n, self.k, b - a, self.slab_ptr(j0 + a), self.slab,
+                 hptr(np.ascontiguousarray(H[a:b])), T.ptr, T.ld, float(alpha))
+        return T
+
+    # k == 1 stacks double as column-major n x ns matrices (the Lanczos basis)
+    def tdot_block(self, X, ns=None):
+        """V[:, :ns]^T X -> host (ns x X.k); only for k == 1 stacks"""
+        assert self.k == 1
+        ns = self.ns if ns is None else ns
+        out = np.empty((ns, X.k))
+        for a0 in range(0, ns, 64):
+            a1 = min(ns, a0 + 64)
+            for b0 in range(0, X.k, 64):
+                b1 = min(X.k, b0 + 64)
+                tmp = np.empty((a1 - a0, b1 - b0))
+                call("eigd_gemm_tn", self.ctx.h, self.n, a1 - a0, b1 - b0, self.slab_ptr(a0), 1, self.slab,
+                     X.cols(b0, b1).ptr, X.ld, hptr(tmp))
+                out[a0:a1, b0:b1] = tmp
+        return out
+
+    def times_into(self, X, Cmat, ns=None, alpha=1.0, beta=0.0):
+        """X = beta X + alpha V[:, :ns] @ C ; only for k == 1 stacks"""
+        assert self.k == 1
+        ns = self.ns if ns is None else ns
+        Cmat = np.ascontiguousarray(Cmat, dtype=np.float64).reshape(ns, X.k)
+        for b0 in range(0, X.k, 64):
+            b1 = min(X.k, b0 + 64)
+            bb = beta
+            for a0 in range(0, ns, 64):
+                a1 = min(ns, a0 + 64)
+                cc = np.ascontiguousarray(Cmat[a0:a1, b0:b1])
+                call("eigd_gemm_nn", self.ctx.h, self.n, a1 - a0, b1 - b0, self.slab_ptr(a0), 1, self.slab, hptr(cc),
+                     X.cols(b0, b1).ptr, X.ld, float(alpha), float(bb))
+                bb = 1.0
+        return X
+
+
+class CSRMatrix:
+    """device copy of a scipy CSR matrix"""
+
+    def __init__(self, ctx, A):
+        from scipy import sparse
+
+        A = sparse.csr_matrix(A)
+        if A.dtype != np.float64:
+            A = A.astype(np.float64)
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("square matrix expected")
+        self.ctx = ctx
+        self.shape = A.shape
+        self.n = A.shape[0]
+        self.nnz = int(A.nnz)
+        ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        ix = np.ascontiguousarray(A.indices, dtype=np.int32)
+        dv = np.ascontiguousarray(A.data, dtype=np.float64)
+        h = c_vp()
+        call("eigd_csr_upload", ctx.h, self.n, self.nnz, hptr(ip), hptr(ix), hptr(dv), C.byref(h))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) is not None and self.ctx.h is not None:
+                _ffi.lib().eigd_mat_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def apply(self, X, Y=None, alpha=1.0, beta=0.0):
+        """Y = alpha A X + beta Y"""
+        if Y is None:
+            Y = self.ctx.empty(X.n, X.k)
+        if X.n != self.n or (Y.n, Y.k) != (X.n, X.k):
+            raise ValueError("shape mismatch in SpMM")
+        call("eigd_spmm", self.h, X.ptr, X.ld, Y.ptr, Y.ld, X.k, float(alpha), float(beta))
+        return Y
+
+    def spmv_bytes(self, k=1):
+        """algorithmic bytes of one product"""
+        if k == 1:
+            return 12.0 * self.nnz + 20.0 * self.n
+        return 12.0 * self.nnz + 4.0 * self.n + 16.0 * self.n * k
+
+
+_I32 = ("perm", "iperm", "f_c0", "f_ns", "f_bs", "f_parent", "f_level", "f_slot", "f_npanels", "border", "rel",
+        "lvl_ptr", "lvl_fronts", "lvl_nsteps", "v_src")
+_I64 = ("f_bptr", "f_foff", "f_voff", "f_ioff", "a_src", "a_dst")
+
+
+class Symbolic:
+    """Host ordering + symbolic multifrontal analysis of a symmetric sparse pattern."""
+
+    SIZE_NAMES = ("n", "nfronts", "nlevels", "nnzL", "front_doubles", "sumd", "maxd", "border_len", "nlower",
+                  "nlaunch_steps", "flops", "maxns")
+
+    def __init__(self, A, leaf_size=0, panel_width=0):
+        from scipy import sparse
+
+        A = sparse.csr_matrix(A)
+        A.sort_indices()
+        self.n = A.shape[0]
+        ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        ix = np.ascontiguousarray(A.indices, dtype=np.int32)
+        h = c_vp()
+        call("eigd_symbolic_create", self.n, hptr(ip), hptr(ix), int(leaf_size), int(panel_width), C.byref(h))
+        self.h = h
+        sz = np.zeros(12, dtype=np.int64)
+        call("eigd_symbolic_sizes", self.h, hptr(sz), 12)
+        self.sizes = dict(zip(self.SIZE_NAMES, (int(v) for v in sz)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) is not None:
+                _ffi.lib().eigd_symbolic_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def array(self, name):
+        s = self.sizes
+        nf = s["nfronts"]
+        lens = {
+            "perm": s["n"], "iperm": s["n"], "border": s["border_len"], "rel": s["border_len"],
+            "lvl_ptr": s["nlevels"] + 1, "lvl_fronts": nf, "lvl_nsteps": s["nlevels"], "v_src": s["sumd"],
+            "f_bptr": nf + 1, "a_src": s["nlower"], "a_dst": s["nlower"],
+        }
+        ln = lens.get(name, nf)
+        if name in _I32:
+            out = np.empty(max(ln, 1), dtype=np.int32)
+            call("eigd_symbolic_get_i32", self.h, name.encode(), hptr(out), ln)
+        elif name in _I64:
+            out = np.empty(max(ln, 1), dtype=np.int64)
+            call("eigd_symbolic_get_i64", self.h, name.encode(), hptr(out), ln)
+        else:
+            raise KeyError(name)
+        return out[:ln]
+
+
+class Factor:
+    """Numeric LL^T factor of a symmetric positive definite CSR matrix on the device."""
+
+    def __init__(self, ctx, A, symbolic=None, leaf_size=0, panel_width=0):
+        from scipy import sparse
+
+        A = sparse.csr_matrix(A)
+        if A.dtype != np.float64:
+            A = A.astype(np.float64)
+        A.sort_indices()
+        self.ctx = ctx
+        self.n = A.shape[0]
+        self.symbolic = symbolic if symbolic is not None else Symbolic(A, leaf_size, panel_width)
+        data = np.ascontiguousarray(A.data, dtype=np.float64)
+        h = c_vp()
+        call("eigd_factor_create", ctx.h, self.symbolic.h, hptr(data), C.byref(h))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) is not None and self.ctx.h is not None:
+                _ffi.lib().eigd_factor_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def refactor(self, A):
+        from scipy import sparse
+
+        A = sparse.csr_matrix(A)
+        A.sort_indices()
+        data = np.ascontiguousarray(A.data, dtype=np.float64)
+        call("eigd_factor_refactor", self.h, hptr(data))
+
+    def solve_inplace(self, X, alpha=1.0):
+        if X.n != self.n:
+            raise ValueError("shape mismatch in factor solve")
+        call("eigd_factor_solve", self.h, X.ptr, X.ld, X.k, float(alpha))
+        return X
+
+    def stats(self):
+        out = np.zeros(4)
+        call("eigd_factor_stats", self.h, hptr(out), 4)
+        return {"nnzL": int(out[0]), "device_bytes": int(out[1]), "flops": float(out[2]), "nfronts": int(out[3])}
+
+    def solve_bytes(self, k):
+        b = C.c_double()
+        call("eigd_factor_solve_bytes", self.h, int(k), C.byref(b))
+        return b.value

@@ -1,0 +1,146 @@
+/*
+ * eigd_hip.h -- C ABI of libeigd_hip.so, the MI355X (gfx950) implementation of the
+ * numerical layer under smdogroup/eigd's adjoint eigenvector-derivative path.
+ *
+ * The reference is pure Python; every flop of its hot path is reached through
+ * scipy/numpy natives.  Each entry point below replaces one of those call-site
+ * classes (citations: file:line in the reference, eigd/eigenvector_derivatives.py
+ * unless another file is named).  The Python host layer (package eigd_amd) binds
+ * these with ctypes and keeps eigd's own class/function surface on top.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (EIGD_E_*); the message of
+ *     the last error on the calling thread is eigd_last_error().
+ *   - `dptr` arguments are DEVICE pointers obtained from eigd_malloc; `h*`
+ *     arguments are HOST pointers borrowed for the duration of the call.
+ *   - dense blocks are row-major "n x k, leading dimension ld" (numpy C order), so a
+ *     numpy (n, N) array is one memcpy away from its device image.
+ *   - a "stack" is `ns` such blocks at a fixed element stride (slab stride): the
+ *     Krylov histories W, Z of sibk/pgmres and the Lanczos basis V (k = 1).
+ *   - one ctx = one device + one stream; calls on one ctx are ordered; functions
+ *     that return host results synchronise the stream before returning.
+ *   - thread-compatible: distinct ctx objects may be used from distinct threads.
+ */
+#ifndef EIGD_HIP_H
+#define EIGD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EIGD_OK 0
+#define EIGD_E_INVALID (-1)  /* bad argument / shape mismatch            */
+#define EIGD_E_HIP (-2)      /* HIP runtime error (no device, OOM, ...)  */
+#define EIGD_E_NOTSPD (-3)   /* shifted matrix not positive definite     */
+#define EIGD_E_INTERNAL (-4) /* violated internal invariant              */
+
+typedef struct eigd_ctx eigd_ctx;
+typedef struct eigd_mat eigd_mat;           /* device CSR matrix                     */
+typedef struct eigd_symbolic eigd_symbolic; /* host ordering + symbolic factorisation */
+typedef struct eigd_factor eigd_factor;     /* device numeric factor                 */
+
+const char* eigd_last_error(void);
+int eigd_version(void);
+
+/* ---- context, memory, transfers ---------------------------------------- */
+int eigd_device_count(int* count);
+int eigd_ctx_create(int device, eigd_ctx** out);
+int eigd_ctx_destroy(eigd_ctx* ctx);
+int eigd_sync(eigd_ctx* ctx);
+int eigd_malloc(eigd_ctx* ctx, size_t bytes, void** dptr);
+int eigd_free(eigd_ctx* ctx, void* dptr);
+int eigd_memset(eigd_ctx* ctx, void* dptr, int value, size_t bytes);
+int eigd_h2d(eigd_ctx* ctx, void* dptr, const void* hsrc, size_t bytes);
+int eigd_d2h(eigd_ctx* ctx, void* hdst, const void* dptr, size_t bytes);
+int eigd_d2d(eigd_ctx* ctx, void* ddst, const void* dsrc, size_t bytes);
+int eigd_mem_info(eigd_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
+/* HIP-event stopwatch on the ctx stream (bench.py roofline timing) */
+int eigd_timer_start(eigd_ctx* ctx);
+int eigd_timer_stop_ms(eigd_ctx* ctx, double* ms);
+
+/* ---- CSR SpMV / SpMM ------------------------------------------------------
+ * replaces scipy _sparsetools csr_matvec / csr_matvecs behind every `A @ x`,
+ * `B @ X` (call sites 255, 260, 263-265, 519, 637, 800, 843-844, 1004-1005,
+ * 1173, 1190-1192, 1250-1252, 1500, 1503).  Y = alpha * A X + beta * Y on
+ * n x k row-major blocks; k = 1 is the LDS-staged CSR-stream SpMV kernel, whose
+ * per-row summation order is scipy's (bit-identical result for alpha=1, beta=0). */
+int eigd_csr_upload(eigd_ctx* ctx, int n, int64_t nnz, const int32_t* hindptr, const int32_t* hindices,
+                    const double* hdata, eigd_mat** out);
+int eigd_csr_update_values(eigd_mat* A, const double* hdata);
+int eigd_mat_free(eigd_mat* A);
+int eigd_spmm(eigd_mat* A, const double* dX, int ldx, double* dY, int ldy, int k, double alpha, double beta);
+
+/* ---- sparse shift-invert factorisation ------------------------------------
+ * replaces SuperLU behind SpLuOperator (11-23): splu(mat) -> analyse + factor,
+ * lu.solve(x) -> eigd_factor_solve.  The matrix must be symmetric; it is given as
+ * full CSR (== CSC).  Ordering (nested dissection on the compressed graph),
+ * elimination tree, supernodes and all index maps are host C++ (eigd_symbolic);
+ * the multifrontal LL^T numeric factorisation and the level-scheduled multi-RHS
+ * triangular sweeps are gfx950 kernels.                                          */
+int eigd_symbolic_create(int n, const int32_t* hindptr, const int32_t* hindices, int leaf_size, int panel_width,
+                         eigd_symbolic** out);
+int eigd_symbolic_free(eigd_symbolic* s);
+/* sizes: [0]=n [1]=nfronts [2]=nlevels [3]=nnz(L) incl. diagonal blocks [4]=front buffer doubles
+ *        [5]=sum of front dimensions [6]=max front dimension [7]=border entries [8]=lower nnz of A
+ *        [9]=number of (level, step) launches [10]=flops of the numeric factorisation [11]=max columns in a front */
+int eigd_symbolic_sizes(eigd_symbolic* s, int64_t* out, int nout);
+/* copy-out of the symbolic arrays (tests emulate the numeric phase in numpy from these) */
+int eigd_symbolic_get_i32(eigd_symbolic* s, const char* name, int32_t* out, int64_t cap);
+int eigd_symbolic_get_i64(eigd_symbolic* s, const char* name, int64_t* out, int64_t cap);
+
+int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* s, const double* hdata /* CSR values, full matrix */,
+                       eigd_factor** out);
+int eigd_factor_refactor(eigd_factor* f, const double* hdata);
+int eigd_factor_free(eigd_factor* f);
+/* X (n x k row-major, ld) <- alpha * M^{-1} X ; any k >= 1 (processed in column blocks of <= 32) */
+int eigd_factor_solve(eigd_factor* f, double* dX, int ldx, int k, double alpha);
+/* stats: [0]=nnz(L) [1]=device bytes held [2]=factor flops [3]=min pivot*1e300? (unused) */
+int eigd_factor_stats(eigd_factor* f, double* out, int nout);
+/* bytes of L streamed by one k-column solve (algorithmic, for the roofline) */
+int eigd_factor_solve_bytes(eigd_factor* f, int k, double* bytes);
+
+/* ---- dense panel kernels ---------------------------------------------------
+ * replace the BLAS calls numpy makes for the tall-skinny products, projections,
+ * Gram-Schmidt sweeps and axpy soups of the path.                               */
+
+/* C (ku x kx, HOST, row-major) = U^T X.  U(r, a) = dU[r*rsu + a*csu] (row-major block: rsu=ld,
+ * csu=1; Lanczos basis stored as k=1 stack: rsu=1, csu=slab stride).  X n x kx row-major.
+ * sites: V.T @ Phib 502/510/620, Phi.T @ R 810/989/1180, W.T @ R 1283, _project 28      */
+int eigd_gemm_tn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu, const double* dX,
+                 int ldx, double* hC);
+/* X (n x kx) = beta * X + alpha * U C, C (ku x kx) given on the HOST.
+ * sites: V @ Y0 1648, B @ V @ (...) 519, Z @ y 1028/1277/1301, Vb @ (...) 678, _project 29   */
+int eigd_gemm_nn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu, const double* hC,
+                 double* dX, int ldx, double alpha, double beta);
+/* fused oblique projector X <- X - U (V^T X), coefficient matrix stays on the device (26-30) */
+int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv, double* dX,
+                 int ldx);
+/* column-wise dots  out[c] = sum_r X[r,c] Y[r,c]  (HOST out, length k); inner products / norms
+ * of 1157-1158, 1219, 1233, 1259, 1504, 1537 batched over the modes                     */
+int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout);
+/* out[r,c] = sum_t coef[t*k + c] * X_t[r,c], nterms <= 4, out may alias any X_t
+ * (the w-vector / residual assembly of 96-134, 807-809, 1189-1192, axpys 851-860)      */
+int eigd_lincomb(eigd_ctx* ctx, int n, int k, double* dOut, int ldo, int nterms, const double* const* dXs,
+                 const int* ldxs, const double* hcoef);
+/* batched Gram-Schmidt against a stack of ns slabs (each n x k, ld = k, element stride `slab`):
+ *   stack_dot : hH[j*k + c] = sum_r S_j[r,c] T[r,c]            (1229, 1255, 1013, 1530)
+ *   stack_axpy: T[r,c] += alpha * sum_j S_j[r,c] hH[j*k + c]    (1230, 1256, 1014, 1531, 1277) */
+int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, const double* dT, int ldt,
+                   double* hH);
+int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, const double* hH, double* dT,
+                    int ldt, double alpha);
+/* copy an n x k block between buffers with different leading dimensions / column offsets */
+int eigd_copy_block(eigd_ctx* ctx, int n, int k, const double* dSrc, int lds, double* dDst, int ldd);
+/* gather columns: Dst[r, j] = Src[r, cols[j]] (compaction of the active modes) */
+int eigd_gather_cols(eigd_ctx* ctx, int n, int kdst, const double* dSrc, int lds, const int32_t* hcols, double* dDst,
+                     int ldd);
+int eigd_scatter_cols(eigd_ctx* ctx, int n, int ksrc, const double* dSrc, int lds, const int32_t* hcols, double* dDst,
+                      int ldd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EIGD_HIP_H */

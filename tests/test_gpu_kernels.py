@@ -1,0 +1,214 @@
+"""
+GPU parity of every C-ABI kernel against numpy / scipy on seeded inputs.
+Bit-exact where the arithmetic order is the reference's (SpMV), tight tolerances elsewhere.
+"""
+import numpy as np
+import pytest
+from scipy import sparse
+from scipy.sparse.linalg import splu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from eigd_amd.device import default_context
+
+    return default_context()
+
+
+def grid_matrix(nx, ny, dof=2, seed=0):
+    from test_symbolic_cpu import grid_matrix as g
+
+    return g(nx, ny, dof, seed)
+
+
+def relerr(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("nx,dof", [(37, 2), (120, 1), (200, 2)])
+def test_spmv_bit_exact_vs_scipy(ctx, nx, dof):
+    from eigd_amd.device import CSRMatrix
+
+    A = grid_matrix(nx, nx + 3, dof, seed=nx)
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=A.shape[0])
+    dA = CSRMatrix(ctx, A)
+    y = dA.apply(ctx.from_host(x)).get()[:, 0]
+    assert np.array_equal(y, A @ x)  # same summation order, separately rounded mul/add
+    # alpha / beta form
+    y0 = rng.normal(size=A.shape[0])
+    Y = ctx.from_host(y0)
+    dA.apply(ctx.from_host(x), Y, alpha=-0.5, beta=2.0)
+    assert relerr(Y.get()[:, 0], -0.5 * (A @ x) + 2.0 * y0) < 1e-15
+
+
+def test_spmv_long_rows_and_empty_rows(ctx):
+    from eigd_amd.device import CSRMatrix
+
+    rng = np.random.default_rng(2)
+    n = 5000
+    A = sparse.random(n, n, density=0.002, random_state=3, format="lil")
+    A[7, :] = rng.normal(size=n)          # one dense row (longer than an LDS tile)
+    A[11, :] = 0.0                        # an empty row
+    A = A.tocsr()
+    x = rng.normal(size=n)
+    y = CSRMatrix(ctx, A).apply(ctx.from_host(x)).get()[:, 0]
+    assert relerr(y, A @ x) < 1e-13
+
+
+@pytest.mark.parametrize("k", [2, 3, 6, 13, 32, 40, 70])
+def test_spmm_matches_scipy(ctx, k):
+    from eigd_amd.device import CSRMatrix
+
+    A = grid_matrix(61, 47, 2, seed=k)
+    rng = np.random.default_rng(k)
+    X = rng.normal(size=(A.shape[0], k))
+    Y = CSRMatrix(ctx, A).apply(ctx.from_host(X)).get()
+    assert np.array_equal(Y, A @ X)
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (257, 1), (10007, 5), (50000, 32), (4099, 64)])
+def test_column_kernels(ctx, n, k):
+    rng = np.random.default_rng(n + k)
+    X, Y, Z = rng.normal(size=(n, k)), rng.normal(size=(n, k)), rng.normal(size=(n, k))
+    dX, dY, dZ = ctx.from_host(X), ctx.from_host(Y), ctx.from_host(Z)
+    assert np.allclose(dX.coldot(dY), np.einsum("ij,ij->j", X, Y), rtol=1e-12, atol=1e-12 * n)
+    assert np.allclose(dX.colnorms(), np.linalg.norm(X, axis=0), rtol=1e-13)
+    c1, c2 = rng.normal(size=k), rng.normal(size=k)
+    out = ctx.empty(n, k).assign_lincomb([(c1, dX), (c2, dY), (-1.0, dZ)])
+    assert relerr(out.get(), X * c1 + Y * c2 - Z) < 1e-15
+    dX.assign_lincomb([(2.0, dX), (1.0, dY)])  # aliasing output
+    assert relerr(dX.get(), 2.0 * X + Y) < 1e-15
+
+
+@pytest.mark.parametrize("n,ku,kx", [(3000, 1, 1), (20011, 6, 6), (70001, 32, 32), (5003, 13, 64), (9001, 64, 5), (3001, 70, 33)])
+def test_tall_skinny_products_and_projection(ctx, n, ku, kx):
+    rng = np.random.default_rng(ku * 100 + kx)
+    U, V, X = rng.normal(size=(n, ku)), rng.normal(size=(n, ku)), rng.normal(size=(n, kx))
+    dU, dV, dX = ctx.from_host(U), ctx.from_host(V), ctx.from_host(X)
+    C = dU.tdot(dX)
+    assert relerr(C, U.T @ X) < 1e-13
+    Cm = rng.normal(size=(ku, kx))
+    out = dX.copy().add_product(dU, Cm, alpha=0.7, beta=-1.3)
+    assert relerr(out.get(), -1.3 * X + 0.7 * U @ Cm) < 1e-14
+    out0 = ctx.empty(n, kx).add_product(dU, Cm, alpha=1.0, beta=0.0)  # beta = 0 must ignore garbage
+    assert relerr(out0.get(), U @ Cm) < 1e-14
+    P = dX.copy().project(dU, dV)
+    assert relerr(P.get(), X - U @ (V.T @ X)) < 1e-13
+    # column views with a leading dimension
+    if kx >= 4:
+        sub = dX.cols(1, 3)
+        assert np.array_equal(sub.get(), X[:, 1:3])
+        assert relerr(dU.tdot(sub), U.T @ X[:, 1:3]) < 1e-13
+
+
+@pytest.mark.parametrize("n,k,ns", [(5000, 1, 1), (20001, 1, 37), (30011, 8, 9), (10007, 32, 21), (4001, 5, 50)])
+def test_stack_kernels(ctx, n, k, ns):
+    rng = np.random.default_rng(ns)
+    S = rng.normal(size=(ns, n, k))
+    T = rng.normal(size=(n, k))
+    st = ctx.stack(ns + 2, n, k)
+    for j in range(ns):
+        st[j].set(S[j])
+    dT = ctx.from_host(T)
+    H = st.dot(dT, ns=ns)
+    Href = np.einsum("jrc,rc->jc", S, T)
+    assert np.allclose(H, Href, rtol=1e-12, atol=1e-11 * np.sqrt(n))
+    st.axpy_into(dT, Href, alpha=-1.0)
+    assert relerr(dT.get(), T - np.einsum("jrc,jc->rc", S, Href)) < 1e-13
+    if k == 1:  # column-major view of a k = 1 stack: V^T X and V @ C
+        X = rng.normal(size=(n, 7))
+        V = S[:, :, 0].T  # n x ns
+        assert relerr(st.tdot_block(ctx.from_host(X), ns=ns), V.T @ X) < 1e-12
+        Cm = rng.normal(size=(ns, 7))
+        out = st.times_into(ctx.empty(n, 7), Cm, ns=ns)
+        assert relerr(out.get(), V @ Cm) < 1e-13
+
+
+def test_gather_scatter_columns(ctx):
+    rng = np.random.default_rng(9)
+    X = rng.normal(size=(7001, 12))
+    dX = ctx.from_host(X)
+    cols = [3, 0, 11, 7]
+    G = dX.gather_cols(cols)
+    assert np.array_equal(G.get(), X[:, cols])
+    Z = ctx.zeros(7001, 12)
+    G.scatter_cols_into(Z, cols)
+    ref = np.zeros_like(X)
+    ref[:, cols] = X[:, cols]
+    assert np.array_equal(Z.get(), ref)
+
+
+@pytest.mark.parametrize("nx,ny,dof,leaf,pw", [(9, 7, 2, 8, 8), (31, 29, 2, 16, 16), (64, 64, 2, 48, 64), (150, 131, 1, 32, 64), (200, 200, 2, 0, 0)])
+def test_factor_solve_matches_superlu(ctx, nx, ny, dof, leaf, pw):
+    from eigd_amd.device import Factor
+
+    A = grid_matrix(nx, ny, dof, seed=nx + ny)
+    n = A.shape[0]
+    F = Factor(ctx, A, leaf_size=leaf, panel_width=pw)
+    lu = splu(A.tocsc())
+    rng = np.random.default_rng(0)
+    for k in (1, 3, 8, 13, 32, 45):
+        B = rng.normal(size=(n, k))
+        X = F.solve_inplace(ctx.from_host(B)).get()
+        Xref = lu.solve(B)
+        assert relerr(X, Xref) < 1e-11, k
+        assert np.linalg.norm(A @ X - B) / np.linalg.norm(B) < 1e-12, k
+    # alpha and strided views
+    B = rng.normal(size=(n, 6))
+    dB = ctx.from_host(B)
+    F.solve_inplace(dB.cols(2, 5), alpha=-1.0)
+    out = dB.get()
+    assert np.array_equal(out[:, :2], B[:, :2]) and np.array_equal(out[:, 5:], B[:, 5:])
+    assert relerr(out[:, 2:5], -lu.solve(B[:, 2:5])) < 1e-11
+    # sweeps are deterministic
+    X1 = F.solve_inplace(ctx.from_host(B)).get()
+    X2 = F.solve_inplace(ctx.from_host(B)).get()
+    assert np.array_equal(X1, X2)
+
+
+def test_factor_column_independence_and_refactor(ctx):
+    """a column's solution does not depend on the width of the block it is solved in"""
+    from eigd_amd.device import Factor
+
+    A = grid_matrix(50, 41, 2, seed=4)
+    F = Factor(ctx, A)
+    rng = np.random.default_rng(3)
+    B = rng.normal(size=(A.shape[0], 32))
+    Xall = F.solve_inplace(ctx.from_host(B)).get()
+    X4 = F.solve_inplace(ctx.from_host(B[:, 4:8])).get()
+    assert np.array_equal(Xall[:, 4:8], X4)
+    A2 = A + sparse.identity(A.shape[0]) * 0.5
+    F.refactor(A2.tocsr())
+    X = F.solve_inplace(ctx.from_host(B)).get()
+    assert np.linalg.norm(A2 @ X - B) / np.linalg.norm(B) < 1e-12
+
+
+def test_factor_rejects_indefinite(ctx):
+    from eigd_amd._ffi import NotPositiveDefiniteError
+    from eigd_amd.device import Factor
+
+    A = grid_matrix(20, 20, 1, seed=1)
+    Aind = (A - sparse.identity(A.shape[0]) * 100.0).tocsr()
+    with pytest.raises(NotPositiveDefiniteError):
+        Factor(ctx, Aind)
+
+
+def test_fem_like_ill_conditioned_factor(ctx):
+    """Q4 plate-like stencil with a 1e6 stiffness contrast (SIMP void/solid), solved to SuperLU accuracy"""
+    from eigd_amd.device import Factor
+
+    nx = 80
+    K = grid_matrix(nx, nx, 2, seed=8)
+    rng = np.random.default_rng(8)
+    s = 10.0 ** rng.uniform(-3, 3, size=K.shape[0])
+    D = sparse.diags(np.sqrt(s))
+    A = (D @ K @ D).tocsr()
+    A.sort_indices()
+    F = Factor(ctx, A)
+    B = rng.normal(size=(A.shape[0], 4))
+    X = F.solve_inplace(ctx.from_host(B)).get()
+    Xref = splu(A.tocsc()).solve(B)
+    assert relerr(X, Xref) < 1e-9
