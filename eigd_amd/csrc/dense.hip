@@ -4,7 +4,7 @@
 // All blocks are n x k row-major (numpy C order), n ~ 1e6, k <= 64.  Every kernel is a
 // single streaming pass over its operands (HBM bound); cross-workgroup sums go through a
 // partial-sum slab that a second small kernel adds in a FIXED order, so results do not
-// depend on scheduling (bitwise reproducible, also between 1-GPU and mode-sharded runs).
+// depend on scheduling (run-to-run bitwise reproducible for a given block shape).
 #include <algorithm>
 
 #include "common.h"

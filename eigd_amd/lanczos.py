@@ -1,0 +1,512 @@
+"""
+Eigen-solvers with eigd's call surface, driven on the MI355X:
+
+  BasicLanczos  (reference eigd/eigenvector_derivatives.py:1331-1870)
+  IRAM          (reference 1873-2207 + eigd/arpack.py:24-101, 104-442)
+
+Per Lanczos step the device does one k=1 triangular sweep, SpMVs with B, and a classical
+Gram-Schmidt pass (applied twice) against the stored basis in the B inner product.  The
+basis V and B V stay resident in HBM as k=1 stacks; only the m x m tridiagonal work
+(np.linalg.eigh, sorting, convergence tests) runs on the host, as in the reference.
+
+IRAM is a thick-restart Lanczos: ARPACK's implicit restart is replaced by the mathematically
+equivalent explicit restart with the wanted Ritz vectors, producing the same kind of output
+the reference extracts from ARPACK's work arrays -- a B-orthonormal basis V (n x m) and a
+symmetric projected matrix T (m x m) with  OP V = V T + f e_m^T  -- which is the only property
+the Lanczos adjoint approximation uses.  T is tridiagonal apart from
+the arrow rows of the last restart.
+"""
+
+import warnings
+
+import numpy as np
+from scipy.sparse.linalg import aslinearoperator
+
+from . import adjoint as adj
+from .adjoint import DeviceProblem, _is_close
+from .device import DeviceBlock, default_context
+from .operators import SpLuOperator
+
+METHODS = ("pcpg", "pgmres", "sibk", "laa", "dl")
+
+
+def ritz_to_eigs(theta, sigma, mode):
+    """undo the spectral transformation and give the sort order (ref 1432-1437, 1960-1965)"""
+    if mode == "normal":
+        lam = 1.0 / theta + sigma
+        return lam, np.argsort(lam)
+    lam = sigma * theta / (theta - 1.0)
+    return lam, np.argsort(-1.0 / lam)
+
+
+def _check_shapes(A, B, factor):
+    n = A.shape[1]
+    if A.shape != (n, n):
+        raise ValueError(f"A must have dimensions ({n},{n})")
+    if B.shape != (n, n):
+        raise ValueError(f"B must have dimensions ({n},{n})")
+    if factor.shape != (n, n):
+        raise ValueError(f"Factorized operator must have dimensions ({n},{n})")
+    return n
+
+
+class _LanczosDevice:
+    """basis storage + the B-inner-product Gram-Schmidt step shared by both solvers"""
+
+    def __init__(self, prob, nvec):
+        self.prob = prob
+        self.ctx = prob.ctx
+        self.n = prob.n
+        self.V = self.ctx.stack(nvec, self.n, 1)
+        self.BV = self.ctx.stack(nvec, self.n, 1)
+        self.w = self.ctx.empty(self.n, 1)
+
+    def normalize_into(self, v, j):
+        """V[j] = v / ||v||_B, BV[j] = B v / ||v||_B ; returns the norm"""
+        self.prob.opB.apply(v, self.w)
+        nrm = float(np.sqrt(v.coldot(self.w)[0]))
+        self.V[j].assign_lincomb([(1.0 / nrm, v)])
+        self.BV[j].assign_lincomb([(1.0 / nrm, self.w)])
+        return nrm
+
+    def orthogonalize(self, v, ns):
+        """v <- v - V[:, :ns] (BV[:, :ns]^T v), twice; returns the summed coefficients (ns,)"""
+        h1 = self.BV.dot(v, ns=ns)
+        self.V.axpy_into(v, h1, alpha=-1.0)
+        h2 = self.BV.dot(v, ns=ns)
+        self.V.axpy_into(v, h2, alpha=-1.0)
+        return (h1 + h2)[:, 0]
+
+    def apply_op(self, j, out):
+        """out = factor(B V[j])"""
+        out.copy_from(self.BV[j])
+        self.prob.fac(out)
+        return out
+
+    def basis_to_host(self, m):
+        from ._ffi import call, hptr
+
+        Vt = np.empty((m, self.n))
+        call("eigd_d2h", self.ctx.h, hptr(Vt), self.V.ptr, 8 * self.n * m)
+        return np.ascontiguousarray(Vt.T)
+
+
+class _AdjointAPI:
+    """solve_adjoint / eval_adjoint_residual_norm / add_total_derivative (ref 1652-1870, 1988-2207)"""
+
+    # subclasses provide: _lamN(), _warn_dl(), self._dev (LanczosDevice), self._m, self.Y, self.theta,
+    # self.indices, self.T, self.sigma, self.mode, self.eig_atol, self._prob
+
+    @property
+    def V(self):
+        """Lanczos basis as a numpy array (downloaded on first use)"""
+        if self._V_host is None:
+            self._V_host = self._dev.basis_to_host(self._nV)
+        return self._V_host
+
+    @V.setter
+    def V(self, value):
+        self._V_host = None if value is None else np.asarray(value)
+        if value is not None and getattr(self, "_dev", None) is not None:
+            # a caller replaced the basis: mirror it on the device
+            Vh = np.asarray(value)
+            from ._ffi import call, hptr
+
+            nv = min(Vh.shape[1], self._dev.V.ns)
+            Vt = np.ascontiguousarray(Vh[:, :nv].T)
+            call("eigd_h2d", self._dev.ctx.h, self._dev.V.ptr, hptr(Vt), 8 * self._dev.n * nv)
+
+    def _sync_phi(self):
+        """the eigenvectors used by the adjoint stage are whatever self.Phi holds now"""
+        if self._phi_token is not self.Phi:
+            self._prob.set_phi(Phi_host=self.Phi)
+            self._phi_token = self.Phi
+
+    def _mode_columns(self, N, comm):
+        if comm is None or comm.size == 1:
+            return None
+        return np.arange(comm.rank, N, comm.size)
+
+    def solve_adjoint(self, Phib, method="sibk", psi=None, rtol=1e-10, atol=1e-30, lanczos_guess=True, comm=None,
+                      **kwargs):
+        """
+        Same contract as the reference.  Extras: ``Phib`` may be a device block (then ``psi`` comes
+        back as a device block); ``comm`` (rank/size/allreduce_sum) shards the independent per-mode
+        solves -- the returned ``psi`` then holds this rank's columns and zeros elsewhere.
+        """
+        n = self.A.shape[1]
+        lam = np.asarray(self._lamN(), dtype=float)
+        N = len(lam)
+        if method not in METHODS:
+            raise ValueError(f"Unknown method {method!r}")
+        if psi is not None and psi.shape != (n, N):
+            raise ValueError(f"Initial guess must have the shape ({n},{N})")
+        on_device = isinstance(Phib, DeviceBlock)
+        if tuple(Phib.shape) != (n, N):
+            raise ValueError(f"Right-hand-side must have the shape ({n},{N})")
+        if method == "dl":
+            self._warn_dl()
+            lanczos_guess = False
+        prob, ctx = self._prob, self._prob.ctx
+        self._sync_phi()
+        dPhib = Phib if on_device else ctx.from_host(Phib)
+        seq_sibk = method == "sibk" and (kwargs.get("bs_target", 1) != 1 or kwargs.get("update_guess", False))
+        cols = None if (method == "dl" or seq_sibk) else self._mode_columns(N, comm)
+        sel = np.arange(N) if cols is None else cols
+        lam_c = lam[sel]
+        dPhib_c = dPhib if cols is None else dPhib.gather_cols(cols)
+        Y, theta, indices = np.asarray(self.Y), np.asarray(self.theta), np.asarray(self.indices)
+        if lanczos_guess or method == "laa":
+            psi_c = adj._laa_device(prob, self._dev.V, self._m, dPhib, lam, self.sigma, Y, theta, indices, True,
+                                    self.mode, cols=cols)
+        else:
+            psi_c = ctx.zeros(n, len(sel))
+        data = {}
+        eig_atol = self.eig_atol
+        kw = dict(kwargs)
+        callback = kw.pop("callback", None)
+        rnorm0 = adj._rnorm0(dPhib)
+        G = None
+        if method == "sibk":
+            maxiter = kw.pop("maxiter", 50)
+            nrestart = kw.pop("nrestart", 2)
+            bs_target = kw.pop("bs_target", 1)
+            update_guess = kw.pop("update_guess", False)
+            kw.pop("eig_atol", None)
+            if kw:
+                raise TypeError(f"sibk() got unexpected keyword arguments {sorted(kw)}")
+            G = -prob.Phi.tdot(dPhib)
+            if seq_sibk:
+                self.last_info = adj._sibk_sequential(prob, dPhib_c, psi_c, lam_c, self.sigma, rtol, atol, maxiter,
+                                                      bs_target, update_guess, callback, nrestart)
+            else:
+                self.last_info = adj._sibk_device(prob, dPhib_c, psi_c, lam_c, self.sigma, rtol, atol, maxiter,
+                                                  nrestart, callback, rnorm0=rnorm0)
+        elif method == "pgmres":
+            maxiter = kw.pop("maxiter", 50)
+            if kw:
+                raise TypeError(f"pgmres() got unexpected keyword arguments {sorted(kw)}")
+            Gc, self.last_info = adj._pgmres_device(prob, dPhib_c, psi_c, lam_c, rtol, atol, maxiter, callback,
+                                                    rnorm0=rnorm0)
+            G = self._assemble_G(Gc, sel, N, comm)
+        elif method == "pcpg":
+            maxiter = kw.pop("maxiter", 100)
+            reset = kw.pop("reset", 25)
+            if kw:
+                raise TypeError(f"pcpg() got unexpected keyword arguments {sorted(kw)}")
+            Gc, self.last_info = adj._pcpg_device(prob, dPhib_c, psi_c, lam_c, rtol, atol, maxiter, reset, callback,
+                                                  rnorm0=rnorm0)
+            G = self._assemble_G(Gc, sel, N, comm)
+        elif method == "laa":
+            G = -prob.Phi.tdot(dPhib)                      # ref 1772-1779 / 2109-2116 (G from Phib)
+        elif method == "dl":
+            if self.T is None:
+                raise ValueError("dl needs the Lanczos matrix T")
+            psi_c, data = adj._dl_device(prob, dPhib, lam, self.sigma, indices, self._dev.V, self._m,
+                                         np.asarray(self.T), Y, theta, eig_atol, self.mode)
+        if G is not None:
+            Cc, data = adj.correction_coefficients(lam, G, eig_atol, self.mode)
+            adj._apply_correction(psi_c, prob.Phi, Cc, cols=cols)
+        if cols is None:
+            dpsi = psi_c
+        else:
+            dpsi = ctx.zeros(n, N)
+            psi_c.scatter_cols_into(dpsi, cols)
+        if on_device:
+            return dpsi, data
+        return dpsi.get(), data
+
+    @staticmethod
+    def _assemble_G(Gc, sel, N, comm):
+        G = np.zeros((N, N))
+        G[:, sel] = Gc
+        if comm is not None and comm.size > 1:
+            G = comm.allreduce_sum(G)
+        return G
+
+    def eval_adjoint_residual_norm(self, Phib, psi, b_ortho=False):
+        self._sync_phi()
+        ctx = self._prob.ctx
+        dPhib = Phib if isinstance(Phib, DeviceBlock) else ctx.from_host(Phib)
+        dpsi = psi if isinstance(psi, DeviceBlock) else ctx.from_host(psi)
+        return adj._residual_norm_device(self._prob, np.asarray(self._lamN(), dtype=float), dPhib, dpsi, b_ortho)
+
+    def add_total_derivative(self, lamb, Phib, psi, dAdx, dBdx, dfdx, adj_corr_data={}, deriv_type="vector",
+                             comm=None):
+        """ref 1830-1870 / 2167-2207; with ``comm`` each rank sums its own modes, then one all-reduce of dfdx"""
+        lam = np.asarray(self._lamN(), dtype=float)
+        n, N = self.A.shape[1], len(lam)
+        for arr, what in ((psi, "Eigenvectors"), (Phib, "Right-hand-side")):
+            if tuple(arr.shape) != (n, N):
+                raise ValueError(f"{what} must have the shape ({n},{N})")
+        if deriv_type not in ("vector", "tensor"):
+            return dfdx
+        self._sync_phi()
+        ctx = self._prob.ctx
+        dPhib = Phib if isinstance(Phib, DeviceBlock) else ctx.from_host(Phib)
+        dpsi = psi if isinstance(psi, DeviceBlock) else ctx.from_host(psi)
+        cols = self._mode_columns(N, comm)
+        if cols is None:
+            return adj._total_derivative_device(self._prob.Phi, dPhib, dpsi, lam, lamb, dAdx, dBdx, dfdx,
+                                                adj_corr_data, self.mode, deriv_type, None, Phi_host=self.Phi)
+        part = np.zeros_like(dfdx)
+        adj._total_derivative_device(self._prob.Phi, dPhib, dpsi, lam, lamb, dAdx, dBdx, part, adj_corr_data,
+                                     self.mode, deriv_type, cols, Phi_host=self.Phi)
+        part = comm.allreduce_sum(part)
+        dfdx += part
+        return dfdx
+
+
+class BasicLanczos(_AdjointAPI):
+    """Un-restarted shift-invert Lanczos with B-orthogonalisation (ref 1331-1650); real dtype."""
+
+    def __init__(self, N=10, m=60, tol=1e-14, Ntarget=None, eig_atol=1e-5, mode="normal", ortho_type="full",
+                 ctx=None):
+        self.N = N
+        self.m_max = m
+        self.tol = tol
+        self.Ntarget = Ntarget
+        self.eig_atol = eig_atol
+        self.mode = mode
+        self.ortho_type = ortho_type
+        self._ctx = ctx
+        if self.Ntarget is not None and not isinstance(self.Ntarget, int):
+            raise ValueError("Ntarget must be an integer or None")
+        if ortho_type not in ("full", "selective"):
+            raise ValueError(f"Unknown ortho_type {ortho_type!r}")
+        if mode not in ("normal", "buckling"):
+            raise ValueError(f"Unknown mode {mode!r}")
+        self._V_host = None
+        self._phi_token = None
+        self.T = None
+
+    def _lamN(self):
+        return self.lam0
+
+    def _warn_dl(self):
+        pass
+
+    def _reduced(self, m):
+        """eigh of the leading m x m tridiagonal + sort (ref 1416-1439)"""
+        T = np.diag(self.alpha[:m]) + np.diag(self.beta[: m - 1], 1) + np.diag(self.beta[: m - 1], -1)
+        theta, Y = np.linalg.eigh(T)
+        lam, indices = ritz_to_eigs(theta, self.sigma, self.mode)
+        return theta, Y, T, lam, indices
+
+    @staticmethod
+    def _converged(beta_last, Yrow, N, tol):
+        """leading run of sorted Ritz pairs with |beta y_last| < tol (ref 1441-1451)"""
+        count = 0
+        for e in np.abs(beta_last * Yrow):
+            if e < tol:
+                count += 1
+            else:
+                break
+        return count >= N
+
+    def solve(self, A, B, factor, sigma):
+        n = _check_shapes(A, B, factor)
+        if np.issubdtype(np.dtype(A.dtype), np.complexfloating):
+            raise TypeError("the MI355X path is real (float64); the complex-step check runs on the CPU reference")
+        self.factor = aslinearoperator(factor)
+        self.B = aslinearoperator(B)
+        self.A = aslinearoperator(A)
+        self.sigma = sigma
+        ctx = self._ctx or (factor.ctx if isinstance(factor, SpLuOperator) else default_context())
+        prob = DeviceProblem(ctx, A, B, factor, self.mode)
+        self._prob = prob
+        mm = self.m_max
+        dev = _LanczosDevice(prob, mm + 1)
+        self._dev = dev
+        self.alpha = np.zeros(mm)
+        self.beta = np.zeros(mm)
+
+        v0 = np.random.default_rng(12345).uniform(size=n, low=-1.0, high=1.0)  # ref 1514-1515
+        v = ctx.from_host(v0)
+        dev.normalize_into(v, 0)
+
+        Nchk = self.N if self.Ntarget is None else self.Ntarget
+        self.m = mm
+        S = BS = None
+        for i in range(1, mm + 1):
+            dev.apply_op(i - 1, v)                                         # ref 1524
+            if i > 1:
+                v.assign_lincomb([(1.0, v), (-self.beta[i - 2], dev.V[i - 2])])  # ref 1526
+            if self.ortho_type == "full":
+                h = dev.orthogonalize(v, i)                                # ref 1529-1534
+                self.alpha[i - 1] = h[i - 1]
+            else:
+                j0 = max(0, i - 2)                                         # ref 1563: the two previous vectors
+                h1 = dev.BV.dot(v, ns=i - j0, j0=j0)
+                dev.V.axpy_into(v, h1, alpha=-1.0, j0=j0)
+                self.alpha[i - 1] = h1[-1, 0]
+                if S is not None and S.k > 0:                              # ref 1571-1574
+                    hs = BS.tdot(v)
+                    v.add_product(S, hs, alpha=-1.0, beta=1.0)
+            self.beta[i - 1] = dev.normalize_into(v, i)                    # ref 1537-1538
+            if i >= 2:
+                theta, Y, T, lam, indices = self._reduced(i)
+                Y0 = Y[:, indices]
+                if self._converged(self.beta[i - 1], Y0[i - 1, :], Nchk, self.tol):
+                    self.m = i
+                    break
+                if self.ortho_type == "selective":                         # ref 1596-1605
+                    errs = np.abs(self.beta[i - 1] * Y0[i - 1, :])
+                    conv = [j for j in range(i) if errs[j] < np.sqrt(self.tol)]
+                    if conv:
+                        S = ctx.empty(n, len(conv))
+                        dev.V.times_into(S, Y0[:, conv], ns=i)
+                        BS = prob.opB.apply(S)
+                    else:
+                        S = BS = None
+
+        self.theta, self.Y, self.T, self.lam, self.indices = self._reduced(self.m)
+        if self.Ntarget is not None:                                       # ref 1615-1625
+            self.N = self.Ntarget
+            while self.N < self.m and _is_close(self.lam[self.indices[self.N - 1]], self.lam[self.indices[self.N]],
+                                                self.eig_atol):
+                self.N += 1
+        elif _is_close(self.lam[self.indices[self.N - 1]], self.lam[self.indices[self.N]], self.eig_atol):
+            warnings.warn(f"BasicLanczos: Ritz values {self.N} and {self.N+1} are numerically repeated.")
+        sel = self.indices[: self.N]
+        self.lam0 = self.lam[sel]
+        self.Y0 = self.Y[:, sel]
+        self.eig_res = np.abs(self.beta[-1] * self.Y0[-1, :])              # ref 1640-1645
+        self.fail = bool(np.any(self.eig_res > self.tol))
+        dPhi = ctx.empty(n, self.N)
+        dev.V.times_into(dPhi, self.Y0, ns=self.m)                         # ref 1648
+        prob.set_phi(Phi_dev=dPhi)
+        self.Phi = dPhi.get()
+        self._phi_token = self.Phi
+        self._m = self.m
+        self._nV = self.m_max + 1
+        self._V_host = None
+        return self.lam0, self.Phi
+
+
+class IRAM(_AdjointAPI):
+    """
+    Restarted shift-invert Lanczos with the reference's IRAM surface (ref 1873-1986).
+    ``m = max(20, 2N+1, m)`` as the reference (1895-1898); ``tol = 0`` means machine precision,
+    ARPACK's convention (dsaupd).
+    """
+
+    def __init__(self, N=10, m=None, eig_atol=1e-5, tol=0.0, mode="normal", maxiter=None, ctx=None):
+        self.N = N
+        self.m = int(max(20, 2 * N + 1) if m is None else max(20, 2 * N + 1, m))
+        self.tol = tol
+        self.eig_atol = eig_atol
+        self.mode = mode
+        self.maxiter = maxiter
+        self._ctx = ctx
+        if mode not in ("normal", "buckling"):
+            raise ValueError(f"Unknown mode {mode!r}")
+        self._V_host = None
+        self._phi_token = None
+
+    def _lamN(self):
+        return self.lam
+
+    def _warn_dl(self):
+        warnings.warn('Adjoint method "dl" is not recommended for the ARPACK IRAM eigenvalue sovler.')
+
+    def solve(self, A, B, factor, sigma):
+        n = _check_shapes(A, B, factor)
+        if np.issubdtype(np.dtype(A.dtype), np.complexfloating):
+            raise TypeError("Input matrix is not real-valued.")
+        self.factor = aslinearoperator(factor)
+        self.B = aslinearoperator(B)
+        self.A = aslinearoperator(A)
+        self.sigma = sigma
+        ctx = self._ctx or (factor.ctx if isinstance(factor, SpLuOperator) else default_context())
+        prob = DeviceProblem(ctx, A, B, factor, self.mode)
+        self._prob = prob
+        m, k = self.m, self.N
+        if not (k < m <= n):
+            raise ValueError("ncv must be k<ncv<=n")  # scipy's message for the same condition
+        dev = _LanczosDevice(prob, m + 1)
+        self._dev = dev
+        eps = np.finfo(float).eps
+        tol = self.tol if self.tol > 0 else eps
+        eps23 = eps ** (2.0 / 3.0)
+        maxiter = self.maxiter if self.maxiter is not None else 10 * n  # scipy's default for eigsh
+
+        v0 = np.random.default_rng(12345).uniform(size=n, low=-1.0, high=1.0)
+        v = ctx.from_host(v0)
+        dev.normalize_into(v, 0)
+        T = np.zeros((m, m))
+        j0 = 0          # first step to run
+        beta_m = 0.0
+        self.n_restarts = 0
+        scratch = None
+        while True:
+            for j in range(j0, m):
+                dev.apply_op(j, v)
+                h = dev.orthogonalize(v, j + 1)
+                T[: j + 1, j] = h
+                T[j, : j + 1] = h
+                beta = dev.normalize_into(v, j + 1)
+                if j + 1 < m:
+                    T[j + 1, j] = T[j, j + 1] = beta
+                else:
+                    beta_m = beta
+            # keep exactly the structure the recurrence implies: entries above the arrow/tridiagonal are round-off
+            theta, S = np.linalg.eigh(T)
+            order = np.argsort(-np.abs(theta))          # which = "LM"
+            bounds = np.abs(beta_m * S[m - 1, :])
+            wanted = order[:k]
+            conv = bounds[wanted] <= tol * np.maximum(eps23, np.abs(theta[wanted]))
+            nconv = int(np.count_nonzero(conv))
+            if nconv >= k or self.n_restarts >= maxiter:
+                break
+            # thick restart: keep the wanted pairs plus part of the converged unwanted ones (ARPACK dsaup2)
+            keep = min(k + min(nconv, (m - k) // 2), m - 1)
+            keep = max(keep, min(k + 1, m - 1))
+            selk = order[:keep]
+            selk = selk[np.argsort(-theta[selk])]
+            Sk = S[:, selk]
+            if scratch is None:
+                scratch = (ctx.stack(m, n, 1), ctx.stack(m, n, 1))
+            nV, nBV = scratch
+            from ._ffi import call, hptr
+
+            # new basis = V S_k (column-major k=1 stacks): one product per kept vector block
+            for src, dst in ((dev.V, nV), (dev.BV, nBV)):
+                blk = ctx.empty(n, keep)
+                src.times_into(blk, Sk, ns=m)
+                for q in range(keep):
+                    dst[q].copy_from(blk.cols(q, q + 1))
+            for q in range(keep):
+                dev.V[q].copy_from(nV[q])
+                dev.BV[q].copy_from(nBV[q])
+            dev.V[keep].copy_from(dev.V[m])
+            dev.BV[keep].copy_from(dev.BV[m])
+            T = np.zeros((m, m))
+            T[np.arange(keep), np.arange(keep)] = theta[selk]
+            arrow = beta_m * Sk[m - 1, :]
+            # the next step recomputes column `keep` in full (arrow + diagonal) by Gram-Schmidt
+            j0 = keep
+            self._arrow = arrow
+            self.n_restarts += 1
+        if nconv < k:
+            from scipy.sparse.linalg import ArpackNoConvergence
+
+            raise ArpackNoConvergence(f"No convergence ({self.n_restarts} restarts, {nconv}/{k} eigenvectors converged)",
+                                      None, None)
+        self.T = T
+        self.theta, self.Y = np.linalg.eigh(self.T)                        # ref 1958
+        eigs, self.indices = ritz_to_eigs(self.theta, sigma, self.mode)    # ref 1960-1965
+        if _is_close(eigs[self.indices[self.N - 1]], eigs[self.indices[self.N]], self.eig_atol):
+            warnings.warn(f"IRAM: Ritz values {self.N} and {self.N+1} are numerically repeated.")
+        sel = self.indices[: self.N]
+        self.lam = eigs[sel]
+        dPhi = ctx.empty(n, self.N)
+        dev.V.times_into(dPhi, self.Y[:, sel], ns=m)   # Phi = V Y[:, indices[:N]]: signs agree by construction (ref 1976-1984)
+        prob.set_phi(Phi_dev=dPhi)
+        self.Phi = dPhi.get()
+        self._phi_token = self.Phi
+        self.eig_res = np.abs(beta_m * self.Y[m - 1, sel])
+        self._m = m
+        self._nV = m
+        self._V_host = None
+        return self.lam, self.Phi

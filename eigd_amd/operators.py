@@ -1,0 +1,123 @@
+"""
+Operator layer: the drop-in ``SpLuOperator`` (reference eigd/eigenvector_derivatives.py:11-23)
+and the adapters that let the device drivers apply A, B and ``factor`` to device blocks.
+"""
+
+import weakref
+
+import numpy as np
+from scipy import sparse
+from scipy.sparse.linalg import LinearOperator
+
+from .device import CSRMatrix, Factor, Symbolic, default_context
+
+
+class SpLuOperator(LinearOperator):
+    """
+    Shift-invert operator ``x -> mat^{-1} x`` factored and applied on the MI355X.
+
+    Same surface as the reference class (``shape``, ``dtype``, ``count``, callable on
+    ``(n,)`` and ``(n, k)`` numpy arrays).  ``mat`` must be symmetric positive definite,
+    which is what every shift of the reference's examples produces (K - sigma M with sigma
+    below the spectrum, K + sigma G with sigma below the first buckling load); an indefinite
+    matrix raises ``NotPositiveDefiniteError`` (a ``numpy.linalg.LinAlgError``).
+    """
+
+    def __init__(self, mat, ctx=None, symbolic=None, leaf_size=0, panel_width=0, check_symmetry=True):
+        if not sparse.issparse(mat):
+            mat = sparse.csr_matrix(mat)
+        if mat.shape[0] != mat.shape[1]:
+            raise ValueError("expected a square matrix")
+        if np.issubdtype(mat.dtype, np.complexfloating):
+            raise TypeError("complex matrices are not supported by the MI355X factor (complex-step path)")
+        self.ctx = ctx if ctx is not None else default_context()
+        self.shape = mat.shape
+        self.dtype = np.dtype(np.float64)
+        self.count = 0
+        csr = mat.tocsr().astype(np.float64)  # for a symmetric matrix CSC and CSR coincide
+        csr.sort_indices()
+        if check_symmetry:
+            x = np.random.default_rng(0).uniform(-1.0, 1.0, size=csr.shape[0])
+            d = csr @ x - csr.T @ x
+            if np.linalg.norm(d) > 1e-10 * max(np.linalg.norm(csr @ x), 1e-300):
+                raise ValueError("SpLuOperator (MI355X) needs a symmetric matrix")
+        self.factor = Factor(self.ctx, csr, symbolic=symbolic, leaf_size=leaf_size, panel_width=panel_width)
+        self.symbolic = self.factor.symbolic
+
+    # -- device path (used by the drivers) ------------------------------------
+    def solve_device(self, X, alpha=1.0, count=None):
+        """
+        X <- alpha * mat^{-1} X in place on a device block.  ``count`` is the number of columns
+        that carry a live right-hand side (finished modes of a lock-step block are zero columns);
+        the counter then means what the reference's does: applications per mode (ref 19-22).
+        """
+        self.count += X.k if count is None else int(count)
+        return self.factor.solve_inplace(X, alpha)
+
+    def refactor(self, mat):
+        """numeric refactorisation with new values on the same sparsity pattern"""
+        self.factor.refactor(mat.tocsr().astype(np.float64))
+
+    # -- host path (reference call surface) ------------------------------------
+    def _matvec(self, x):
+        x = np.asarray(x)
+        X = self.ctx.from_host(x.astype(np.float64).reshape(self.shape[0], -1))
+        self.solve_device(X)
+        out = X.get()
+        return out[:, 0] if x.ndim == 1 else out
+
+    def _matmat(self, X):
+        return self._matvec(X)
+
+
+# ---------------------------------------------------------------------------
+_csr_cache = weakref.WeakKeyDictionary()
+
+
+class DeviceOperator:
+    """y = A x on device blocks for a scipy sparse matrix (device CSR) or a host LinearOperator."""
+
+    def __init__(self, ctx, A):
+        self.ctx = ctx
+        self.shape = A.shape
+        self.host = None
+        self.csr = None
+        if isinstance(A, CSRMatrix):
+            self.csr = A
+        elif sparse.issparse(A):
+            self.csr = CSRMatrix(ctx, A)
+        elif hasattr(A, "A") and sparse.issparse(getattr(A, "A")):  # scipy MatrixLinearOperator
+            self.csr = CSRMatrix(ctx, A.A)
+        elif isinstance(A, np.ndarray):
+            self.csr = CSRMatrix(ctx, sparse.csr_matrix(A))
+        else:
+            self.host = A  # foreign operator: applied on the host, block copied both ways
+
+    def apply(self, X, Y=None):
+        if self.csr is not None:
+            return self.csr.apply(X, Y)
+        out = np.asarray(self.host @ X.get())
+        if Y is None:
+            return self.ctx.from_host(out)
+        Y.set(out)
+        return Y
+
+
+class FactorApply:
+    """X <- alpha factor(X) on device blocks for our SpLuOperator or any foreign callable."""
+
+    def __init__(self, ctx, factor):
+        self.ctx = ctx
+        self.factor = factor
+        self.native = isinstance(factor, SpLuOperator)
+
+    def __call__(self, X, alpha=1.0, count=None):
+        if self.native:
+            return self.factor.solve_device(X, alpha, count)
+        out = np.asarray(self.factor(X.get()))  # honours a user-supplied operator
+        X.set(alpha * out.reshape(X.n, X.k))
+        return X
+
+
+def is_native_factor(factor):
+    return isinstance(factor, SpLuOperator)
