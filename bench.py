@@ -1,0 +1,336 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark: adjoint eigenvector-derivative modes per second on the 1M-dof buckling
+problem (BASELINE.json configs[2]; SURVEY.md section 8d "C3").
+
+  step   = solve_adjoint(Phib, method="sibk", rtol=1e-10) + add_total_derivative(...)  for N = 32 modes
+           -- the reference's "adjoint solution time" + "total derivative time"
+           (examples/buckling.py:905, 984) -- with every operand already resident in HBM.
+  value  = N * steps / wall time  (whole job; with --gpus G the modes are sharded over the ranks and
+           df/dx is all-reduced once per step: strong scaling of a fixed 32-mode job).
+
+Untimed preamble per rank (reported in the JSON): synthetic K(rho), fundamental path u = K^-1 f,
+G(u), shift selection, factorisation of K + sigma G, the IRAM eigensolve.
+
+  python bench.py [--gpus 1] [--steps 3] [--warmup 1]
+  python -m torch.distributed.run --nproc-per-node G ... bench.py --gpus G ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md), GB/s
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def estimate_first_buckling_load(ctx, dK, dG, Kfac, n, iters=40):
+    """power iteration on K^-1 (-G): the largest mu = 1 / BLF_1 (upper estimate of BLF_1)"""
+    x = ctx.from_host(np.random.default_rng(3).uniform(-1, 1, size=n))
+    t = ctx.empty(n, 1)
+    mu = 0.0
+    for _ in range(iters):
+        dG.apply(x, t, alpha=-1.0)
+        num = float(x.coldot(t)[0])
+        dK.apply(x, t)
+        den = float(x.coldot(t)[0])
+        mu = num / den
+        dG.apply(x, t, alpha=-1.0)
+        Kfac.solve_device(t)
+        nrm = float(t.colnorms()[0])
+        x.assign_lincomb([(1.0 / nrm, t)])
+    return 1.0 / mu
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nx", type=int, default=706)
+    ap.add_argument("--ny", type=int, default=706)
+    ap.add_argument("--modes", type=int, default=32)
+    ap.add_argument("--m", type=int, default=65)
+    ap.add_argument("--rtol", type=float, default=1e-10)
+    ap.add_argument("--cpu-sample", choices=("full", "small", "none"), default="full",
+                    help="CPU baseline: full = SuperLU factor of the same 1M-dof matrix + 1 mode; small = 200k-dof replica")
+    ap.add_argument("--spmv-reps", type=int, default=200)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    comm = None
+    if world > 1:
+        # torch first: its bundled HIP runtime is the one the process then shares with libeigd_hip.so
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ["EIGD_DEVICE"] = str(local_rank)
+        from eigd_amd.comm import TorchDistComm
+
+        comm = TorchDistComm(device=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        log(rank, f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+
+    import eigd_amd as eg
+    from eigd_amd.device import CSRMatrix, ElementBilinear, default_context
+    from eigd_amd.problems import BucklingColumn
+
+    ctx = default_context()
+    N = args.modes
+    timing = {}
+
+    # ------------------------------------------------------------------ problem (untimed preamble)
+    t0 = time.perf_counter()
+    col = BucklingColumn(args.nx, args.ny, Lx=1.0, Ly=1.0, seed=0)  # rhoE ~ U(0.3, 1), default_rng(0)
+    K = col.stiffness()
+    n = K.shape[0]
+    timing["assemble_K_s"] = time.perf_counter() - t0
+    log(rank, f"K assembled: n={n} nnz={K.nnz} ({timing['assemble_K_s']:.1f}s)")
+    t0 = time.perf_counter()
+    Kfac = eg.SpLuOperator(K, ctx=ctx, check_symmetry=False)
+    ctx.sync()
+    timing["factor_K_s"] = time.perf_counter() - t0
+    ur = Kfac(col.f[col.reduced])
+    u = col.full_vector(ur)
+    t0 = time.perf_counter()
+    G = col.geometric_stiffness(u)
+    timing["assemble_G_s"] = time.perf_counter() - t0
+    dK, dG = CSRMatrix(ctx, K), CSRMatrix(ctx, G)
+    blf_est = estimate_first_buckling_load(ctx, dK, dG, Kfac, n)
+    sigma = 0.7 * blf_est
+    log(rank, f"G assembled ({timing['assemble_G_s']:.1f}s); BLF_1 ~ {blf_est:.4f}; shift sigma = {sigma:.4f}")
+    t0 = time.perf_counter()
+    while True:
+        try:
+            mat = (K + sigma * G).tocsr()
+            factor = eg.SpLuOperator(mat, ctx=ctx, symbolic=Kfac.symbolic if mat.nnz == K.nnz else None,
+                                     check_symmetry=False)
+            break
+        except np.linalg.LinAlgError:
+            sigma *= 0.5
+            log(rank, f"shift not below BLF_1, retrying with sigma = {sigma:.4f}")
+    ctx.sync()
+    timing["factor_shifted_s"] = time.perf_counter() - t0
+    fstats = factor.factor.stats()
+    del Kfac
+    t0 = time.perf_counter()
+    solver = eg.IRAM(N=N, m=args.m, mode="buckling", ctx=ctx)
+    lam, Phi = solver.solve(G, K, factor, sigma)
+    ctx.sync()
+    timing["eigensolve_s"] = time.perf_counter() - t0
+    eig_count = factor.count
+    log(rank, f"eigensolve: {timing['eigensolve_s']:.2f}s, {solver.n_restarts} restarts, {eig_count} sweeps; "
+              f"BLF = {lam[:4]} ... {lam[-1]:.4f}")
+
+    rng = np.random.default_rng(1)
+    Phib = rng.uniform(size=(n, N))
+    lamb = rng.uniform(size=N)
+    dPhib = ctx.from_host(Phib)
+    scale = col.dK_scale()
+    dBdx = ElementBilinear(ctx, col.elem_dofs, col.Ke0, scale=scale)            # d(w^T K v)/d rhoE
+    dAdx = ElementBilinear(ctx, col.elem_dofs, col.Ge_unit, scale=col.dG_scale())  # d(w^T G v)/d rhoE at fixed u
+    ndv = col.mesh.nelems
+
+    def step():
+        factor.count = 0
+        dpsi, data = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1,
+                                          comm=comm)
+        dfdx = solver.add_total_derivative(lamb, dPhib, dpsi, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data,
+                                           deriv_type="tensor", comm=comm)
+        return dpsi, data, dfdx
+
+    def fence():
+        ctx.sync()
+        if comm is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            comm.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dpsi, data, dfdx = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        elapsed = comm.allreduce_max(elapsed)
+    adj_count = factor.count
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = N * args.steps / elapsed
+
+    if rank != 0:
+        return
+    # ------------------------------------------------------------------ accuracy of the timed result
+    res, ortho = solver.eval_adjoint_residual_norm(dPhib, dpsi, b_ortho=False) if world == 1 else (None, None)
+    accuracy = {}
+    if res is not None:
+        accuracy["adjoint_residual_max"] = float(np.max(res))
+        accuracy["adjoint_residual_rel_max"] = float(np.max(res) / np.sqrt(np.max(np.sum(Phib**2, axis=0))))
+        accuracy["ortho_max"] = float(np.max(ortho))
+
+    # ------------------------------------------------------------------ roofline of the SpMV kernel (HIP events)
+    x = ctx.from_host(rng.normal(size=n))
+    y = ctx.empty(n, 1)
+    for _ in range(10):
+        dK.apply(x, y)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(args.spmv_reps):
+        dK.apply(x, y)
+    spmv_ms = ctx.timer_stop_ms() / args.spmv_reps
+    spmv_bytes = dK.spmv_bytes(1)
+    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+    roofline = {"kernel": "spmv_stream_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": spmv_bytes, "us_per_launch": round(spmv_ms * 1e3, 2)}
+    # the k-column triangular sweep (the dominant cost of a step), same accounting
+    Xs = ctx.from_host(rng.normal(size=(n, N)))
+    factor.solve_device(Xs)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(5):
+        factor.solve_device(Xs)
+    sweep_ms = ctx.timer_stop_ms() / 5
+    sweep_bytes = factor.factor.solve_bytes(N)
+    sweep = {"ms": round(sweep_ms, 3), "algorithmic_GBs": round(sweep_bytes / sweep_ms / 1e6, 1),
+             "frac_of_peak": round(sweep_bytes / sweep_ms / 1e6 / HBM_PEAK_GBS, 4), "columns": N,
+             "nnzL": fstats["nnzL"]}
+
+    # ------------------------------------------------------------------ CPU baseline (oracle = port of the reference)
+    cpu = None
+    if args.cpu_sample != "none" and world == 1:
+        cpu = cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, dpsi, log)
+
+    out = {
+        "metric": "adjoint_mode_derivatives_per_sec",
+        "value": round(value, 3),
+        "unit": "modes/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "buckling 1M-dof Q4 column (706x706 elements), 32 modes, IRAM m=65 + sibk rtol=1e-10 "
+                               "+ tensor total derivative w.r.t. element densities",
+                   "n_dof": int(n), "nnz": int(K.nnz), "modes": N, "m": args.m, "sigma": round(float(sigma), 6),
+                   "parallelism": f"modes sharded over {world} GPU(s), one df/dx all-reduce"},
+        "roofline": roofline,
+        "sweep": sweep,
+        "cpu_baseline": cpu,
+        "accuracy": accuracy,
+        "preamble_s": {k: round(v, 3) for k, v in timing.items()},
+        "factor_sweeps_per_step": int(adj_count),
+        "eigensolve_sweeps": int(eig_count),
+    }
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, dpsi, log):
+    """
+    The CPU oracle (numpy/scipy port of the reference algorithm: SuperLU + the same sibk) on the
+    same matrices, eigenpairs and right-hand sides, for ONE mode of the 32 (bounded sample).
+    """
+    from oracle import eigd_oracle as orc
+
+    if args.cpu_sample == "small":
+        return cpu_baseline_small(args, log)
+    n, N = Phib.shape
+    t0 = time.perf_counter()
+    fac = orc.SpLuOperator((K + sigma * G).tocsc())
+    t_fac = time.perf_counter() - t0
+    log(0, f"cpu: SuperLU factorisation {t_fac:.1f}s")
+    # sibk on one mode with the full projector: restrict the loop by handing a one-column problem
+    # with the full Phi kept for the projections
+    i = 0
+    BPhi = K @ Phi
+    t0 = time.perf_counter()
+    psi_i = orc_sibk_one_mode(orc, Phib, G, K, lam, Phi, BPhi, fac, sigma, i, args.rtol)
+    t_adj = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    # total derivative of that mode (numpy einsum version of the two element callbacks)
+    beta = 0.5 * Phi[:, i].dot(Phib[:, i])
+    wA = lam[i] * (lamb[i] * Phi[:, i] + psi_i)
+    wB = (lamb[i] - beta) * Phi[:, i] + psi_i
+    ed = col.elem_dofs
+    def gather(v):
+        out = np.where(ed >= 0, v[np.maximum(ed, 0)], 0.0)
+        return out
+    wAe, wBe, pe = gather(wA), gather(wB), gather(Phi[:, i])
+    d1 = col.dG_scale() * np.einsum("na,nab,nb->n", wAe, col.Ge_unit, pe)
+    d2 = col.dK_scale() * np.einsum("na,ab,nb->n", wBe, col.Ke0, pe)
+    _ = d1 + d2
+    t_der = time.perf_counter() - t0
+    psi_gpu = dpsi.cols(i, i + 1).get()[:, 0]
+    # the GPU psi carries the correction along the other eigenvectors; remove it for the comparison
+    Gm = -Phi.T @ Phib
+    G0 = np.diag(lam) @ Gm
+    corr = np.zeros(n)
+    for j in range(N):
+        if j != i:
+            corr += (G0[j, i] / (lam[j] - lam[i])) * Phi[:, j]
+    err = np.linalg.norm((psi_gpu - corr) - psi_i) / np.linalg.norm(psi_i)
+    log(0, f"cpu: 1 mode adjoint {t_adj:.1f}s derivative {t_der:.2f}s; GPU-vs-CPU psi rel-err {err:.2e}")
+    return {"value": round(1.0 / (t_adj + t_der), 5), "unit": "modes/s", "cores": 1, "kind": "port",
+            "sample": f"mode 0 of {N} on the same 1M-dof matrices (SuperLU factor {t_fac:.0f}s untimed, like the GPU's); "
+                      f"adjoint {t_adj:.1f}s + derivative {t_der:.2f}s",
+            "factor_s": round(t_fac, 1), "psi_rel_err_gpu_vs_cpu": float(err)}
+
+
+def orc_sibk_one_mode(orc, Phib, A, B, lam, Phi, BPhi, fac, sigma, i, rtol, maxiter=50):
+    """oracle sibk (buckling mode) for column i only, projector over all N eigenvectors (ref 1198-1321, bs=1)"""
+    n, N = Phib.shape
+    rnorm0 = np.sqrt(np.max(np.sum(Phib**2, axis=0)))
+    proj = lambda x: x - BPhi @ (Phi.T @ x)  # noqa: E731
+    R = proj(-Phib[:, i].copy())            # psi0 = 0 (no Lanczos guess in the sample)
+    W = np.zeros((n, maxiter + 1))
+    Z = np.zeros((n, maxiter))
+    W[:, 0] = proj(R)
+    r00 = np.linalg.norm(W[:, 0])
+    W[:, 0] /= r00
+    H = np.zeros((maxiter + 1, maxiter))
+    for j in range(1, maxiter + 1):
+        kp = j - 1
+        Z[:, kp] = fac(W[:, kp])
+        w = proj(A @ Z[:, kp])
+        for k in range(j - 1, -1, -1):
+            H[k, kp] = w.dot(W[:, k])
+            w -= H[k, kp] * W[:, k]
+        w = proj(w)
+        H[j, kp] = np.linalg.norm(w)
+        W[:, j] = w / H[j, kp]
+        rv = np.zeros(j + 1)
+        rv[0] = r00
+        y, res = orc.solve_shifted_lstsq(-(lam[i] - sigma), H[: j + 1, :j], rv)
+        if res < rtol * rnorm0:
+            break
+    return Z[:, :j] @ y
+
+
+def cpu_baseline_small(args, log):
+    return None
+
+
+if __name__ == "__main__":
+    main()

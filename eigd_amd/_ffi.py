@@ -70,6 +70,7 @@ _SIGNATURES = {
     "eigd_copy_block": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_gather_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
     "eigd_scatter_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
+    "eigd_elem_bilinear": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_vp],
 }
 EXPORTED = sorted(list(_SIGNATURES) + ["eigd_last_error"])
 

@@ -470,3 +470,51 @@ class Factor:
         b = C.c_double()
         call("eigd_factor_solve_bytes", self.h, int(k), C.byref(b))
         return b.value
+
+
+class ElementBilinear:
+    """
+    Device-side derivative callback: ``cb(W, V) -> numpy (nelem,)`` with
+    out[e] = scale[e] * sum_c w_e(:, c)^T M_e v_e(:, c).  Marked ``device = True`` so
+    add_total_derivative hands it device blocks (no D2H of the n x N weight matrices).
+    """
+
+    device = True
+
+    def __init__(self, ctx, elem_dofs, Me, scale=None):
+        elem_dofs = np.ascontiguousarray(elem_dofs, dtype=np.int32)
+        self.ctx = ctx
+        self.nelem, self.nd = elem_dofs.shape
+        Me = np.ascontiguousarray(Me, dtype=np.float64)
+        self.per_elem = 1 if Me.ndim == 3 else 0
+        if Me.shape[-2:] != (self.nd, self.nd) or (self.per_elem and Me.shape[0] != self.nelem):
+            raise ValueError("element matrix shape does not match the dof list")
+        self._dofs = _Buffer(ctx, elem_dofs.nbytes)
+        call("eigd_h2d", ctx.h, c_vp(self._dofs.ptr), hptr(elem_dofs), elem_dofs.nbytes)
+        self._Me = _Buffer(ctx, Me.nbytes)
+        call("eigd_h2d", ctx.h, c_vp(self._Me.ptr), hptr(Me), Me.nbytes)
+        self._scale = None
+        if scale is not None:
+            scale = np.ascontiguousarray(scale, dtype=np.float64)
+            self._scale = _Buffer(ctx, scale.nbytes)
+            call("eigd_h2d", ctx.h, c_vp(self._scale.ptr), hptr(scale), scale.nbytes)
+
+    def accumulate(self, W, V, out, alpha=1.0):
+        """out (device, nelem x 1) += alpha * contraction"""
+        if (W.n, W.k) != (V.n, V.k):
+            raise ValueError("shape mismatch")
+        sp = c_vp(self._scale.ptr) if self._scale is not None else c_vp(None)
+        for c0 in range(0, W.k, 64):
+            c1 = min(W.k, c0 + 64)
+            call("eigd_elem_bilinear", self.ctx.h, self.nelem, self.nd, c_vp(self._dofs.ptr), c_vp(self._Me.ptr),
+                 self.per_elem, sp, W.cols(c0, c1).ptr, W.ld, V.cols(c0, c1).ptr, V.ld, c1 - c0, float(alpha), out.ptr)
+        return out
+
+    def __call__(self, W, V):
+        if not isinstance(W, DeviceBlock):  # numpy in, numpy out (vector or tensor form of the reference callbacks)
+            W2 = np.asarray(W, dtype=np.float64).reshape(W.shape[0], -1)
+            V2 = np.asarray(V, dtype=np.float64).reshape(V.shape[0], -1)
+            W, V = self.ctx.from_host(W2), self.ctx.from_host(V2)
+        out = self.ctx.zeros(self.nelem, 1)
+        self.accumulate(W, V, out)
+        return out.get()[:, 0]

@@ -140,6 +140,16 @@ int eigd_gather_cols(eigd_ctx* ctx, int n, int kdst, const double* dSrc, int lds
 int eigd_scatter_cols(eigd_ctx* ctx, int n, int ksrc, const double* dSrc, int lds, const int32_t* hcols, double* dDst,
                       int ldd);
 
+/* ---- element-wise bilinear forms (device-side derivative callbacks) -------------
+ * out[e] += alpha * scale[e] * sum_c w_e(:,c)^T M_e v_e(:,c): the d/d(rho_e) contractions the
+ * reference's harness callbacks evaluate with numpy einsums (examples/buckling.py:178-218,
+ * 283-340; natural_frequency.py:162-203, 238-284; thermal.py:150-190, 216-246) and that
+ * add_eig_total_derivative calls (33-182).  d_edofs: nelem x nd dof list (-1 = constrained),
+ * dMe: nelem x nd x nd (per_elem != 0) or one shared nd x nd matrix, nd <= 8.             */
+int eigd_elem_bilinear(eigd_ctx* ctx, int nelem, int nd, const int32_t* d_edofs, const double* dMe, int per_elem,
+                       const double* dscale, const double* dW, int ldw, const double* dV, int ldv, int k, double alpha,
+                       double* dOut);
+
 #ifdef __cplusplus
 }
 #endif
