@@ -367,3 +367,71 @@ def test_mode_sharding_single_process_equivalence():
         parts.append(comm.acc[-1])
     assert relerr(psi_sh, psi) < 1e-12   # only the reduction trees depend on the block width
     assert relerr(np.sum(parts, axis=0), dfdx) < 1e-13
+
+
+_RANK_WORKER = '''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["EIGD_ROOT"]); sys.path.insert(0, os.path.join(os.environ["EIGD_ROOT"], "tests"))
+import torch, torch.distributed as dist      # torch first: one HIP runtime for torch and libeigd_hip.so
+backend = os.environ["EIGD_TEST_BACKEND"]
+if backend == "nccl":
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+else:
+    dist.init_process_group("gloo")
+os.environ["EIGD_DEVICE"] = "0"
+import eigd_amd as eg
+from eigd_amd.comm import TorchDistComm
+from conftest import csr_from, load_golden
+comm = TorchDistComm(device=torch.device("cuda", 0) if backend == "nccl" else "cpu")
+g = load_golden("g4_laplace900_basiclanczos")
+K, M = csr_from(g, "K"), csr_from(g, "M")
+fac = eg.SpLuOperator((K + 0.1 * M).tocsc())
+s = eg.BasicLanczos(N=6, m=60)
+s.solve(K, M, fac, -0.1)
+rng = np.random.default_rng(2)
+Ca, Cb = rng.normal(size=(K.shape[0], 9)), rng.normal(size=(K.shape[0], 9))
+cb = lambda C: (lambda w, v: C.T @ np.sum(w * v, axis=1))
+Phib, lamb = g["Phib"], g["lamb"]
+psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-12)
+ref = s.add_total_derivative(lamb, Phib, psi, cb(Ca), cb(Cb), np.zeros(9), adj_corr_data=data, deriv_type="tensor")
+for method in ("sibk", "pgmres", "pcpg"):
+    psi_r, data_r = s.solve_adjoint(Phib, method=method, rtol=1e-12, comm=comm)
+    out = s.add_total_derivative(lamb, Phib, psi_r, cb(Ca), cb(Cb), np.zeros(9), adj_corr_data=data_r,
+                                 deriv_type="tensor", comm=comm)
+    err = np.linalg.norm(out - ref) / np.linalg.norm(ref)
+    assert err < 1e-8, (method, err)
+    mine = np.arange(comm.rank, 6, comm.size)
+    others = [c for c in range(6) if c not in mine]
+    assert np.all(psi_r[:, others] == 0.0)
+dist.destroy_process_group()
+print("rank", comm.rank, "ok")
+'''
+
+
+def _run_ranks(tmp_path, nproc, backend, port):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank_worker.py"
+    script.write_text(_RANK_WORKER)
+    env = dict(os.environ, EIGD_ROOT=root, EIGD_TEST_BACKEND=backend, MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("ok") == nproc
+
+
+def test_two_rank_gpu_sharding_gloo(tmp_path):
+    """two processes share the GPU, modes sharded 3 + 3, df/dx all-reduced over gloo"""
+    _run_ranks(tmp_path, 2, "gloo", 29531)
+
+
+def test_one_rank_rccl_allreduce_path(tmp_path):
+    """the bench's multi-GPU plumbing with RCCL (nccl backend) at world size 1: torch and libeigd_hip.so in one process"""
+    _run_ranks(tmp_path, 1, "nccl", 29532)
