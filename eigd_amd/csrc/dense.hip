@@ -19,14 +19,18 @@ static inline int grid_for_rows(int n, int rows_per_block) {
   return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(need, kMaxBlocks)));
 }
 
-// out[o] = sum_g partial[g * nout + o], g ascending
-__global__ void reduce_partials_kernel(const double* __restrict__ partial, int nblocks, int nout,
-                                       double* __restrict__ out) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+// out[o] = sum over g of partial[g * nout + o]: one wave per output, lane l adds g = l, l+64, ...
+// in ascending order, then a fixed shuffle tree -- the same association for every launch shape.
+__global__ __launch_bounds__(kThreads) void reduce_partials_kernel(const double* __restrict__ partial, int nblocks,
+                                                                  int nout, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (o >= nout) return;
   double s = 0.0;
-  for (int g = 0; g < nblocks; ++g) s += partial[static_cast<int64_t>(g) * nout + o];
-  out[o] = s;
+  for (int g = lane; g < nblocks; g += 64) s += partial[static_cast<int64_t>(g) * nout + o];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) out[o] = s;
 }
 
 // ---------------------------------------------------------------------------
@@ -271,8 +275,8 @@ static int dispatch_kp(int k, F&& f) {
 }
 
 static int reduce_to_host(eigd_ctx* ctx, const double* partial, int nblocks, int nout, double* dres, double* hout) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 255) / 256), dim3(256), 0, ctx->stream, partial, nblocks, nout,
-                     dres);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 3) / 4), dim3(kThreads), 0, ctx->stream, partial, nblocks,
+                     nout, dres);
   EIGD_LAUNCH_CHECK();
   if (hout) {
     EIGD_HIP(hipMemcpyAsync(hout, dres, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));

@@ -43,7 +43,9 @@ struct FrontArrays {
   const int64_t* ioff;
   const int64_t* bptr;
   const int* rel;
+  const int* poff;  // first partial slab of the front's border products, -1 if it has a single tile group
   int W;
+  int BG;           // border tiles per group
 };
 
 __device__ __forceinline__ int find_slot(const int* __restrict__ pref, int na, int idx) {
@@ -288,73 +290,133 @@ __global__ __launch_bounds__(kThreads) void vec_extend_add_kernel(FrontArrays fa
   }
 }
 
-// backward: border part of each front's vector pulled from its parent's (already final) vector
-__global__ __launch_bounds__(kThreads) void vec_gather_kernel(FrontArrays fa, const int* __restrict__ fronts, int kb,
-                                                             double* __restrict__ V) {
-  const int f = fronts[blockIdx.x];
-  const int p = fa.parent[f];
-  if (p < 0) return;
-  const int ns = fa.ns[f], bs = fa.bs[f];
-  const int* __restrict__ rel = fa.rel + fa.bptr[f];
-  double* Vf = V + (fa.voff[f] + ns) * kb;
-  const double* Vp = V + fa.voff[p] * kb;
-  const int total = bs * kb;
-  for (int idx = blockIdx.y * kThreads + threadIdx.x; idx < total; idx += gridDim.y * kThreads) {
-    const int i = idx / kb, col = idx - i * kb;
-    Vf[idx] = Vp[static_cast<int64_t>(rel[i]) * kb + col];
-  }
-}
-
 // 64 x (4*KPT) output tile, thread (o = tid/4, cg = tid%4) owns KPT columns.
 //   TRANS == false : acc[o][c] += sum_k As[k*TLD + o] * Bs[k*KB + c]
 //   TRANS == true  : acc[o][c] += sum_k As[o*TLD + k] * Bs[k*KB + c]
+// kdim is rounded up to a multiple of 8 (tiles are zero padded to 64) so the loop unrolls and the
+// LDS reads of eight k-steps are in flight together.
 template <int KPT, bool TRANS>
 __device__ __forceinline__ void tile_mac(const double* __restrict__ As, const double* __restrict__ Bs, int kdim, int o,
                                          int cg, double (&acc)[KPT]) {
   constexpr int KB = 4 * KPT;
-  for (int k = 0; k < kdim; ++k) {
-    const double a = TRANS ? As[o * TLD + k] : As[k * TLD + o];
-    const double* b = Bs + k * KB + cg * KPT;
+  const int kd = (kdim + 7) & ~7;
+  for (int k0 = 0; k0 < kd; k0 += 8) {
 #pragma unroll
-    for (int q = 0; q < KPT; ++q) acc[q] += a * b[q];
+    for (int kk = 0; kk < 8; ++kk) {
+      const int k = k0 + kk;
+      const double a = TRANS ? As[o * TLD + k] : As[k * TLD + o];
+      const double* b = Bs + k * KB + cg * KPT;
+#pragma unroll
+      for (int q = 0; q < KPT; ++q) acc[q] += a * b[q];
+    }
   }
 }
 
 struct StepArgs {
   const int* fronts;       // active fronts of this (level, step), npanels descending
-  const int* pref_chunks;  // na + 1
+  const int* pref_chunks;  // na + 1 : row chunks below the panel
+  const int* pref_work;    // na + 1 : max(1, chunks)
   int na;
   int step;
   int kb;
 };
 
-template <int KPT>
+// Tile loaders.  All global loads of a tile are issued before the first LDS store (register
+// staging, fully unrolled): a 64 x 64 tile costs one memory latency, not sixteen.
+constexpr int TILE_IT = TW * TW / kThreads;  // 16 elements per lane
+
+// As[j*TLD + r] = L(row0 + r, j0 + j), zero padded to 64 x 64
 __device__ __forceinline__ void load_panel_chunk(double* As, const double* __restrict__ Lp, int64_t d, int w, int row0,
                                                  int rows) {
-  // As[j*TLD + r] = L(row0 + r, j0 + j)
-  for (int idx = threadIdx.x; idx < TW * TW; idx += kThreads) {
-    const int j = idx / TW, r = idx - j * TW;
-    As[j * TLD + r] = (j < w && r < rows) ? Lp[static_cast<int64_t>(j) * d + row0 + r] : 0.0;
+  double tmp[TILE_IT];
+  const int r = threadIdx.x & (TW - 1), jb = threadIdx.x >> 6;  // lane -> (row, first column); columns step by 4
+#pragma unroll
+  for (int it = 0; it < TILE_IT; ++it) {
+    const int j = jb + it * (kThreads / TW);
+    tmp[it] = (j < w && r < rows) ? Lp[static_cast<int64_t>(j) * d + row0 + r] : 0.0;
   }
+#pragma unroll
+  for (int it = 0; it < TILE_IT; ++it) As[(jb + it * (kThreads / TW)) * TLD + r] = tmp[it];
 }
 
+// As[r*TLD + c] = M(r, c) for a tile stored with element (r, c) at c*ld + r (rows contiguous), zero padded
+__device__ __forceinline__ void load_tile_transposed(double* As, const double* __restrict__ M, int64_t ld, int nrows,
+                                                     int ncols) {
+  double tmp[TILE_IT];
+  const int r = threadIdx.x & (TW - 1), cb = threadIdx.x >> 6;
+#pragma unroll
+  for (int it = 0; it < TILE_IT; ++it) {
+    const int c = cb + it * (kThreads / TW);
+    tmp[it] = (c < ncols && r < nrows) ? M[static_cast<int64_t>(c) * ld + r] : 0.0;
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_IT; ++it) As[r * TLD + cb + it * (kThreads / TW)] = tmp[it];
+}
+
+// As[j*TLD + i] = inv(i, j) of the step's diagonal block, zero padded
+__device__ __forceinline__ void load_inverse(double* As, const double* __restrict__ Ig, int W, int w) {
+  double tmp[TILE_IT];
+  const int i = threadIdx.x & (TW - 1), jb = threadIdx.x >> 6;
+#pragma unroll
+  for (int it = 0; it < TILE_IT; ++it) {
+    const int j = jb + it * (kThreads / TW);
+    tmp[it] = (j < w && i < w) ? Ig[j * W + i] : 0.0;
+  }
+#pragma unroll
+  for (int it = 0; it < TILE_IT; ++it) As[(jb + it * (kThreads / TW)) * TLD + i] = tmp[it];
+}
+
+// Bs[r*KB + c] = Vrows[r*kb + c] (r < rows), zero padded to 64 x KB
 template <int KPT>
 __device__ __forceinline__ void load_vec_rows(double* Bs, const double* __restrict__ Vrows, int kb, int rows) {
   constexpr int KB = 4 * KPT;
-  for (int idx = threadIdx.x; idx < TW * KB; idx += kThreads) {
+  constexpr int IT = TW * KB / kThreads;  // KPT elements per lane
+  double tmp[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int idx = threadIdx.x + it * kThreads;
     const int r = idx / KB, c = idx - r * KB;
-    Bs[idx] = (r < rows && c < kb) ? Vrows[static_cast<int64_t>(r) * kb + c] : 0.0;
+    tmp[it] = (r < rows && c < kb) ? Vrows[static_cast<int64_t>(r) * kb + c] : 0.0;
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) Bs[threadIdx.x + it * kThreads] = tmp[it];
+}
+
+// Bs[r*KB + c] = Vsrc[rel[r]*kb + c] (gathered rows), zero padded; optionally mirrored into Vdst[r*kb + c]
+template <int KPT>
+__device__ __forceinline__ void load_vec_rows_rel(double* Bs, const double* Vsrc, const int* __restrict__ rel, int kb,
+                                                  int rows, double* Vdst) {
+  constexpr int KB = 4 * KPT;
+  constexpr int IT = TW * KB / kThreads;
+  double tmp[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int idx = threadIdx.x + it * kThreads;
+    const int r = idx / KB, c = idx - r * KB;
+    tmp[it] = (r < rows && c < kb) ? Vsrc[static_cast<int64_t>(rel[r]) * kb + c] : 0.0;
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int idx = threadIdx.x + it * kThreads;
+    const int r = idx / KB, c = idx - r * KB;
+    Bs[idx] = tmp[it];
+    if (Vdst != nullptr && r < rows && c < kb) Vdst[static_cast<int64_t>(r) * kb + c] = tmp[it];
   }
 }
 
-// forward, diagonal block: y1 = inv(L11) v1 ; fronts whose rows below fit one chunk are finished here
+// Forward step of one panel, fused: every workgroup recomputes y1 = inv(L11) v1 (64 x 64 x k
+// flops, the inverse block comes from L2) and then updates ITS chunk of the rows below,
+// v2 -= L21 y1.  y1 goes to the Y workspace (chunk 0 writes it) so v1 stays read-only during the
+// launch: one launch per (level, step) instead of a diagonal launch plus an update launch.
 template <int KPT>
-__global__ __launch_bounds__(kThreads) void fwd_diag_kernel(FrontArrays fa, StepArgs sa, const double* __restrict__ F,
-                                                           const double* __restrict__ Inv, double* __restrict__ V) {
+__global__ __launch_bounds__(kThreads) void fwd_step_kernel(FrontArrays fa, StepArgs sa, const double* __restrict__ F,
+                                                           const double* __restrict__ Inv, double* __restrict__ V,
+                                                           double* __restrict__ Y) {
   constexpr int KB = 4 * KPT;
   __shared__ double As[TW * TLD];
   __shared__ double Bs[TW * KB];
-  const int q = blockIdx.x;
+  const int q = find_slot(sa.pref_work, sa.na, blockIdx.x);
+  const int chunk = blockIdx.x - sa.pref_work[q];
   const int f = sa.fronts[q];
   const int nch = sa.pref_chunks[q + 1] - sa.pref_chunks[q];
   const int W = fa.W, kb = sa.kb;
@@ -363,13 +425,9 @@ __global__ __launch_bounds__(kThreads) void fwd_diag_kernel(FrontArrays fa, Step
   const int j0 = sa.step * W;
   const int w = min(W, ns - j0);
   const int j1 = j0 + w;
-  const double* Ig = Inv + fa.ioff[f] + static_cast<int64_t>(sa.step) * W * W;
   double* Vf = V + fa.voff[f] * kb;
   const int tid = threadIdx.x, o = tid / 4, cg = tid % 4;
-  for (int idx = tid; idx < TW * TW; idx += kThreads) {
-    const int j = idx / TW, i = idx - j * TW;
-    As[j * TLD + i] = (j < w && i < w) ? Ig[j * W + i] : 0.0;  // As[j][i] = inv(i, j)
-  }
+  load_inverse(As, Inv + fa.ioff[f] + static_cast<int64_t>(sa.step) * W * W, W, w);
   load_vec_rows<KPT>(Bs, Vf + static_cast<int64_t>(j0) * kb, kb, w);
   __syncthreads();
   double acc[KPT];
@@ -378,53 +436,20 @@ __global__ __launch_bounds__(kThreads) void fwd_diag_kernel(FrontArrays fa, Step
   tile_mac<KPT, false>(As, Bs, w, o, cg, acc);
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < KPT; ++t) {
-    const int c = cg * KPT + t;
-    Bs[o * KB + c] = (o < w) ? acc[t] : 0.0;
-    if (o < w && c < kb) Vf[static_cast<int64_t>(j0 + o) * kb + c] = acc[t];
-  }
-  if (nch != 1) return;
-  const int rows = static_cast<int>(d) - j1;
-  __syncthreads();
-  load_panel_chunk<KPT>(As, F + fa.foff[f] + static_cast<int64_t>(j0) * d, d, w, j1, rows);
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
-  tile_mac<KPT, false>(As, Bs, w, o, cg, acc);
-  if (o < rows) {
+  for (int t = 0; t < KPT; ++t) Bs[o * KB + cg * KPT + t] = (o < w) ? acc[t] : 0.0;
+  if (chunk == 0 && o < w) {
+    double* Yf = Y + (fa.voff[f] + j0) * kb;
 #pragma unroll
     for (int t = 0; t < KPT; ++t) {
       const int c = cg * KPT + t;
-      if (c < kb) Vf[static_cast<int64_t>(j1 + o) * kb + c] -= acc[t];
+      if (c < kb) Yf[static_cast<int64_t>(o) * kb + c] = acc[t];
     }
   }
-}
-
-// forward, rows below: v2 -= L21 y1, one 64-row chunk per workgroup (fronts with > 1 chunk)
-template <int KPT>
-__global__ __launch_bounds__(kThreads) void fwd_update_kernel(FrontArrays fa, StepArgs sa, const double* __restrict__ F,
-                                                             double* __restrict__ V) {
-  constexpr int KB = 4 * KPT;
-  const int q = find_slot(sa.pref_chunks, sa.na, blockIdx.x);
-  const int nch = sa.pref_chunks[q + 1] - sa.pref_chunks[q];
-  if (nch <= 1) return;
-  __shared__ double As[TW * TLD];
-  __shared__ double Bs[TW * KB];
-  const int f = sa.fronts[q];
-  const int chunk = blockIdx.x - sa.pref_chunks[q];
-  const int W = fa.W, kb = sa.kb;
-  const int ns = fa.ns[f];
-  const int64_t d = ns + fa.bs[f];
-  const int j0 = sa.step * W;
-  const int w = min(W, ns - j0);
-  const int row0 = j0 + w + chunk * TW;
+  if (nch == 0) return;
+  const int row0 = j1 + chunk * TW;
   const int rows = min(TW, static_cast<int>(d) - row0);
-  double* Vf = V + fa.voff[f] * kb;
-  const int tid = threadIdx.x, o = tid / 4, cg = tid % 4;
-  load_panel_chunk<KPT>(As, F + fa.foff[f] + static_cast<int64_t>(j0) * d, d, w, row0, rows);
-  load_vec_rows<KPT>(Bs, Vf + static_cast<int64_t>(j0) * kb, kb, w);
+  load_panel_chunk(As, F + fa.foff[f] + static_cast<int64_t>(j0) * d, d, w, row0, rows);
   __syncthreads();
-  double acc[KPT];
 #pragma unroll
   for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
   tile_mac<KPT, false>(As, Bs, w, o, cg, acc);
@@ -437,98 +462,167 @@ __global__ __launch_bounds__(kThreads) void fwd_update_kernel(FrontArrays fa, St
   }
 }
 
-// backward, rows below: partial t = L21(chunk)^T x2(chunk) into the partial slab (fronts with > 1 chunk)
+// Backward, border rows: y(own columns) -= L21(border)^T x(border).  A workgroup owns one
+// 64-column chunk of a front and one group of BG border tiles, which it walks in order; the border
+// values of x are read straight from the parent's slice of V through the relative index list (group 0
+// of chunk 0 also mirrors them into the front's own slice for its children).  Fronts whose border
+// fits one group subtract directly (and single-panel ones are finished here); the others write a
+// partial slab that bwd_fold_kernel adds in fixed order -- no atomics.
 template <int KPT>
-__global__ __launch_bounds__(kThreads) void bwd_partial_kernel(FrontArrays fa, StepArgs sa, const double* __restrict__ F,
-                                                              const double* __restrict__ V, double* __restrict__ P) {
+__global__ __launch_bounds__(kThreads) void bwd_border_kernel(FrontArrays fa, const int* __restrict__ fronts, int nf,
+                                                             const int* __restrict__ pref_bwork, int kb,
+                                                             const double* __restrict__ F,
+                                                             const double* __restrict__ Inv, double* V,
+                                                             double* __restrict__ Y, double* __restrict__ P) {
   constexpr int KB = 4 * KPT;
-  const int q = find_slot(sa.pref_chunks, sa.na, blockIdx.x);
-  const int nch = sa.pref_chunks[q + 1] - sa.pref_chunks[q];
-  if (nch <= 1) return;
+  const int q = find_slot(pref_bwork, nf, blockIdx.x);
+  const int f = fronts[q];
+  const int p = fa.parent[f];
+  const int bs = fa.bs[f];
+  const int W = fa.W;
+  const int ns = fa.ns[f];
+  if ((p < 0 || bs == 0) && ns > W) return;  // nothing to fold in; the step kernels do the rest
   __shared__ double As[TW * TLD];
   __shared__ double Bs[TW * KB];
-  const int f = sa.fronts[q];
-  const int chunk = blockIdx.x - sa.pref_chunks[q];
-  const int W = fa.W, kb = sa.kb;
-  const int ns = fa.ns[f];
-  const int64_t d = ns + fa.bs[f];
-  const int j0 = sa.step * W;
-  const int w = min(W, ns - j0);
-  const int row0 = j0 + w + chunk * TW;
-  const int rows = min(TW, static_cast<int>(d) - row0);
-  const double* Vf = V + fa.voff[f] * kb;
+  const int ntiles = (bs + TW - 1) / TW;
+  const int ngroups = max(1, (ntiles + fa.BG - 1) / fa.BG);
+  const int local = blockIdx.x - pref_bwork[q];
+  const int cc = local / ngroups, rg = local - cc * ngroups;
+  const int64_t d = ns + bs;
+  const int c0 = cc * W;
+  const int wc = min(W, ns - c0);
+  const int* __restrict__ rel = fa.rel + fa.bptr[f];
+  const double* Vp = V + fa.voff[p >= 0 ? p : f] * kb;
+  double* Vb = V + (fa.voff[f] + ns) * kb;
+  const double* Fc = F + fa.foff[f] + static_cast<int64_t>(c0) * d + ns;  // element (border r, col c) at c*d + r
   const int tid = threadIdx.x, o = tid / 4, cg = tid % 4;
-  load_panel_chunk<KPT>(As, F + fa.foff[f] + static_cast<int64_t>(j0) * d, d, w, row0, rows);
-  load_vec_rows<KPT>(Bs, Vf + static_cast<int64_t>(row0) * kb, kb, rows);
-  __syncthreads();
   double acc[KPT];
 #pragma unroll
   for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
-  tile_mac<KPT, true>(As, Bs, rows, o, cg, acc);
-  double* Pp = P + static_cast<int64_t>(blockIdx.x) * (TW * KBMAX);
-  if (o < w) {
+  const int rbeg = rg * fa.BG * TW, rend = min(bs, (rg + 1) * fa.BG * TW);
+  for (int r0 = rbeg; r0 < rend; r0 += TW) {
+    const int rows = min(TW, bs - r0);
+    load_tile_transposed(As, Fc + r0, d, rows, wc);  // As[r*TLD + c] = L(ns + r0 + r, c0 + c)
+    load_vec_rows_rel<KPT>(Bs, Vp, rel + r0, kb, rows, cc == 0 ? Vb + static_cast<int64_t>(r0) * kb : nullptr);
+    __syncthreads();
+    tile_mac<KPT, false>(As, Bs, rows, o, cg, acc);
+    __syncthreads();
+  }
+  double* Yf = Y + (fa.voff[f] + c0) * kb;
+  if (ngroups > 1) {  // partial slab [cc][rg], 64 x KBMAX
+    double* Pp = P + (static_cast<int64_t>(fa.poff[f]) + local) * (TW * KBMAX);
 #pragma unroll
     for (int t = 0; t < KPT; ++t) Pp[o * KBMAX + cg * KPT + t] = acc[t];
+    return;
   }
-}
-
-// backward, diagonal block: x1 = inv(L11)^T (y1 - sum of partials)
-template <int KPT>
-__global__ __launch_bounds__(kThreads) void bwd_diag_kernel(FrontArrays fa, StepArgs sa, const double* __restrict__ F,
-                                                           const double* __restrict__ Inv, const double* __restrict__ P,
-                                                           double* __restrict__ V) {
-  constexpr int KB = 4 * KPT;
-  __shared__ double As[TW * TLD];
-  __shared__ double Bs[TW * KB];
-  const int q = blockIdx.x;
-  const int f = sa.fronts[q];
-  const int pc0 = sa.pref_chunks[q];
-  const int nch = sa.pref_chunks[q + 1] - pc0;
-  const int W = fa.W, kb = sa.kb;
-  const int ns = fa.ns[f];
-  const int64_t d = ns + fa.bs[f];
-  const int j0 = sa.step * W;
-  const int w = min(W, ns - j0);
-  const int j1 = j0 + w;
-  const double* Ig = Inv + fa.ioff[f] + static_cast<int64_t>(sa.step) * W * W;
-  double* Vf = V + fa.voff[f] * kb;
-  const int tid = threadIdx.x, o = tid / 4, cg = tid % 4;
-  double acc[KPT];
+  if (ns > W) {  // multi-panel front, single group: fold into the right-hand side directly
+    if (o < wc) {
 #pragma unroll
-  for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
-  if (nch == 1) {
-    const int rows = static_cast<int>(d) - j1;
-    load_panel_chunk<KPT>(As, F + fa.foff[f] + static_cast<int64_t>(j0) * d, d, w, j1, rows);
-    load_vec_rows<KPT>(Bs, Vf + static_cast<int64_t>(j1) * kb, kb, rows);
-    __syncthreads();
-    tile_mac<KPT, true>(As, Bs, rows, o, cg, acc);
-    __syncthreads();
-  } else if (nch > 1 && o < w) {
-    for (int ch = 0; ch < nch; ++ch) {
-      const double* Pp = P + static_cast<int64_t>(pc0 + ch) * (TW * KBMAX) + o * KBMAX + cg * KPT;
-#pragma unroll
-      for (int t = 0; t < KPT; ++t) acc[t] += Pp[t];
+      for (int t = 0; t < KPT; ++t) {
+        const int c = cg * KPT + t;
+        if (c < kb) Yf[static_cast<int64_t>(o) * kb + c] -= acc[t];
+      }
     }
+    return;
   }
-  // z = y1 - t  -> Bs ; inv -> As
+  // single-panel front with a single group (the leaves and small separators): finish here
 #pragma unroll
   for (int t = 0; t < KPT; ++t) {
     const int c = cg * KPT + t;
-    Bs[o * KB + c] = (o < w && c < kb) ? Vf[static_cast<int64_t>(j0 + o) * kb + c] - acc[t] : 0.0;
+    Bs[o * KB + c] = (o < wc && c < kb) ? Yf[static_cast<int64_t>(o) * kb + c] - acc[t] : 0.0;
   }
-  for (int idx = tid; idx < TW * TW; idx += kThreads) {
-    const int j = idx / TW, i = idx - j * TW;
-    As[j * TLD + i] = (j < w && i < w) ? Ig[j * W + i] : 0.0;  // As[j][i] = inv(i, j)
-  }
+  load_inverse(As, Inv + fa.ioff[f], W, wc);
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
-  tile_mac<KPT, true>(As, Bs, w, o, cg, acc);  // x1[o] = sum_i inv(i, o) z[i]
-  if (o < w) {
+  tile_mac<KPT, true>(As, Bs, wc, o, cg, acc);
+  if (o < wc) {
+    double* Vf = V + (fa.voff[f] + o) * kb;
 #pragma unroll
     for (int t = 0; t < KPT; ++t) {
       const int c = cg * KPT + t;
-      if (c < kb) Vf[static_cast<int64_t>(j0 + o) * kb + c] = acc[t];
+      if (c < kb) Vf[c] = acc[t];
+    }
+  }
+}
+
+// y(chunk) -= sum over groups of the partial slabs, groups in ascending order
+__global__ __launch_bounds__(kThreads) void bwd_fold_kernel(FrontArrays fa, const int* __restrict__ fronts, int nf,
+                                                           const int* __restrict__ pref_panels, int kb,
+                                                           const double* __restrict__ P, double* __restrict__ Y) {
+  const int q = find_slot(pref_panels, nf, blockIdx.x);
+  const int f = fronts[q];
+  const int po = fa.poff[f];
+  if (po < 0) return;
+  const int cc = blockIdx.x - pref_panels[q];
+  const int W = fa.W;
+  const int ns = fa.ns[f], bs = fa.bs[f];
+  const int ntiles = (bs + TW - 1) / TW;
+  const int ngroups = (ntiles + fa.BG - 1) / fa.BG;
+  const int wc = min(W, ns - cc * W);
+  double* Yf = Y + (fa.voff[f] + cc * W) * kb;
+  const double* Pp = P + (static_cast<int64_t>(po) + cc * ngroups) * (TW * KBMAX);
+  for (int idx = threadIdx.x; idx < wc * kb; idx += kThreads) {
+    const int o = idx / kb, c = idx - o * kb;
+    double s = 0.0;
+    for (int g = 0; g < ngroups; ++g) s += Pp[static_cast<int64_t>(g) * (TW * KBMAX) + o * KBMAX + c];
+    Yf[idx] -= s;
+  }
+}
+
+// Backward step of one panel, fused and right-looking: every workgroup recomputes
+// x1 = inv(L11)^T y1, workgroup 0 stores it in V, and workgroup cc folds it into the 64 earlier
+// columns it owns: y(cc) -= L(panel rows, cc columns)^T x1.  No partial sums, one launch per step.
+template <int KPT>
+__global__ __launch_bounds__(kThreads) void bwd_step_kernel(FrontArrays fa, StepArgs sa, const double* __restrict__ F,
+                                                           const double* __restrict__ Inv, double* __restrict__ V,
+                                                           double* __restrict__ Y) {
+  constexpr int KB = 4 * KPT;
+  __shared__ double As[TW * TLD];
+  __shared__ double Bs[TW * KB];
+  const int wpf = max(1, sa.step);  // workgroups per front: one per earlier 64-column chunk
+  const int q = blockIdx.x / wpf;
+  const int cc = blockIdx.x - q * wpf;
+  const int f = sa.fronts[q];
+  const int W = fa.W, kb = sa.kb;
+  const int ns = fa.ns[f];
+  if (ns <= W && fa.poff[f] < 0) return;  // single-panel, single-group fronts are finished by bwd_border_kernel
+  const int64_t d = ns + fa.bs[f];
+  const int j0 = sa.step * W;
+  const int w = min(W, ns - j0);
+  double* Yf = Y + fa.voff[f] * kb;
+  const int tid = threadIdx.x, o = tid / 4, cg = tid % 4;
+  load_inverse(As, Inv + fa.ioff[f] + static_cast<int64_t>(sa.step) * W * W, W, w);
+  load_vec_rows<KPT>(Bs, Yf + static_cast<int64_t>(j0) * kb, kb, w);
+  __syncthreads();
+  double acc[KPT];
+#pragma unroll
+  for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
+  tile_mac<KPT, true>(As, Bs, w, o, cg, acc);  // x1[o] = sum_i inv(i, o) y1[i]
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < KPT; ++t) Bs[o * KB + cg * KPT + t] = (o < w) ? acc[t] : 0.0;
+  if (cc == 0 && o < w) {
+    double* Vf = V + (fa.voff[f] + j0) * kb;
+#pragma unroll
+    for (int t = 0; t < KPT; ++t) {
+      const int c = cg * KPT + t;
+      if (c < kb) Vf[static_cast<int64_t>(o) * kb + c] = acc[t];
+    }
+  }
+  if (sa.step == 0) return;
+  // As[r*TLD + c] = L(j0 + r, cc*W + c): the panel's rows in the columns of chunk cc (full 64 wide)
+  load_tile_transposed(As, F + fa.foff[f] + static_cast<int64_t>(cc) * W * d + j0, d, w, W);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
+  tile_mac<KPT, false>(As, Bs, w, o, cg, acc);
+  if (o < W) {
+    double* Yc = Yf + static_cast<int64_t>(cc * W + o) * kb;
+#pragma unroll
+    for (int t = 0; t < KPT; ++t) {
+      const int c = cg * KPT + t;
+      if (c < kb) Yc[c] -= acc[t];
     }
   }
 }
@@ -545,9 +639,11 @@ struct eigd_factor {
   int *d_c0 = nullptr, *d_ns = nullptr, *d_bs = nullptr, *d_parent = nullptr, *d_rel = nullptr;
   int64_t *d_foff = nullptr, *d_voff = nullptr, *d_ioff = nullptr, *d_bptr = nullptr;
   int *d_lvl_fronts = nullptr, *d_pref_chunks = nullptr, *d_pref_tiles = nullptr, *d_cs_child = nullptr;
+  int *d_pref_work = nullptr, *d_pref_panels = nullptr, *d_pref_bwork = nullptr, *d_poff = nullptr;
+  double* d_P = nullptr;
   int64_t *d_a_src = nullptr, *d_a_dst = nullptr;
   int* d_v_src = nullptr;
-  double *d_data = nullptr, *d_F = nullptr, *d_Inv = nullptr, *d_V = nullptr, *d_P = nullptr;
+  double *d_data = nullptr, *d_F = nullptr, *d_Inv = nullptr, *d_V = nullptr, *d_Y = nullptr;
   int* d_flag = nullptr;
   size_t bytes = 0;
   int64_t max_chunks = 0;
@@ -565,7 +661,9 @@ struct eigd_factor {
     a.ioff = d_ioff;
     a.bptr = d_bptr;
     a.rel = d_rel;
+    a.poff = d_poff;
     a.W = sym->W;
+    a.BG = sym->BG;
     return a;
   }
 };
@@ -645,6 +743,18 @@ int sweep(eigd_factor* f, double* dX, int ldx, int kb, double alpha) {
   hipLaunchKernelGGL(solve_init_kernel, dim3(std::max(gb, 1)), dim3(256), 0, st, s.sumd, kb, f->d_v_src, dX, ldx, alpha,
                      f->d_V);
   EIGD_LAUNCH_CHECK();
+  auto step_args = [&](int l, int step) {
+    const int rec = s.ls_ptr[l] + step;
+    const int64_t po = s.ls_pref_ptr[rec];
+    StepArgs sa;
+    sa.fronts = f->d_lvl_fronts + s.lvl_ptr[l];
+    sa.pref_chunks = f->d_pref_chunks + po;
+    sa.pref_work = f->d_pref_work + po;
+    sa.na = s.ls_nactive[rec];
+    sa.step = step;
+    sa.kb = kb;
+    return sa;
+  };
   // ---- forward: leaves -> root
   for (int l = 0; l < s.nlevels; ++l) {
     for (int slot = 0; slot < s.maxslots; ++slot) {
@@ -657,48 +767,31 @@ int sweep(eigd_factor* f, double* dX, int ldx, int kb, double alpha) {
       EIGD_LAUNCH_CHECK();
     }
     for (int step = 0; step < s.lvl_nsteps[l]; ++step) {
-      const int rec = s.ls_ptr[l] + step;
-      const int64_t po = s.ls_pref_ptr[rec];
-      StepArgs sa;
-      sa.fronts = f->d_lvl_fronts + s.lvl_ptr[l];
-      sa.pref_chunks = f->d_pref_chunks + po;
-      sa.na = s.ls_nactive[rec];
-      sa.step = step;
-      sa.kb = kb;
-      const int nchunks = s.pref_chunks[po + sa.na];
-      hipLaunchKernelGGL(fwd_diag_kernel<KPT>, dim3(sa.na), dim3(kThreads), 0, st, fa, sa, f->d_F, f->d_Inv, f->d_V);
+      const StepArgs sa = step_args(l, step);
+      const int nwork = s.pref_work[s.ls_pref_ptr[s.ls_ptr[l] + step] + sa.na];
+      hipLaunchKernelGGL(fwd_step_kernel<KPT>, dim3(nwork), dim3(kThreads), 0, st, fa, sa, f->d_F, f->d_Inv, f->d_V,
+                         f->d_Y);
       EIGD_LAUNCH_CHECK();
-      if (nchunks > sa.na || nchunks > 1) {  // some front has more than one chunk
-        hipLaunchKernelGGL(fwd_update_kernel<KPT>, dim3(nchunks), dim3(kThreads), 0, st, fa, sa, f->d_F, f->d_V);
-        EIGD_LAUNCH_CHECK();
-      }
     }
   }
-  // ---- backward: root -> leaves
+  // ---- backward: root -> leaves.  Y holds the right-hand sides, V receives the solution.
   for (int l = s.nlevels - 1; l >= 0; --l) {
     const int nf = s.lvl_ptr[l + 1] - s.lvl_ptr[l];
-    if (l < s.nlevels - 1 || true) {
-      hipLaunchKernelGGL(vec_gather_kernel, dim3(nf, 4), dim3(kThreads), 0, st, fa, f->d_lvl_fronts + s.lvl_ptr[l], kb,
-                         f->d_V);
+    const int64_t pp = s.lvl_pp_ptr[l];
+    const int npan = s.pref_panels[pp + nf];
+    const int nbw = s.pref_bwork[pp + nf];
+    hipLaunchKernelGGL(bwd_border_kernel<KPT>, dim3(nbw), dim3(kThreads), 0, st, fa, f->d_lvl_fronts + s.lvl_ptr[l],
+                       nf, f->d_pref_bwork + pp, kb, f->d_F, f->d_Inv, f->d_V, f->d_Y, f->d_P);
+    EIGD_LAUNCH_CHECK();
+    if (nbw > npan) {  // some front of the level has more than one tile group
+      hipLaunchKernelGGL(bwd_fold_kernel, dim3(npan), dim3(kThreads), 0, st, fa, f->d_lvl_fronts + s.lvl_ptr[l], nf,
+                         f->d_pref_panels + pp, kb, f->d_P, f->d_Y);
       EIGD_LAUNCH_CHECK();
     }
     for (int step = s.lvl_nsteps[l] - 1; step >= 0; --step) {
-      const int rec = s.ls_ptr[l] + step;
-      const int64_t po = s.ls_pref_ptr[rec];
-      StepArgs sa;
-      sa.fronts = f->d_lvl_fronts + s.lvl_ptr[l];
-      sa.pref_chunks = f->d_pref_chunks + po;
-      sa.na = s.ls_nactive[rec];
-      sa.step = step;
-      sa.kb = kb;
-      const int nchunks = s.pref_chunks[po + sa.na];
-      if (nchunks > sa.na || nchunks > 1) {
-        hipLaunchKernelGGL(bwd_partial_kernel<KPT>, dim3(nchunks), dim3(kThreads), 0, st, fa, sa, f->d_F, f->d_V,
-                           f->d_P);
-        EIGD_LAUNCH_CHECK();
-      }
-      hipLaunchKernelGGL(bwd_diag_kernel<KPT>, dim3(sa.na), dim3(kThreads), 0, st, fa, sa, f->d_F, f->d_Inv, f->d_P,
-                         f->d_V);
+      const StepArgs sa = step_args(l, step);
+      hipLaunchKernelGGL(bwd_step_kernel<KPT>, dim3(sa.na * std::max(1, step)), dim3(kThreads), 0, st, fa, sa, f->d_F,
+                         f->d_Inv, f->d_V, f->d_Y);
       EIGD_LAUNCH_CHECK();
     }
   }
@@ -799,7 +892,8 @@ int eigd_factor_free(eigd_factor* f) {
   void* ptrs[] = {f->d_c0,        f->d_ns,          f->d_bs,         f->d_parent,   f->d_rel,   f->d_foff,
                   f->d_voff,      f->d_ioff,        f->d_bptr,       f->d_lvl_fronts, f->d_pref_chunks,
                   f->d_pref_tiles, f->d_cs_child,   f->d_a_src,      f->d_a_dst,    f->d_v_src, f->d_data,
-                  f->d_F,         f->d_Inv,         f->d_V,          f->d_P,        f->d_flag};
+                  f->d_F,         f->d_Inv,         f->d_V,          f->d_Y,        f->d_flag,  f->d_pref_work,
+                  f->d_pref_panels, f->d_pref_bwork, f->d_poff,     f->d_P};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;
@@ -816,8 +910,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   int64_t max_chunks = 1;
   for (size_t rec = 0; rec < s.ls_nactive.size(); ++rec)
     max_chunks = std::max<int64_t>(max_chunks, s.pref_chunks[s.ls_pref_ptr[rec] + s.ls_nactive[rec]]);
-  const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + s.sumd * KBMAX +
-                                        max_chunks * TW * KBMAX) +
+  const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + 2 * s.sumd * KBMAX + s.nslabs * TW * KBMAX) +
                       16 * s.a_src.size() + (size_t(64) << 20);
   if (need > free_b) {
     set_error("factor needs %.2f GiB of device memory, %.2f GiB free", need / 1073741824.0, free_b / 1073741824.0);
@@ -842,6 +935,10 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   UP(d_lvl_fronts, s.lvl_fronts)
   UP(d_pref_chunks, s.pref_chunks)
   UP(d_pref_tiles, s.pref_tiles)
+  UP(d_pref_work, s.pref_work)
+  UP(d_pref_panels, s.pref_panels)
+  UP(d_pref_bwork, s.pref_bwork)
+  UP(d_poff, s.f_poff)
   UP(d_cs_child, s.cs_child)
   UP(d_a_src, s.a_src)
   UP(d_a_dst, s.a_dst)
@@ -866,7 +963,8 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   rc = dmalloc(&f->d_F, s.front_doubles);
   rc = dmalloc(&f->d_Inv, s.inv_doubles);
   rc = dmalloc(&f->d_V, static_cast<size_t>(s.sumd) * KBMAX);
-  rc = dmalloc(&f->d_P, static_cast<size_t>(max_chunks) * TW * KBMAX);
+  rc = dmalloc(&f->d_Y, static_cast<size_t>(s.sumd) * KBMAX);
+  rc = dmalloc(&f->d_P, static_cast<size_t>(std::max<int64_t>(s.nslabs, 1)) * TW * KBMAX);
   if (rc == EIGD_OK) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_flag), sizeof(int));
     if (e != hipSuccess) {

@@ -36,7 +36,17 @@ def _solve_basic(g, A, B, sigma, mode, prefix="", **kw):
         warnings.simplefilter("ignore")
         lam, Phi = s.solve(A, B, factor, sigma)
     assert s.N == int(g[prefix + "N"])
-    assert np.array_equal(s.indices[: s.N], g[prefix + "indices"][: s.N])   # bit-exact mode ordering
+    # mode ordering: identical index sequence, except inside clusters of numerically equal Ritz values
+    # (e.g. the three rigid-body modes at lam ~ 1e-15), whose internal order is decided by round-off
+    mine, ref = s.indices[: s.N], g[prefix + "indices"][: s.N]
+    lam_ref = g[prefix + "lam"]
+    start = 0
+    for e in range(1, s.N + 1):
+        if e == s.N or abs(lam_ref[e] - lam_ref[e - 1]) > 1e-9 * max(1.0, abs(lam_ref[e])):
+            assert sorted(mine[start:e]) == sorted(ref[start:e])
+            if e - start == 1:
+                assert mine[start] == ref[start]
+            start = e
     assert relerr(lam, g[prefix + "lam"]) < RTOL
     assert relerr(s.alpha[:5], g[prefix + "alpha"][:5]) < 1e-9
     assert relerr(s.beta[:5], g[prefix + "beta"][:5]) < 1e-9
