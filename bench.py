@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--cpu-sample", choices=("full", "small", "none"), default="full",
                     help="CPU baseline: full = SuperLU factor of the same 1M-dof matrix + 1 mode; small = 200k-dof replica")
     ap.add_argument("--spmv-reps", type=int, default=200)
+    ap.add_argument("--pyprofile", default=None, help="write a cProfile summary of one extra step to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,10 +167,14 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
+    step_times = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         dpsi, data, dfdx = step()
+        step_times.append(time.perf_counter() - ts)
     fence()
     elapsed = time.perf_counter() - t0
+    log(rank, "step times (s):", [round(t, 3) for t in step_times])
     if comm is not None:
         elapsed = comm.allreduce_max(elapsed)
     adj_count = factor.count
@@ -178,6 +183,17 @@ def main():
 
     if rank != 0:
         return
+    if args.pyprofile:
+        import cProfile
+        import pstats
+
+        pr = cProfile.Profile()
+        pr.enable()
+        step()
+        ctx.sync()
+        pr.disable()
+        with open(args.pyprofile, "w") as fh:
+            pstats.Stats(pr, stream=fh).sort_stats("cumulative").print_stats(45)
     # ------------------------------------------------------------------ accuracy of the timed result
     res, ortho = solver.eval_adjoint_residual_norm(dPhib, dpsi, b_ortho=False) if world == 1 else (None, None)
     accuracy = {}

@@ -420,19 +420,29 @@ def solve_shifted_lstsq(alpha, H, r):
     return y, np.linalg.norm(H0 @ y - r)
 
 
-def _cgs2(Wst, T, ns):
-    """T <- (I - W W^T) T twice over the first ns slabs; returns the summed coefficients (ns x k)"""
-    h1 = Wst.dot(T, ns=ns)
-    Wst.axpy_into(T, h1, alpha=-1.0)
-    h2 = Wst.dot(T, ns=ns)
-    Wst.axpy_into(T, h2, alpha=-1.0)
+def _cgs2(Wst, T, ns, c0=0):
+    """T <- (I - W W^T) T twice over the first ns slabs (columns c0.. of the stack); returns the summed coefficients"""
+    h1 = Wst.dot(T, ns=ns, c0=c0)
+    Wst.axpy_into(T, h1, alpha=-1.0, c0=c0)
+    h2 = Wst.dot(T, ns=ns, c0=c0)
+    Wst.axpy_into(T, h2, alpha=-1.0, c0=c0)
     return h1 + h2
+
+
+def _active_range(done):
+    """smallest column range [lo, hi) holding every unfinished mode (low modes finish first)"""
+    live = np.flatnonzero(~done)
+    return int(live[0]), int(live[-1]) + 1
 
 
 def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     """
     One attempt of the bs_target=1 solver for all columns of R0 at once.
     Returns (update block dpsi, converged flags, info list).
+
+    The modes advance in lock step; every operator application acts on the contiguous column
+    range that still holds unfinished modes (the range shrinks as the low modes converge), so
+    late iterations do not pay for finished columns.
     """
     ctx, mode = prob.ctx, prob.mode
     k = R0.k
@@ -451,7 +461,7 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     if done.all():
         return dpsi, converged, info
     W = ctx.stack(maxiter + 1, prob.n, k)
-    Z = ctx.stack(maxiter, prob.n, k)
+    Z = ctx.stack(maxiter, prob.n, k).zero()             # finished columns keep zero (never NaN) entries
     W0 = W[0]
     W0.copy_from(R0)
     prob.project_r(W0)                                   # ref 1232
@@ -464,21 +474,21 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     jlast = 0
     for j in range(1, maxiter + 1):
         kp = j - 1
-        Zk = Z[kp]
-        Zk.copy_from(W[kp])
-        prob.fac(Zk, count=int(np.count_nonzero(~done)))  # ref 1248: one k-column sweep
-        Kop.apply(Zk, T)                                 # ref 1250 / 1252
-        prob.project_r(T)
-        h = _cgs2(W, T, j)                               # ref 1254-1256 (Gram-Schmidt vs all previous W)
-        prob.project_r(T)                                # ref 1257
-        hn = T.colnorms()                                # ref 1259
+        lo, hi = _active_range(done)
+        Zk, Ta = Z[kp].cols(lo, hi), T.cols(lo, hi)
+        Zk.copy_from(W[kp].cols(lo, hi))
+        prob.fac(Zk, count=int(np.count_nonzero(~done)))  # ref 1248: one multi-column sweep
+        Kop.apply(Zk, Ta)                                # ref 1250 / 1252
+        prob.project_r(Ta)
+        h = _cgs2(W, Ta, j, c0=lo)                       # ref 1254-1256 (Gram-Schmidt vs all previous W)
+        prob.project_r(Ta)                               # ref 1257
+        hn = Ta.colnorms()                               # ref 1259
         jlast = j
-        newly = []
-        for c in range(k):
+        for c in range(lo, hi):
             if done[c]:
                 continue
-            H[c, :j, kp] = h[:, c]
-            H[c, j, kp] = hn[c]
+            H[c, :j, kp] = h[:, c - lo]
+            H[c, j, kp] = hn[c - lo]
             rvec = np.zeros(j + 1)
             rvec[0] = r00[c]
             y, res = solve_shifted_lstsq(sgn * (lam_c[c] - sigma), H[c, : j + 1, :j], rvec)  # ref 1262-1270
@@ -487,14 +497,14 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
                 info[c] = j
                 Ycoef[:j, c] = y
                 done[c] = converged[c] = True
-                newly.append(c)
             elif j == maxiter:                           # ref 1312-1313: keep the best iterate
                 Ycoef[:j, c] = y
                 done[c] = True
         if done.all():
             break
-        scale = np.where(done | (hn == 0.0), 0.0, 1.0 / np.where(hn == 0.0, 1.0, hn))
-        W[j].assign_lincomb([(scale, T)])                # ref 1260
+        dn = done[lo:hi]
+        scale = np.where(dn | (hn == 0.0), 0.0, 1.0 / np.where(hn == 0.0, 1.0, hn))
+        W[j].cols(lo, hi).assign_lincomb([(scale, Ta)])  # ref 1260
     Z.axpy_into(dpsi, Ycoef[:jlast], alpha=1.0)          # ref 1277 / 1313: psi += Z y
     return dpsi, converged, info
 
@@ -681,7 +691,7 @@ def _pgmres_device(prob, dPhib, dpsi, lam_c, rtol, atol, maxiter, callback, rnor
             done[c] = True
     if not done.all():
         W = ctx.stack(maxiter + 1, prob.n, k)
-        Z = ctx.stack(maxiter, prob.n, k)
+        Z = ctx.stack(maxiter, prob.n, k).zero()
         scale = np.where(done | (beta == 0.0), 0.0, 1.0 / np.where(beta == 0.0, 1.0, beta))
         W[0].assign_lincomb([(scale, R)])
         H = np.zeros((k, maxiter + 1, maxiter))
@@ -689,20 +699,21 @@ def _pgmres_device(prob, dPhib, dpsi, lam_c, rtol, atol, maxiter, callback, rnor
         T = ctx.empty(prob.n, k)
         jlast = 0
         for j in range(maxiter):
-            Zj = Z[j]
-            Zj.copy_from(W[j])
+            lo, hi = _active_range(done)
+            Zj, Ta = Z[j].cols(lo, hi), T.cols(lo, hi)
+            Zj.copy_from(W[j].cols(lo, hi))
             prob.project_r(Zj)                           # ref 963: oper = factor(project(x))
             prob.fac(Zj, count=int(np.count_nonzero(~done)))
-            prob.adjoint_operator(Zj, lam_c, out=T)      # ref 1004-1010
-            prob.project_r(T)
-            h = _cgs2(W, T, j + 1)                       # ref 1012-1014
-            hn = T.colnorms()                            # ref 1016
+            prob.adjoint_operator(Zj, lam_c[lo:hi], out=Ta)  # ref 1004-1010
+            prob.project_r(Ta)
+            h = _cgs2(W, Ta, j + 1, c0=lo)               # ref 1012-1014
+            hn = Ta.colnorms()                           # ref 1016
             jlast = j + 1
-            for c in range(k):
+            for c in range(lo, hi):
                 if done[c]:
                     continue
-                H[c, : j + 1, j] = h[:, c]
-                H[c, j + 1, j] = hn[c]
+                H[c, : j + 1, j] = h[:, c - lo]
+                H[c, j + 1, j] = hn[c - lo]
                 rhs = np.zeros(j + 2)
                 rhs[0] = beta[c]
                 Hj = H[c, : j + 2, : j + 1]
@@ -719,8 +730,9 @@ def _pgmres_device(prob, dPhib, dpsi, lam_c, rtol, atol, maxiter, callback, rnor
                     done[c] = True
             if done.all():
                 break
-            scale = np.where(done | (hn == 0.0), 0.0, 1.0 / np.where(hn == 0.0, 1.0, hn))
-            W[j + 1].assign_lincomb([(scale, T)])
+            dn = done[lo:hi]
+            scale = np.where(dn | (hn == 0.0), 0.0, 1.0 / np.where(hn == 0.0, 1.0, hn))
+            W[j + 1].cols(lo, hi).assign_lincomb([(scale, Ta)])
         Z.axpy_into(dpsi, Ycoef[:jlast], alpha=1.0)      # ref 1028 / 1032
     _emit(callback, hist, range(k))
     return Gc, info

@@ -61,8 +61,8 @@ __global__ __launch_bounds__(kThreads) void coldot_kernel(int n, int k, const do
 // ---------------------------------------------------------------------------
 template <int KP, int JB>
 __global__ __launch_bounds__(kThreads) void stack_dot_kernel(int n, int k, int nj, const double* __restrict__ S,
-                                                            int64_t slab, const double* __restrict__ T, int ldt,
-                                                            double* __restrict__ partial) {
+                                                            int64_t slab, int lds, const double* __restrict__ T,
+                                                            int ldt, double* __restrict__ partial) {
   constexpr int RP = kThreads / KP;
   __shared__ double red[kThreads];
   const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
@@ -72,10 +72,12 @@ __global__ __launch_bounds__(kThreads) void stack_dot_kernel(int n, int k, int n
   if (c < k)
     for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
       const double t = T[r * ldt + c];
-      const double* sp = S + r * k + c;
+      const double* sp = S + r * lds + c;
+      double sv[JB];
 #pragma unroll
-      for (int j = 0; j < JB; ++j)
-        if (j < nj) acc[j] += sp[j * slab] * t;
+      for (int j = 0; j < JB; ++j) sv[j] = (j < nj) ? sp[j * slab] : 0.0;
+#pragma unroll
+      for (int j = 0; j < JB; ++j) acc[j] += sv[j] * t;
     }
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(kThreads) void stack_dot_kernel(int n, int k, int n
 // T[r][c] += alpha * sum_j S_j[r][c] * H[j][c]   (H on the device, ns x k)
 template <int KP>
 __global__ __launch_bounds__(kThreads) void stack_axpy_kernel(int n, int k, int ns, const double* __restrict__ S,
-                                                             int64_t slab, const double* __restrict__ H,
+                                                             int64_t slab, int lds, const double* __restrict__ H,
                                                              double* __restrict__ T, int ldt, double alpha) {
   constexpr int RP = kThreads / KP;
   extern __shared__ double Hs[];  // ns * k
@@ -102,9 +104,17 @@ __global__ __launch_bounds__(kThreads) void stack_axpy_kernel(int n, int k, int 
   const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
   if (c >= k) return;
   for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
-    const double* sp = S + r * k + c;
+    const double* sp = S + r * lds + c;
     double s = 0.0;
-    for (int j = 0; j < ns; ++j) s += sp[j * slab] * Hs[j * k + c];
+    int j = 0;
+    for (; j + 8 <= ns; j += 8) {
+      double sv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sv[q] = sp[(j + q) * slab];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += sv[q] * Hs[(j + q) * k + c];
+    }
+    for (; j < ns; ++j) s += sp[j * slab] * Hs[j * k + c];
     T[r * ldt + c] += alpha * s;
   }
 }
@@ -134,65 +144,56 @@ __global__ __launch_bounds__(kThreads) void lincomb_kernel(int n, int k, double*
 }
 
 // ---------------------------------------------------------------------------
-// C = U^T X  (partials per workgroup), U(r,a) = U[r*rsu + a*csu]
+// C = U^T X  (partials per workgroup), U(r,a) = U[r*rsu + a*csu].
+// The ku x kx result is cut into 16 x 16 tiles; a wave accumulates its tiles with
+// v_mfma_f64_16x16x4_f64 (K = 4 rows per instruction), lane (i = l&15, k = l>>4) feeding
+// A[i][k] = U(r+k, a0+i) and B[k][j] = X(r+k, b0+j) straight from global memory -- sixteen row
+// quads are in flight per wave, no LDS staging.  This is the dense projection Phi^T X / V^T Phib.
 // ---------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(int n, int ku, int kx, const double* __restrict__ U,
                                                           int64_t rsu, int64_t csu, const double* __restrict__ X,
                                                           int ldx, double* __restrict__ partial) {
-  __shared__ double Us[kRB][kMaxK + 1];
-  __shared__ double Xs[kRB][kMaxK + 1];
-  const int tid = threadIdx.x;
-  const int a0 = (tid / 16) * 4, b0 = (tid % 16) * 4;
-  double acc[4][4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int nta = (ku + 15) >> 4, ntb = (kx + 15) >> 4;
+  const int ntiles = nta * ntb;  // <= 16
+  double4_t acc[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-  // zero the padding columns once
-  for (int q = tid; q < kRB * (kMaxK + 1); q += kThreads) {
-    (&Us[0][0])[q] = 0.0;
-    (&Xs[0][0])[q] = 0.0;
-  }
-  __syncthreads();
+  for (int t = 0; t < 4; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
   for (int64_t base = static_cast<int64_t>(blockIdx.x) * kRB; base < n; base += static_cast<int64_t>(gridDim.x) * kRB) {
-    const int rows = static_cast<int>((n - base) < kRB ? (n - base) : kRB);
-    if (rsu == 1) {
-      for (int q = tid; q < kRB * ku; q += kThreads) {
-        const int r = q % kRB, a = q / kRB;
-        Us[r][a] = (r < rows) ? U[(base + r) + a * csu] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile >= ntiles) break;
+      const int ta = tile / ntb, tb = tile - ta * ntb;
+      const int a = ta * 16 + li, b = tb * 16 + li;
+      const bool oka = a < ku, okb = b < kx;
+      double av[kRB / 4], bv[kRB / 4];
+#pragma unroll
+      for (int q = 0; q < kRB / 4; ++q) {
+        const int64_t r = base + q * 4 + lk;
+        const bool okr = r < n;
+        av[q] = (okr && oka) ? U[r * rsu + a * csu] : 0.0;
+        bv[q] = (okr && okb) ? X[r * ldx + b] : 0.0;
       }
-    } else {
-      for (int q = tid; q < kRB * ku; q += kThreads) {
-        const int a = q % ku, r = q / ku;
-        Us[r][a] = (r < rows) ? U[(base + r) * rsu + a * csu] : 0.0;
-      }
+#pragma unroll
+      for (int q = 0; q < kRB / 4; ++q) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc[t], 0, 0, 0);
     }
-    for (int q = tid; q < kRB * kx; q += kThreads) {
-      const int b = q % kx, r = q / kx;
-      Xs[r][b] = (r < rows) ? X[(base + r) * ldx + b] : 0.0;
-    }
-    __syncthreads();
-    if (a0 < ku && b0 < kx) {
-      for (int r = 0; r < kRB; ++r) {
-        double u[4], x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] = Us[r][a0 + i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = Xs[r][b0 + j];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] += u[i] * x[j];
-      }
-    }
-    __syncthreads();
   }
   double* p = partial + static_cast<int64_t>(blockIdx.x) * ku * kx;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int t = 0; t < 4; ++t) {
+    const int tile = wave + 4 * t;
+    if (tile >= ntiles) break;
+    const int ta = tile / ntb, tb = tile - ta * ntb;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (a0 + i < ku && b0 + j < kx) p[(a0 + i) * kx + b0 + j] = acc[i][j];
+    for (int reg = 0; reg < 4; ++reg) {
+      const int a = ta * 16 + lk + 4 * reg, b = tb * 16 + li;  // f64 MFMA result map: row = (l>>4) + 4*reg, col = l&15
+      if (a < ku && b < kx) p[a * kx + b] = acc[t][reg];
+    }
+  }
 }
 
 // X[r][b] = beta * X[r][b] + alpha * sum_a U(r,a) C[a][b], C on the device (ku x kx)
@@ -208,15 +209,31 @@ __global__ __launch_bounds__(kThreads) void gemm_nn_kernel(int n, int ku, int kx
   for (int64_t base = static_cast<int64_t>(blockIdx.x) * kRB; base < n; base += static_cast<int64_t>(gridDim.x) * kRB) {
     const int rows = static_cast<int>((n - base) < kRB ? (n - base) : kRB);
     __syncthreads();
-    if (rsu == 1) {
-      for (int q = tid; q < kRB * ku; q += kThreads) {
-        const int rr = q % kRB, a = q / kRB;
-        Us[rr][a] = (rr < rows) ? U[(base + rr) + a * csu] : 0.0;
+    {
+      constexpr int IT = kRB * kMaxK / kThreads;  // 16 staged elements per lane
+      double tmp[IT];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int qq = tid + it * kThreads;
+        int rr, a;
+        if (rsu == 1) {
+          rr = qq % kRB;
+          a = qq / kRB;
+        } else {
+          a = qq % ku;
+          rr = qq / ku;
+        }
+        tmp[it] = (qq < kRB * ku && rr < rows) ? U[(base + rr) * rsu + a * csu] : 0.0;
       }
-    } else {
-      for (int q = tid; q < kRB * ku; q += kThreads) {
-        const int a = q % ku, rr = q / ku;
-        Us[rr][a] = (rr < rows) ? U[(base + rr) * rsu + a * csu] : 0.0;
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int qq = tid + it * kThreads;
+        if (qq < kRB * ku) {
+          if (rsu == 1)
+            Us[qq % kRB][qq / kRB] = tmp[it];
+          else
+            Us[qq / ku][qq % ku] = tmp[it];
+        }
       }
     }
     __syncthreads();
@@ -390,36 +407,40 @@ int eigd_lincomb(eigd_ctx* ctx, int n, int k, double* dOut, int ldo, int nterms,
   return EIGD_OK;
 }
 
-int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, const double* dT, int ldt,
-                   double* hH) {
+int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* dT,
+                   int ldt, double* hH) {
   EIGD_REQUIRE(ctx && dS && dT && hH, "null argument");
-  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && slab >= static_cast<int64_t>(n) * k,
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && lds >= k &&
+                   slab >= static_cast<int64_t>(n - 1) * lds + k,
                "bad shape n=%d k=%d ns=%d", n, k, ns);
-  constexpr int JB = 8;
+  constexpr int JB = 16;
   const int kp = next_pow2(k);
   const int nb = grid_for_rows(n, (kThreads / kp) * 8);
-  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) + 1) * JB * k + sizeof(double) * ns * k);
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) * JB * k + static_cast<size_t>(ns) * k));
   if (rc) return rc;
-  double* res = ctx->scratch;                  // JB * k
-  double* partial = ctx->scratch + JB * k;     // nb * JB * k
+  double* res = ctx->scratch;                               // ns * k results
+  double* partial = ctx->scratch + static_cast<size_t>(ns) * k;  // nb * JB * k
   for (int j0 = 0; j0 < ns; j0 += JB) {
     const int nj = std::min(JB, ns - j0);
     rc = dispatch_kp(k, [&](auto KP) {
       hipLaunchKernelGGL((stack_dot_kernel<decltype(KP)::value, JB>), dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, nj,
-                         dS + j0 * slab, slab, dT, ldt, partial);
+                         dS + j0 * slab, slab, lds, dT, ldt, partial);
     });
     if (rc) return rc;
     EIGD_LAUNCH_CHECK();
-    rc = reduce_to_host(ctx, partial, nb, nj * k, res, hH + static_cast<size_t>(j0) * k);
+    rc = reduce_to_host(ctx, partial, nb, nj * k, res + static_cast<size_t>(j0) * k, nullptr);
     if (rc) return rc;
   }
+  EIGD_HIP(hipMemcpyAsync(hH, res, sizeof(double) * ns * k, hipMemcpyDeviceToHost, ctx->stream));
+  EIGD_HIP(hipStreamSynchronize(ctx->stream));
   return EIGD_OK;
 }
 
-int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, const double* hH, double* dT,
-                    int ldt, double alpha) {
+int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* hH,
+                    double* dT, int ldt, double alpha) {
   EIGD_REQUIRE(ctx && dS && dT && hH, "null argument");
-  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && slab >= static_cast<int64_t>(n) * k,
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && lds >= k &&
+                   slab >= static_cast<int64_t>(n - 1) * lds + k,
                "bad shape n=%d k=%d ns=%d", n, k, ns);
   EIGD_REQUIRE(static_cast<size_t>(ns) * k * sizeof(double) <= 60 * 1024, "stack too deep for one pass: ns*k=%d", ns * k);
   int rc = ctx->ensure_coef(sizeof(double) * ns * k);
@@ -430,7 +451,7 @@ int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
   const int nb = grid_for_rows(n, (kThreads / kp) * 4);
   rc = dispatch_kp(k, [&](auto KP) {
     hipLaunchKernelGGL(stack_axpy_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), sizeof(double) * ns * k,
-                       ctx->stream, n, k, ns, dS, slab, ctx->coef, dT, ldt, alpha);
+                       ctx->stream, n, k, ns, dS, slab, lds, ctx->coef, dT, ldt, alpha);
   });
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();

@@ -87,7 +87,23 @@ __global__ __launch_bounds__(kThreads) void spmm_rows_kernel(int n, int k, const
   if (r >= n || c >= k) return;
   const int a = indptr[r], z = indptr[r + 1];
   double s = 0.0;
-  for (int e = a; e < z; ++e) s = __dadd_rn(s, __dmul_rn(vals[e], X[static_cast<int64_t>(indices[e]) * ldx + c]));
+  int e = a;
+  // eight non-zeros per trip: index / value / gathered-row loads are all issued before the first add;
+  // the adds stay in CSR order (bit-identical to scipy's csr_matvecs)
+  for (; e + 8 <= z; e += 8) {
+    int col[8];
+    double v[8], x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      col[q] = indices[e + q];
+      v[q] = vals[e + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = X[static_cast<int64_t>(col[q]) * ldx + c];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s = __dadd_rn(s, __dmul_rn(v[q], x[q]));
+  }
+  for (; e < z; ++e) s = __dadd_rn(s, __dmul_rn(vals[e], X[static_cast<int64_t>(indices[e]) * ldx + c]));
   double* yp = Y + static_cast<int64_t>(r) * ldy + c;
   *yp = (beta == 0.0) ? alpha * s : alpha * s + beta * (*yp);
 }

@@ -262,6 +262,10 @@ class DeviceStack:
             raise IndexError(j)
         return DeviceBlock(self.ctx, self.n, self.k, self.buf, j * self.slab, self.k)
 
+    def zero(self):
+        call("eigd_memset", self.ctx.h, self.ptr, 0, 8 * self.ns * self.slab)
+        return self
+
     @property
     def ptr(self):
         return c_vp(self.buf.ptr)
@@ -269,23 +273,24 @@ class DeviceStack:
     def slab_ptr(self, j):
         return c_vp(self.buf.ptr + 8 * j * self.slab)
 
-    def dot(self, T, ns=None, j0=0):
-        """H[j, c] = S_j[:, c] . T[:, c]  for j in [j0, j0+ns)"""
+    def dot(self, T, ns=None, j0=0, c0=0):
+        """H[j, c] = S_j[:, c0 + c] . T[:, c]  for j in [j0, j0+ns), c in [0, T.k)"""
         ns = self.ns - j0 if ns is None else ns
-        H = np.empty((ns, self.k))
+        H = np.empty((ns, T.k))
         if ns > 0:
-            call("eigd_stack_dot", self.ctx.h, self.n, self.k, ns, self.slab_ptr(j0), self.slab, T.ptr, T.ld, hptr(H))
+            call("eigd_stack_dot", self.ctx.h, self.n, T.k, ns, c_vp(self.buf.ptr + 8 * (j0 * self.slab + c0)),
+                 self.slab, self.k, T.ptr, T.ld, hptr(H))
         return H
 
-    def axpy_into(self, T, H, alpha=1.0, j0=0):
-        """T[:, c] += alpha * sum_j S_{j0+j}[:, c] H[j, c]"""
-        H = np.ascontiguousarray(H, dtype=np.float64).reshape(-1, self.k)
+    def axpy_into(self, T, H, alpha=1.0, j0=0, c0=0):
+        """T[:, c] += alpha * sum_j S_{j0+j}[:, c0 + c] H[j, c]"""
+        H = np.ascontiguousarray(H, dtype=np.float64).reshape(-1, T.k)
         ns = H.shape[0]
-        step = max(1, (60 * 1024) // (8 * self.k))
+        step = max(1, (60 * 1024) // (8 * T.k))
         for a in range(0, ns, step):
             b = min(ns, a + step)
-            call("eigd_stack_axpy", self.ctx.h, self.n, self.k, b - a, self.slab_ptr(j0 + a), self.slab,
-                 hptr(np.ascontiguousarray(H[a:b])), T.ptr, T.ld, float(alpha))
+            call("eigd_stack_axpy", self.ctx.h, self.n, T.k, b - a, c_vp(self.buf.ptr + 8 * ((j0 + a) * self.slab + c0)),
+                 self.slab, self.k, hptr(np.ascontiguousarray(H[a:b])), T.ptr, T.ld, float(alpha))
         return T
 
     # k == 1 stacks double as column-major n x ns matrices (the Lanczos basis)

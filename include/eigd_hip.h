@@ -125,13 +125,14 @@ int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const do
  * (the w-vector / residual assembly of 96-134, 807-809, 1189-1192, axpys 851-860)      */
 int eigd_lincomb(eigd_ctx* ctx, int n, int k, double* dOut, int ldo, int nterms, const double* const* dXs,
                  const int* ldxs, const double* hcoef);
-/* batched Gram-Schmidt against a stack of ns slabs (each n x k, ld = k, element stride `slab`):
+/* batched Gram-Schmidt against a stack of ns slabs (each n x k, leading dimension lds, element stride `slab`;
+ * a column range of a wider stack is addressed by offsetting dS and keeping lds):
  *   stack_dot : hH[j*k + c] = sum_r S_j[r,c] T[r,c]            (1229, 1255, 1013, 1530)
  *   stack_axpy: T[r,c] += alpha * sum_j S_j[r,c] hH[j*k + c]    (1230, 1256, 1014, 1531, 1277) */
-int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, const double* dT, int ldt,
-                   double* hH);
-int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, const double* hH, double* dT,
-                    int ldt, double alpha);
+int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* dT,
+                   int ldt, double* hH);
+int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* hH,
+                    double* dT, int ldt, double alpha);
 /* copy an n x k block between buffers with different leading dimensions / column offsets */
 int eigd_copy_block(eigd_ctx* ctx, int n, int k, const double* dSrc, int lds, double* dDst, int ldd);
 /* gather columns: Dst[r, j] = Src[r, cols[j]] (compaction of the active modes) */
