@@ -290,27 +290,80 @@ __global__ __launch_bounds__(kThreads) void vec_extend_add_kernel(FrontArrays fa
   }
 }
 
-// 64 x (4*KPT) output tile, thread (o = tid/4, cg = tid%4) owns KPT columns.
-//   TRANS == false : acc[o][c] += sum_k As[k*TLD + o] * Bs[k*KB + c]
-//   TRANS == true  : acc[o][c] += sum_k As[o*TLD + k] * Bs[k*KB + c]
-// kdim is rounded up to a multiple of 8 (tiles are zero padded to 64) so the loop unrolls and the
-// LDS reads of eight k-steps are in flight together.
-template <int KPT, bool TRANS>
-__device__ __forceinline__ void tile_mac(const double* __restrict__ As, const double* __restrict__ Bs, int kdim, int o,
-                                         int cg, double (&acc)[KPT]) {
-  constexpr int KB = 4 * KPT;
-  const int kd = (kdim + 7) & ~7;
-  for (int k0 = 0; k0 < kd; k0 += 8) {
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const int k = k0 + kk;
-      const double a = TRANS ? As[o * TLD + k] : As[k * TLD + o];
-      const double* b = Bs + k * KB + cg * KPT;
-#pragma unroll
-      for (int q = 0; q < KPT; ++q) acc[q] += a * b[q];
+// ---------------------------------------------------------------------------
+// Tile products of the sweeps.  A workgroup produces a 64 x KB block of outputs (KB = 4*KPT >= k)
+// from a 64 x 64 tile As of the factor and a 64 x KB block Bs of right-hand sides, both in LDS:
+//   TRANS == false : out[o][c] += sum_k As[k*TLD + o] * Bs[k*BLD + c]
+//   TRANS == true  : out[o][c] += sum_k As[o*TLD + k] * Bs[k*BLD + c]
+//
+//  * k <= 8  (KPT 1, 2): vector FMAs, lane (o = tid/4, cg = tid%4) owns KPT columns of row o.
+//  * k > 8   (KPT 4, 8): v_mfma_f64_16x16x4_f64.  Wave w owns output rows 16w..16w+15 and all KB/16
+//    column tiles; per K-step of 4 a lane feeds ONE double of A and one of B per tile, so the LDS
+//    traffic per flop is ~9x lower than the vector form (which is LDS-bound at KB = 32).  Result map of
+//    the f64 MFMA: acc[reg] <-> (row = (lane>>4) + 4*reg, col = lane&15) inside the 16 x 16 tile.
+// ---------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+template <int KPT>
+struct Tile {
+  static constexpr bool kMfma = (KPT >= 4);
+  static constexpr int KB = 4 * KPT;
+  static constexpr int NT = kMfma ? KB / 16 : 1;            // 16-wide column tiles per wave
+  static constexpr int BLD = (KB == 32) ? 48 : KB;          // LDS row stride of Bs (48: conflict-free b-operand reads)
+  static constexpr int NOUT = kMfma ? 4 * NT : KPT;         // outputs per lane
+
+  __device__ static __forceinline__ void coords(int t, int& row, int& col) {
+    if (kMfma) {
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      row = 16 * wave + (lane >> 4) + 4 * (t & 3);
+      col = 16 * (t >> 2) + (lane & 15);
+    } else {
+      row = threadIdx.x >> 2;
+      col = (threadIdx.x & 3) * KPT + t;
     }
   }
-}
+
+  template <bool TRANS>
+  __device__ static __forceinline__ void mac(const double* __restrict__ As, const double* __restrict__ Bs, int kdim,
+                                             double (&acc)[NOUT]) {
+    if constexpr (kMfma) {
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int li = lane & 15, lk = lane >> 4;
+      const int o = 16 * wave + li;
+      double4_t c[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) c[n] = double4_t{acc[4 * n], acc[4 * n + 1], acc[4 * n + 2], acc[4 * n + 3]};
+      const int kd = (kdim + 7) & ~7;
+      for (int k0 = 0; k0 < kd; k0 += 8) {
+#pragma unroll
+        for (int kk = 0; kk < 8; kk += 4) {
+          const int k = k0 + kk + lk;
+          const double a = TRANS ? As[o * TLD + k] : As[k * TLD + o];
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[k * BLD + 16 * n + li], c[n], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[4 * n + r] = c[n][r];
+    } else {
+      const int o = threadIdx.x >> 2, cg = threadIdx.x & 3;
+      const int kd = (kdim + 7) & ~7;
+      for (int k0 = 0; k0 < kd; k0 += 8) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const int k = k0 + kk;
+          const double a = TRANS ? As[o * TLD + k] : As[k * TLD + o];
+          const double* b = Bs + k * BLD + cg * KPT;
+#pragma unroll
+          for (int q = 0; q < KPT; ++q) acc[q] += a * b[q];
+        }
+      }
+    }
+  }
+};
 
 struct StepArgs {
   const int* fronts;       // active fronts of this (level, step), npanels descending
@@ -366,40 +419,26 @@ __device__ __forceinline__ void load_inverse(double* As, const double* __restric
   for (int it = 0; it < TILE_IT; ++it) As[(jb + it * (kThreads / TW)) * TLD + i] = tmp[it];
 }
 
-// Bs[r*KB + c] = Vrows[r*kb + c] (r < rows), zero padded to 64 x KB
+// Bs[r*BLD + c] = Vrows[rowmap(r)*kb + c] (r < rows), zero padded to 64 x KB; rel == nullptr: rowmap(r) = r.
+// Optionally mirrored into Vdst[r*kb + c].
 template <int KPT>
-__device__ __forceinline__ void load_vec_rows(double* Bs, const double* __restrict__ Vrows, int kb, int rows) {
-  constexpr int KB = 4 * KPT;
-  constexpr int IT = TW * KB / kThreads;  // KPT elements per lane
+__device__ __forceinline__ void load_vec_rows(double* Bs, const double* Vsrc, const int* __restrict__ rel, int kb,
+                                              int rows, double* Vdst) {
+  using T = Tile<KPT>;
+  constexpr int IT = TW * T::KB / kThreads;  // KPT elements per lane
   double tmp[IT];
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int idx = threadIdx.x + it * kThreads;
-    const int r = idx / KB, c = idx - r * KB;
-    tmp[it] = (r < rows && c < kb) ? Vrows[static_cast<int64_t>(r) * kb + c] : 0.0;
-  }
-#pragma unroll
-  for (int it = 0; it < IT; ++it) Bs[threadIdx.x + it * kThreads] = tmp[it];
-}
-
-// Bs[r*KB + c] = Vsrc[rel[r]*kb + c] (gathered rows), zero padded; optionally mirrored into Vdst[r*kb + c]
-template <int KPT>
-__device__ __forceinline__ void load_vec_rows_rel(double* Bs, const double* Vsrc, const int* __restrict__ rel, int kb,
-                                                  int rows, double* Vdst) {
-  constexpr int KB = 4 * KPT;
-  constexpr int IT = TW * KB / kThreads;
-  double tmp[IT];
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
-    const int idx = threadIdx.x + it * kThreads;
-    const int r = idx / KB, c = idx - r * KB;
-    tmp[it] = (r < rows && c < kb) ? Vsrc[static_cast<int64_t>(rel[r]) * kb + c] : 0.0;
+    const int r = idx / T::KB, c = idx - r * T::KB;
+    const int64_t src = (rel != nullptr && r < rows) ? rel[r] : r;
+    tmp[it] = (r < rows && c < kb) ? Vsrc[src * kb + c] : 0.0;
   }
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int idx = threadIdx.x + it * kThreads;
-    const int r = idx / KB, c = idx - r * KB;
-    Bs[idx] = tmp[it];
+    const int r = idx / T::KB, c = idx - r * T::KB;
+    Bs[r * T::BLD + c] = tmp[it];
     if (Vdst != nullptr && r < rows && c < kb) Vdst[static_cast<int64_t>(r) * kb + c] = tmp[it];
   }
 }
@@ -412,9 +451,9 @@ template <int KPT>
 __global__ __launch_bounds__(kThreads) void fwd_step_kernel(FrontArrays fa, StepArgs sa, const double* __restrict__ F,
                                                            const double* __restrict__ Inv, double* __restrict__ V,
                                                            double* __restrict__ Y) {
-  constexpr int KB = 4 * KPT;
+  using T = Tile<KPT>;
   __shared__ double As[TW * TLD];
-  __shared__ double Bs[TW * KB];
+  __shared__ double Bs[TW * T::BLD];
   const int q = find_slot(sa.pref_work, sa.na, blockIdx.x);
   const int chunk = blockIdx.x - sa.pref_work[q];
   const int f = sa.fronts[q];
@@ -426,24 +465,21 @@ __global__ __launch_bounds__(kThreads) void fwd_step_kernel(FrontArrays fa, Step
   const int w = min(W, ns - j0);
   const int j1 = j0 + w;
   double* Vf = V + fa.voff[f] * kb;
-  const int tid = threadIdx.x, o = tid / 4, cg = tid % 4;
   load_inverse(As, Inv + fa.ioff[f] + static_cast<int64_t>(sa.step) * W * W, W, w);
-  load_vec_rows<KPT>(Bs, Vf + static_cast<int64_t>(j0) * kb, kb, w);
+  load_vec_rows<KPT>(Bs, Vf + static_cast<int64_t>(j0) * kb, nullptr, kb, w, nullptr);
   __syncthreads();
-  double acc[KPT];
+  double acc[T::NOUT];
 #pragma unroll
-  for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
-  tile_mac<KPT, false>(As, Bs, w, o, cg, acc);
+  for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
+  T::template mac<false>(As, Bs, w, acc);
   __syncthreads();
+  double* Yf = Y + (fa.voff[f] + j0) * kb;
 #pragma unroll
-  for (int t = 0; t < KPT; ++t) Bs[o * KB + cg * KPT + t] = (o < w) ? acc[t] : 0.0;
-  if (chunk == 0 && o < w) {
-    double* Yf = Y + (fa.voff[f] + j0) * kb;
-#pragma unroll
-    for (int t = 0; t < KPT; ++t) {
-      const int c = cg * KPT + t;
-      if (c < kb) Yf[static_cast<int64_t>(o) * kb + c] = acc[t];
-    }
+  for (int t = 0; t < T::NOUT; ++t) {
+    int o, c;
+    T::coords(t, o, c);
+    Bs[o * T::BLD + c] = (o < w) ? acc[t] : 0.0;
+    if (chunk == 0 && o < w && c < kb) Yf[static_cast<int64_t>(o) * kb + c] = acc[t];
   }
   if (nch == 0) return;
   const int row0 = j1 + chunk * TW;
@@ -451,14 +487,13 @@ __global__ __launch_bounds__(kThreads) void fwd_step_kernel(FrontArrays fa, Step
   load_panel_chunk(As, F + fa.foff[f] + static_cast<int64_t>(j0) * d, d, w, row0, rows);
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
-  tile_mac<KPT, false>(As, Bs, w, o, cg, acc);
-  if (o < rows) {
+  for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
+  T::template mac<false>(As, Bs, w, acc);
 #pragma unroll
-    for (int t = 0; t < KPT; ++t) {
-      const int c = cg * KPT + t;
-      if (c < kb) Vf[static_cast<int64_t>(row0 + o) * kb + c] -= acc[t];
-    }
+  for (int t = 0; t < T::NOUT; ++t) {
+    int o, c;
+    T::coords(t, o, c);
+    if (o < rows && c < kb) Vf[static_cast<int64_t>(row0 + o) * kb + c] -= acc[t];
   }
 }
 
@@ -474,7 +509,7 @@ __global__ __launch_bounds__(kThreads) void bwd_border_kernel(FrontArrays fa, co
                                                              const double* __restrict__ F,
                                                              const double* __restrict__ Inv, double* V,
                                                              double* __restrict__ Y, double* __restrict__ P) {
-  constexpr int KB = 4 * KPT;
+  using T = Tile<KPT>;
   const int q = find_slot(pref_bwork, nf, blockIdx.x);
   const int f = fronts[q];
   const int p = fa.parent[f];
@@ -483,7 +518,7 @@ __global__ __launch_bounds__(kThreads) void bwd_border_kernel(FrontArrays fa, co
   const int ns = fa.ns[f];
   if ((p < 0 || bs == 0) && ns > W) return;  // nothing to fold in; the step kernels do the rest
   __shared__ double As[TW * TLD];
-  __shared__ double Bs[TW * KB];
+  __shared__ double Bs[TW * T::BLD];
   const int ntiles = (bs + TW - 1) / TW;
   const int ngroups = max(1, (ntiles + fa.BG - 1) / fa.BG);
   const int local = blockIdx.x - pref_bwork[q];
@@ -495,56 +530,59 @@ __global__ __launch_bounds__(kThreads) void bwd_border_kernel(FrontArrays fa, co
   const double* Vp = V + fa.voff[p >= 0 ? p : f] * kb;
   double* Vb = V + (fa.voff[f] + ns) * kb;
   const double* Fc = F + fa.foff[f] + static_cast<int64_t>(c0) * d + ns;  // element (border r, col c) at c*d + r
-  const int tid = threadIdx.x, o = tid / 4, cg = tid % 4;
-  double acc[KPT];
+  double acc[T::NOUT];
 #pragma unroll
-  for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
+  for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
   const int rbeg = rg * fa.BG * TW, rend = min(bs, (rg + 1) * fa.BG * TW);
   for (int r0 = rbeg; r0 < rend; r0 += TW) {
     const int rows = min(TW, bs - r0);
     load_tile_transposed(As, Fc + r0, d, rows, wc);  // As[r*TLD + c] = L(ns + r0 + r, c0 + c)
-    load_vec_rows_rel<KPT>(Bs, Vp, rel + r0, kb, rows, cc == 0 ? Vb + static_cast<int64_t>(r0) * kb : nullptr);
+    load_vec_rows<KPT>(Bs, Vp, rel + r0, kb, rows, cc == 0 ? Vb + static_cast<int64_t>(r0) * kb : nullptr);
     __syncthreads();
-    tile_mac<KPT, false>(As, Bs, rows, o, cg, acc);
+    T::template mac<false>(As, Bs, rows, acc);
     __syncthreads();
   }
   double* Yf = Y + (fa.voff[f] + c0) * kb;
   if (ngroups > 1) {  // partial slab [cc][rg], 64 x KBMAX
     double* Pp = P + (static_cast<int64_t>(fa.poff[f]) + local) * (TW * KBMAX);
 #pragma unroll
-    for (int t = 0; t < KPT; ++t) Pp[o * KBMAX + cg * KPT + t] = acc[t];
+    for (int t = 0; t < T::NOUT; ++t) {
+      int o, c;
+      T::coords(t, o, c);
+      Pp[o * KBMAX + c] = acc[t];
+    }
     return;
   }
   if (ns > W) {  // multi-panel front, single group: fold into the right-hand side directly
-    if (o < wc) {
 #pragma unroll
-      for (int t = 0; t < KPT; ++t) {
-        const int c = cg * KPT + t;
-        if (c < kb) Yf[static_cast<int64_t>(o) * kb + c] -= acc[t];
-      }
+    for (int t = 0; t < T::NOUT; ++t) {
+      int o, c;
+      T::coords(t, o, c);
+      if (o < wc && c < kb) Yf[static_cast<int64_t>(o) * kb + c] -= acc[t];
     }
     return;
   }
   // single-panel front with a single group (the leaves and small separators): finish here
 #pragma unroll
-  for (int t = 0; t < KPT; ++t) {
-    const int c = cg * KPT + t;
-    Bs[o * KB + c] = (o < wc && c < kb) ? Yf[static_cast<int64_t>(o) * kb + c] - acc[t] : 0.0;
+  for (int t = 0; t < T::NOUT; ++t) {
+    int o, c;
+    T::coords(t, o, c);
+    Bs[o * T::BLD + c] = (o < wc && c < kb) ? Yf[static_cast<int64_t>(o) * kb + c] - acc[t] : 0.0;
   }
   load_inverse(As, Inv + fa.ioff[f], W, wc);
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
-  tile_mac<KPT, true>(As, Bs, wc, o, cg, acc);
-  if (o < wc) {
-    double* Vf = V + (fa.voff[f] + o) * kb;
+  for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
+  T::template mac<true>(As, Bs, wc, acc);
+  double* Vf = V + fa.voff[f] * kb;
 #pragma unroll
-    for (int t = 0; t < KPT; ++t) {
-      const int c = cg * KPT + t;
-      if (c < kb) Vf[c] = acc[t];
-    }
+  for (int t = 0; t < T::NOUT; ++t) {
+    int o, c;
+    T::coords(t, o, c);
+    if (o < wc && c < kb) Vf[static_cast<int64_t>(o) * kb + c] = acc[t];
   }
 }
+
 
 // y(chunk) -= sum over groups of the partial slabs, groups in ascending order
 __global__ __launch_bounds__(kThreads) void bwd_fold_kernel(FrontArrays fa, const int* __restrict__ fronts, int nf,
@@ -577,9 +615,9 @@ template <int KPT>
 __global__ __launch_bounds__(kThreads) void bwd_step_kernel(FrontArrays fa, StepArgs sa, const double* __restrict__ F,
                                                            const double* __restrict__ Inv, double* __restrict__ V,
                                                            double* __restrict__ Y) {
-  constexpr int KB = 4 * KPT;
+  using T = Tile<KPT>;
   __shared__ double As[TW * TLD];
-  __shared__ double Bs[TW * KB];
+  __shared__ double Bs[TW * T::BLD];
   const int wpf = max(1, sa.step);  // workgroups per front: one per earlier 64-column chunk
   const int q = blockIdx.x / wpf;
   const int cc = blockIdx.x - q * wpf;
@@ -591,39 +629,35 @@ __global__ __launch_bounds__(kThreads) void bwd_step_kernel(FrontArrays fa, Step
   const int j0 = sa.step * W;
   const int w = min(W, ns - j0);
   double* Yf = Y + fa.voff[f] * kb;
-  const int tid = threadIdx.x, o = tid / 4, cg = tid % 4;
   load_inverse(As, Inv + fa.ioff[f] + static_cast<int64_t>(sa.step) * W * W, W, w);
-  load_vec_rows<KPT>(Bs, Yf + static_cast<int64_t>(j0) * kb, kb, w);
+  load_vec_rows<KPT>(Bs, Yf + static_cast<int64_t>(j0) * kb, nullptr, kb, w, nullptr);
   __syncthreads();
-  double acc[KPT];
+  double acc[T::NOUT];
 #pragma unroll
-  for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
-  tile_mac<KPT, true>(As, Bs, w, o, cg, acc);  // x1[o] = sum_i inv(i, o) y1[i]
+  for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
+  T::template mac<true>(As, Bs, w, acc);  // x1[o] = sum_i inv(i, o) y1[i]
   __syncthreads();
+  double* Vf = V + (fa.voff[f] + j0) * kb;
 #pragma unroll
-  for (int t = 0; t < KPT; ++t) Bs[o * KB + cg * KPT + t] = (o < w) ? acc[t] : 0.0;
-  if (cc == 0 && o < w) {
-    double* Vf = V + (fa.voff[f] + j0) * kb;
-#pragma unroll
-    for (int t = 0; t < KPT; ++t) {
-      const int c = cg * KPT + t;
-      if (c < kb) Vf[static_cast<int64_t>(o) * kb + c] = acc[t];
-    }
+  for (int t = 0; t < T::NOUT; ++t) {
+    int o, c;
+    T::coords(t, o, c);
+    Bs[o * T::BLD + c] = (o < w) ? acc[t] : 0.0;
+    if (cc == 0 && o < w && c < kb) Vf[static_cast<int64_t>(o) * kb + c] = acc[t];
   }
   if (sa.step == 0) return;
-  // As[r*TLD + c] = L(j0 + r, cc*W + c): the panel's rows in the columns of chunk cc (full 64 wide)
+  // As[r*TLD + c] = L(j0 + r, cc*W + c): the panel's rows in the columns of chunk cc (full width W)
   load_tile_transposed(As, F + fa.foff[f] + static_cast<int64_t>(cc) * W * d + j0, d, w, W);
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < KPT; ++t) acc[t] = 0.0;
-  tile_mac<KPT, false>(As, Bs, w, o, cg, acc);
-  if (o < W) {
-    double* Yc = Yf + static_cast<int64_t>(cc * W + o) * kb;
+  for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
+  T::template mac<false>(As, Bs, w, acc);
+  double* Yc = Yf + static_cast<int64_t>(cc) * W * kb;
 #pragma unroll
-    for (int t = 0; t < KPT; ++t) {
-      const int c = cg * KPT + t;
-      if (c < kb) Yc[c] -= acc[t];
-    }
+  for (int t = 0; t < T::NOUT; ++t) {
+    int o, c;
+    T::coords(t, o, c);
+    if (o < W && c < kb) Yc[static_cast<int64_t>(o) * kb + c] -= acc[t];
   }
 }
 
