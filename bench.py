@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--cpu-sample", choices=("full", "small", "none"), default="full",
                     help="CPU baseline: full = SuperLU factor of the same 1M-dof matrix + 1 mode; small = 200k-dof replica")
     ap.add_argument("--spmv-reps", type=int, default=200)
+    ap.add_argument("--ordering", choices=("geometric", "algebraic"), default="geometric",
+                    help="nested dissection with the mesh coordinates as a hint, or purely from the matrix graph")
     ap.add_argument("--pyprofile", default=None, help="write a cProfile summary of one extra step to this file")
     args = ap.parse_args()
 
@@ -103,7 +105,8 @@ def main():
     timing["assemble_K_s"] = time.perf_counter() - t0
     log(rank, f"K assembled: n={n} nnz={K.nnz} ({timing['assemble_K_s']:.1f}s)")
     t0 = time.perf_counter()
-    Kfac = eg.SpLuOperator(K, ctx=ctx, check_symmetry=False)
+    coords = None if args.ordering == "algebraic" else col.dof_coords()
+    Kfac = eg.SpLuOperator(K, ctx=ctx, check_symmetry=False, coords=coords)
     ctx.sync()
     timing["factor_K_s"] = time.perf_counter() - t0
     ur = Kfac(col.f[col.reduced])
@@ -120,7 +123,7 @@ def main():
         try:
             mat = (K + sigma * G).tocsr()
             factor = eg.SpLuOperator(mat, ctx=ctx, symbolic=Kfac.symbolic if mat.nnz == K.nnz else None,
-                                     check_symmetry=False)
+                                     check_symmetry=False, coords=coords)
             break
         except np.linalg.LinAlgError:
             sigma *= 0.5
@@ -251,6 +254,7 @@ def main():
         "config": {"workload": "buckling 1M-dof Q4 column (706x706 elements), 32 modes, IRAM m=65 + sibk rtol=1e-10 "
                                "+ tensor total derivative w.r.t. element densities",
                    "n_dof": int(n), "nnz": int(K.nnz), "modes": N, "m": args.m, "sigma": round(float(sigma), 6),
+                   "ordering": args.ordering,
                    "parallelism": f"modes sharded over {world} GPU(s), one df/dx all-reduce"},
         "roofline": roofline,
         "sweep": sweep,

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "eigd_mat_free": [c_vp],
     "eigd_spmm": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_dbl],
     "eigd_symbolic_create": [c_int, c_vp, c_vp, c_int, c_int, P(c_vp)],
+    "eigd_symbolic_create_geom": [c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, P(c_vp)],
     "eigd_symbolic_free": [c_vp],
     "eigd_symbolic_sizes": [c_vp, c_vp, c_int],
     "eigd_symbolic_get_i32": [c_vp, C.c_char_p, c_vp, c_i64],

@@ -840,10 +840,16 @@ extern "C" {
 
 int eigd_symbolic_create(int n, const int32_t* hindptr, const int32_t* hindices, int leaf_size, int panel_width,
                          eigd_symbolic** out) {
+  return eigd_symbolic_create_geom(n, hindptr, hindices, leaf_size, panel_width, 0, nullptr, out);
+}
+
+int eigd_symbolic_create_geom(int n, const int32_t* hindptr, const int32_t* hindices, int leaf_size, int panel_width,
+                              int dim, const double* hcoords, eigd_symbolic** out) {
   EIGD_REQUIRE(hindptr && hindices && out, "null argument");
+  EIGD_REQUIRE(hcoords == nullptr || (dim >= 1 && dim <= 3), "coordinates need 1 <= dim <= 3");
   *out = nullptr;
   eigd_symbolic* h = new eigd_symbolic();
-  if (!analyze(n, hindptr, hindices, leaf_size, panel_width, h->s)) {
+  if (!analyze(n, hindptr, hindices, leaf_size, panel_width, h->s, dim, hcoords)) {
     set_error("symbolic analysis failed: %s", h->s.error.c_str());
     delete h;
     return EIGD_E_INVALID;

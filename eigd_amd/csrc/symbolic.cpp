@@ -136,6 +136,8 @@ struct ND {
   std::vector<TreeNode> nodes;
   std::vector<int> node_verts;
   int next_region = 1;
+  const double* coords = nullptr;  // optional: dim coordinates per compressed vertex
+  int dim = 0;
 
   ND(const Graph& gg, int leaf) : g(gg), leaf_size(leaf) {
     region.assign(g.nv, 0);
@@ -178,6 +180,140 @@ struct ND {
     for (int v : order) dist[v] = -1;
   }
 
+  // vertex separator from a rooted level structure (George & Liu): pseudo-peripheral root, lightest
+  // level of the middle band, trimmed to the vertices that touch the far side
+  bool level_split(const std::vector<int>& comp, int crid, int64_t wsum, std::vector<int>& order,
+                   std::vector<int>& sep, std::vector<int>& p1, std::vector<int>& p2) {
+    // pseudo-peripheral root
+    int root = comp[0];
+    int nlev = 0;
+    for (int it = 0; it < 6; ++it) {
+      int nl = bfs(root, crid, order);
+      if (nl <= nlev && it > 0) {
+        clear_dist(order);
+        break;
+      }
+      nlev = nl;
+      // min-degree vertex of the last level
+      int best = order.back();
+      int64_t bdeg = g.xadj[best + 1] - g.xadj[best];
+      for (size_t q = order.size(); q-- > 0;) {
+        int v = order[q];
+        if (dist[v] != nl - 1) break;
+        int64_t dg = g.xadj[v + 1] - g.xadj[v];
+        if (dg < bdeg) {
+          bdeg = dg;
+          best = v;
+        }
+      }
+      clear_dist(order);
+      if (best == root) break;
+      root = best;
+    }
+    nlev = bfs(root, crid, order);
+    if (nlev < 3) {  // clique-like: no vertex separator from a level structure
+      clear_dist(order);
+      return false;
+    }
+    std::vector<int64_t> lw(nlev, 0);
+    for (int v : order) lw[dist[v]] += g.vw[v];
+    std::vector<int64_t> cum(nlev + 1, 0);
+    for (int l = 0; l < nlev; ++l) cum[l + 1] = cum[l] + lw[l];
+    // lightest level inside the middle band, else the level nearest to the midpoint
+    int ksep = -1;
+    int64_t bestw = -1;
+    for (int l = 1; l < nlev - 1; ++l) {
+      double mid = (cum[l] + 0.5 * lw[l]) / static_cast<double>(wsum);
+      if (mid >= 0.38 && mid <= 0.62 && (ksep < 0 || lw[l] < bestw)) {
+        ksep = l;
+        bestw = lw[l];
+      }
+    }
+    if (ksep < 0) {
+      double bestd = 2.0;
+      for (int l = 1; l < nlev - 1; ++l) {
+        double mid = std::fabs((cum[l] + 0.5 * lw[l]) / static_cast<double>(wsum) - 0.5);
+        if (mid < bestd) {
+          bestd = mid;
+          ksep = l;
+        }
+      }
+    }
+    for (int v : order) {
+      int d = dist[v];
+      if (d < ksep)
+        p1.push_back(v);
+      else if (d > ksep)
+        p2.push_back(v);
+      else {
+        bool touches = false;
+        for (int64_t e = g.xadj[v]; e < g.xadj[v + 1] && !touches; ++e) {
+          int u = g.adj[e];
+          touches = (region[u] == crid && dist[u] == ksep + 1);
+        }
+        (touches ? sep : p1).push_back(v);
+      }
+    }
+    clear_dist(order);
+    return true;
+  }
+
+  // geometric split: cut the longest axis of the bounding box at the weighted median coordinate; the
+  // separator is the layer of the low side that touches the high side (a straight mesh line on a
+  // structured grid, the optimum for 9-point stencils)
+  bool geometric_split(const std::vector<int>& comp, int crid, int64_t wsum, std::vector<int>& sep,
+                       std::vector<int>& p1, std::vector<int>& p2) {
+    if (coords == nullptr) return false;
+    double lo[3], hi[3];
+    for (int a = 0; a < dim; ++a) {
+      lo[a] = 1e300;
+      hi[a] = -1e300;
+    }
+    for (int v : comp)
+      for (int a = 0; a < dim; ++a) {
+        const double x = coords[static_cast<int64_t>(v) * dim + a];
+        lo[a] = std::min(lo[a], x);
+        hi[a] = std::max(hi[a], x);
+      }
+    int axes[3] = {0, 1, 2};
+    std::sort(axes, axes + dim, [&](int a, int b) { return (hi[a] - lo[a]) > (hi[b] - lo[b]); });
+    std::vector<std::pair<double, int>> key(comp.size());
+    for (int t = 0; t < dim; ++t) {
+      const int ax = axes[t];
+      if (!(hi[ax] > lo[ax])) break;
+      for (size_t q = 0; q < comp.size(); ++q) key[q] = {coords[static_cast<int64_t>(comp[q]) * dim + ax], comp[q]};
+      std::sort(key.begin(), key.end());
+      // weighted median, then move the cut to the end of the run of equal coordinates (a whole grid line)
+      int64_t acc = 0;
+      size_t cut = 0;
+      while (cut < key.size() && 2 * acc < wsum) acc += g.vw[key[cut++].second];
+      const double tol = 1e-9 * (hi[ax] - lo[ax]);
+      while (cut < key.size() && key[cut].first <= key[cut - 1].first + tol) ++cut;
+      if (cut == 0 || cut >= key.size()) continue;
+      // mark side: dist = 0 low side, 1 high side
+      for (size_t q = 0; q < key.size(); ++q) dist[key[q].second] = (q < cut) ? 0 : 1;
+      sep.clear();
+      p1.clear();
+      p2.clear();
+      for (size_t q = 0; q < key.size(); ++q) {
+        const int v = key[q].second;
+        if (q >= cut) {
+          p2.push_back(v);
+          continue;
+        }
+        bool touches = false;
+        for (int64_t e = g.xadj[v]; e < g.xadj[v + 1] && !touches; ++e) {
+          const int u = g.adj[e];
+          touches = (region[u] == crid && dist[u] == 1);
+        }
+        (touches ? sep : p1).push_back(v);
+      }
+      for (size_t q = 0; q < key.size(); ++q) dist[key[q].second] = -1;
+      if (!sep.empty() && !p1.empty() && !p2.empty()) return true;
+    }
+    return false;
+  }
+
   void run() {
     struct Task {
       std::vector<int> verts;
@@ -214,80 +350,17 @@ struct ND {
           for (int v : comp) region[v] = -1;
           continue;
         }
-        // pseudo-peripheral root
-        int root = comp[0];
-        int nlev = 0;
-        for (int it = 0; it < 6; ++it) {
-          int nl = bfs(root, crid, order);
-          if (nl <= nlev && it > 0) {
-            clear_dist(order);
-            break;
-          }
-          nlev = nl;
-          // min-degree vertex of the last level
-          int best = order.back();
-          int64_t bdeg = g.xadj[best + 1] - g.xadj[best];
-          for (size_t q = order.size(); q-- > 0;) {
-            int v = order[q];
-            if (dist[v] != nl - 1) break;
-            int64_t dg = g.xadj[v + 1] - g.xadj[v];
-            if (dg < bdeg) {
-              bdeg = dg;
-              best = v;
-            }
-          }
-          clear_dist(order);
-          if (best == root) break;
-          root = best;
-        }
-        nlev = bfs(root, crid, order);
-        if (nlev < 3) {  // clique-like: no vertex separator from a level structure
-          clear_dist(order);
-          add_node(task.parent, comp.data(), static_cast<int64_t>(comp.size()));
-          for (int v : comp) region[v] = -1;
-          continue;
-        }
-        std::vector<int64_t> lw(nlev, 0);
-        for (int v : order) lw[dist[v]] += g.vw[v];
-        std::vector<int64_t> cum(nlev + 1, 0);
-        for (int l = 0; l < nlev; ++l) cum[l + 1] = cum[l] + lw[l];
-        // lightest level inside the middle band, else the level nearest to the midpoint
-        int ksep = -1;
-        int64_t bestw = -1;
-        for (int l = 1; l < nlev - 1; ++l) {
-          double mid = (cum[l] + 0.5 * lw[l]) / static_cast<double>(wsum);
-          if (mid >= 0.38 && mid <= 0.62 && (ksep < 0 || lw[l] < bestw)) {
-            ksep = l;
-            bestw = lw[l];
-          }
-        }
-        if (ksep < 0) {
-          double bestd = 2.0;
-          for (int l = 1; l < nlev - 1; ++l) {
-            double mid = std::fabs((cum[l] + 0.5 * lw[l]) / static_cast<double>(wsum) - 0.5);
-            if (mid < bestd) {
-              bestd = mid;
-              ksep = l;
-            }
-          }
-        }
         std::vector<int> sep, p1, p2;
-        for (int v : order) {
-          int d = dist[v];
-          if (d < ksep)
-            p1.push_back(v);
-          else if (d > ksep)
-            p2.push_back(v);
-          else {
-            bool touches = false;
-            for (int64_t e = g.xadj[v]; e < g.xadj[v + 1] && !touches; ++e) {
-              int u = g.adj[e];
-              touches = (region[u] == crid && dist[u] == ksep + 1);
-            }
-            (touches ? sep : p1).push_back(v);
+        if (!geometric_split(comp, crid, wsum, sep, p1, p2)) {
+          sep.clear();
+          p1.clear();
+          p2.clear();
+          if (!level_split(comp, crid, wsum, order, sep, p1, p2)) {
+            add_node(task.parent, comp.data(), static_cast<int64_t>(comp.size()));
+            for (int v : comp) region[v] = -1;
+            continue;
           }
         }
-        clear_dist(order);
         if (sep.empty() || p1.empty() || p2.empty()) {
           add_node(task.parent, comp.data(), static_cast<int64_t>(comp.size()));
           for (int v : comp) region[v] = -1;
@@ -313,7 +386,8 @@ struct ND {
 }  // namespace
 
 // ---------------------------------------------------------------------------
-bool analyze(int n, const int32_t* ip, const int32_t* ix, int leaf_size, int panel_width, Symbolic& s) {
+bool analyze(int n, const int32_t* ip, const int32_t* ix, int leaf_size, int panel_width, Symbolic& s, int dim,
+             const double* dof_coords) {
   s = Symbolic();
   s.n = n;
   s.leaf_size = leaf_size > 0 ? leaf_size : 48;
@@ -347,6 +421,14 @@ bool analyze(int n, const int32_t* ip, const int32_t* ix, int leaf_size, int pan
   compress(n, ip, ix, g);
   s.ncompressed = g.nv;
   ND nd(g, s.leaf_size);
+  std::vector<double> vcoords;
+  if (dof_coords != nullptr && dim >= 1 && dim <= 3) {  // a compressed vertex sits where its first dof sits
+    vcoords.resize(static_cast<size_t>(g.nv) * dim);
+    for (int v = 0; v < g.nv; ++v)
+      for (int a = 0; a < dim; ++a) vcoords[static_cast<size_t>(v) * dim + a] = dof_coords[static_cast<size_t>(g.cv_dofs[g.cv_ptr[v]]) * dim + a];
+    nd.coords = vcoords.data();
+    nd.dim = dim;
+  }
   nd.run();
 
   // ---- postorder of the separator tree -> fronts and permutation ----------

@@ -67,6 +67,8 @@ struct Symbolic {
 
 // indptr/indices: full symmetric pattern, rows sorted, diagonal present.
 // Returns false and sets s.error on failure.
-bool analyze(int n, const int32_t* indptr, const int32_t* indices, int leaf_size, int panel_width, Symbolic& s);
+// dof_coords (optional, n x dim, dim <= 3): geometric nested dissection instead of level structures.
+bool analyze(int n, const int32_t* indptr, const int32_t* indices, int leaf_size, int panel_width, Symbolic& s,
+             int dim = 0, const double* dof_coords = nullptr);
 
 }  // namespace eigd

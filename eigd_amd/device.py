@@ -383,7 +383,7 @@ class Symbolic:
     SIZE_NAMES = ("n", "nfronts", "nlevels", "nnzL", "front_doubles", "sumd", "maxd", "border_len", "nlower",
                   "nlaunch_steps", "flops", "maxns")
 
-    def __init__(self, A, leaf_size=0, panel_width=0):
+    def __init__(self, A, leaf_size=0, panel_width=0, coords=None):
         from scipy import sparse
 
         A = sparse.csr_matrix(A)
@@ -392,7 +392,12 @@ class Symbolic:
         ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
         ix = np.ascontiguousarray(A.indices, dtype=np.int32)
         h = c_vp()
-        call("eigd_symbolic_create", self.n, hptr(ip), hptr(ix), int(leaf_size), int(panel_width), C.byref(h))
+        if coords is None:
+            call("eigd_symbolic_create", self.n, hptr(ip), hptr(ix), int(leaf_size), int(panel_width), C.byref(h))
+        else:
+            xy = np.ascontiguousarray(coords, dtype=np.float64).reshape(self.n, -1)
+            call("eigd_symbolic_create_geom", self.n, hptr(ip), hptr(ix), int(leaf_size), int(panel_width),
+                 xy.shape[1], hptr(xy), C.byref(h))
         self.h = h
         sz = np.zeros(12, dtype=np.int64)
         call("eigd_symbolic_sizes", self.h, hptr(sz), 12)
@@ -429,7 +434,7 @@ class Symbolic:
 class Factor:
     """Numeric LL^T factor of a symmetric positive definite CSR matrix on the device."""
 
-    def __init__(self, ctx, A, symbolic=None, leaf_size=0, panel_width=0):
+    def __init__(self, ctx, A, symbolic=None, leaf_size=0, panel_width=0, coords=None):
         from scipy import sparse
 
         A = sparse.csr_matrix(A)
@@ -438,7 +443,7 @@ class Factor:
         A.sort_indices()
         self.ctx = ctx
         self.n = A.shape[0]
-        self.symbolic = symbolic if symbolic is not None else Symbolic(A, leaf_size, panel_width)
+        self.symbolic = symbolic if symbolic is not None else Symbolic(A, leaf_size, panel_width, coords)
         data = np.ascontiguousarray(A.data, dtype=np.float64)
         h = c_vp()
         call("eigd_factor_create", ctx.h, self.symbolic.h, hptr(data), C.byref(h))

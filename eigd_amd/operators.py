@@ -23,7 +23,7 @@ class SpLuOperator(LinearOperator):
     matrix raises ``NotPositiveDefiniteError`` (a ``numpy.linalg.LinAlgError``).
     """
 
-    def __init__(self, mat, ctx=None, symbolic=None, leaf_size=0, panel_width=0, check_symmetry=True):
+    def __init__(self, mat, ctx=None, symbolic=None, leaf_size=0, panel_width=0, check_symmetry=True, coords=None):
         if not sparse.issparse(mat):
             mat = sparse.csr_matrix(mat)
         if mat.shape[0] != mat.shape[1]:
@@ -41,7 +41,9 @@ class SpLuOperator(LinearOperator):
             d = csr @ x - csr.T @ x
             if np.linalg.norm(d) > 1e-10 * max(np.linalg.norm(csr @ x), 1e-300):
                 raise ValueError("SpLuOperator (MI355X) needs a symmetric matrix")
-        self.factor = Factor(self.ctx, csr, symbolic=symbolic, leaf_size=leaf_size, panel_width=panel_width)
+        # coords (optional, one row per dof): geometric nested dissection; without it the ordering is algebraic
+        self.factor = Factor(self.ctx, csr, symbolic=symbolic, leaf_size=leaf_size, panel_width=panel_width,
+                             coords=coords)
         self.symbolic = self.factor.symbolic
 
     # -- device path (used by the drivers) ------------------------------------

@@ -173,6 +173,10 @@ class BucklingColumn:
         u[self.reduced] = ur
         return u
 
+    def dof_coords(self):
+        """(n, 2) coordinates of the free dofs: optional ordering hint for SpLuOperator(coords=...)"""
+        return self.mesh.X[self.reduced // 2]
+
     # d/d rhoE of w^T K v and w^T G v at fixed u: element-wise bilinear forms (buckling.py:178-218, 283-340)
     def dK_scale(self):
         return self.p * self.rhoE ** (self.p - 1.0)
@@ -204,6 +208,9 @@ class FreePlate:
         M, _ = _assemble(self.mesh, (self.density * self.rhoE)[:, None, None] * self.Me0[None], 2)
         return M
 
+    def dof_coords(self):
+        return np.repeat(self.mesh.X, 2, axis=0)
+
 
 class ThermalPlate:
     """square heat-conduction plate of examples/thermal.py (1 dof / node): repeated eigenvalues when Lx == Ly"""
@@ -230,3 +237,6 @@ class ThermalPlate:
     def mass(self):
         M, _ = _assemble(self.mesh, (self.rhoE + self.rho0)[:, None, None] * self.Me0[None], 1)
         return M
+
+    def dof_coords(self):
+        return self.mesh.X

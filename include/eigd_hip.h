@@ -82,6 +82,10 @@ int eigd_spmm(eigd_mat* A, const double* dX, int ldx, double* dY, int ldy, int k
  * triangular sweeps are gfx950 kernels.                                          */
 int eigd_symbolic_create(int n, const int32_t* hindptr, const int32_t* hindices, int leaf_size, int panel_width,
                          eigd_symbolic** out);
+/* same, with dof coordinates (n x dim row-major, dim <= 3) as an ordering hint: geometric nested dissection
+ * (straight separators on structured meshes) instead of the purely algebraic level-structure dissection */
+int eigd_symbolic_create_geom(int n, const int32_t* hindptr, const int32_t* hindices, int leaf_size, int panel_width,
+                              int dim, const double* hcoords, eigd_symbolic** out);
 int eigd_symbolic_free(eigd_symbolic* s);
 /* sizes: [0]=n [1]=nfronts [2]=nlevels [3]=nnz(L) incl. diagonal blocks [4]=front buffer doubles
  *        [5]=sum of front dimensions [6]=max front dimension [7]=border entries [8]=lower nnz of A

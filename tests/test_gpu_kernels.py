@@ -212,3 +212,17 @@ def test_fem_like_ill_conditioned_factor(ctx):
     X = F.solve_inplace(ctx.from_host(B)).get()
     Xref = splu(A.tocsc()).solve(B)
     assert relerr(X, Xref) < 1e-9
+
+
+def test_factor_with_geometric_ordering(ctx):
+    from eigd_amd.device import Factor
+
+    nx, ny = 90, 70
+    A = grid_matrix(nx, ny, 2, seed=5)
+    xy = np.stack([np.repeat(np.arange(nx), ny), np.tile(np.arange(ny), nx)], axis=1).astype(float)
+    F = Factor(ctx, A, coords=np.repeat(xy, 2, axis=0))
+    rng = np.random.default_rng(1)
+    for k in (1, 7, 16, 32):
+        B = rng.normal(size=(A.shape[0], k))
+        X = F.solve_inplace(ctx.from_host(B)).get()
+        assert np.linalg.norm(A @ X - B) / np.linalg.norm(B) < 1e-12
