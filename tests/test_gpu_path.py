@@ -445,3 +445,99 @@ def test_two_rank_gpu_sharding_gloo(tmp_path):
 def test_one_rank_rccl_allreduce_path(tmp_path):
     """the bench's multi-GPU plumbing with RCCL (nccl backend) at world size 1: torch and libeigd_hip.so in one process"""
     _run_ranks(tmp_path, 1, "nccl", 29532)
+
+
+def _fd_functional(lam, Phi, lamb, Phib, Phi_ref, mode):
+    """
+    f = lamb . g(lam) + sum_i Phib_i . phi_i with the eigenvector signs aligned to the base point.
+    g(lam) = lam in normal mode.  In buckling mode the reference's total-derivative formula
+    (eigenvector_derivatives.py:118-134) weights the eigenvalue term as lamb_i (lam_i phi^T dA phi + phi^T dB phi)
+    = lamb_i d(ln lam_i): its `lamb` is the sensitivity w.r.t. ln(lam) (a reference convention that its own
+    tests never exercise -- the tanh aggregate of examples/buckling.py has lamb = 0).  We keep the reference
+    formula (parity) and therefore check it against g(lam) = ln(lam).
+    """
+    sg = np.sign(np.einsum("ij,ij->j", Phi, Phi_ref))
+    g = lam if mode == "normal" else np.log(lam)
+    return float(lamb @ g + np.einsum("ij,ij->", Phib, Phi * sg))
+
+
+@pytest.mark.parametrize("kind", ["buckling", "normal"])
+def test_total_derivative_matches_central_difference(kind):
+    """
+    df/d(rho_E) from the adjoint path (device element callbacks) against a central finite difference of
+    f(rho) = lamb . lam(rho) + sum_i Phib_i . phi_i(rho) along a random direction (examples/buckling.py:1025-1035
+    does the same check with dh = 1e-4).  The fundamental path u is frozen for the buckling case, as in the
+    callbacks.
+    """
+    import eigd_amd as eg
+    from eigd_amd.device import ElementBilinear, default_context
+    from eigd_amd.problems import BucklingColumn, FreePlate
+
+    ctx = default_context()
+    rng = np.random.default_rng(4)
+    N = 5
+    if kind == "buckling":
+        prob = BucklingColumn(28, 28, seed=2)
+        K0 = prob.stiffness()
+        u = prob.full_vector(eg.SpLuOperator(K0)(prob.f[prob.reduced]))
+        Ge_unit = prob.element_G(u)
+        sigma, mode = None, "buckling"
+
+        def matrices(rho):
+            prob.rhoE = rho
+            K = prob.stiffness()
+            prob.Ge_unit = Ge_unit
+            from eigd_amd.problems import _assemble
+            G, _ = _assemble(prob.mesh, (rho**prob.p + prob.rho0_G)[:, None, None] * Ge_unit, 2, prob.free_map)
+            return G, K   # (A, B)
+    else:
+        prob = FreePlate(24, 20, Lx=1.2, Ly=1.0, seed=3)
+        sigma, mode = -10.0, "normal"
+
+        def matrices(rho):
+            prob.rhoE = rho
+            return prob.stiffness(), prob.mass()   # (A, B)
+
+    rho0 = prob.rhoE.copy()
+
+    def solve(rho, sig):
+        A, B = matrices(rho)
+        mat = (A - sig * B) if mode == "normal" else (B + sig * A)
+        fac = eg.SpLuOperator(mat.tocsc())
+        nmodes = N + 3 if mode == "normal" else N
+        s = eg.BasicLanczos(N=nmodes, m=80, tol=1e-13, mode=mode)
+        s.solve(A, B, fac, sig)
+        return s, A, B
+
+    if sigma is None:  # shift below the first buckling load
+        A, B = matrices(rho0)
+        from scipy.sparse.linalg import eigsh
+        mu = eigsh(-A, k=1, M=B, which="LA", return_eigenvectors=False)[0]
+        sigma = 0.6 / mu
+    s0, A0, B0 = solve(rho0, sigma)
+    lam0 = np.asarray(s0._lamN())
+    Nn = len(lam0)
+    keep = np.arange(3, Nn) if mode == "normal" else np.arange(Nn)  # rigid-body modes carry no sensitivity weight
+    Phib = np.zeros((A0.shape[0], Nn))
+    Phib[:, keep] = rng.uniform(-1, 1, size=(A0.shape[0], len(keep)))
+    lamb = np.zeros(Nn)
+    lamb[keep] = rng.uniform(0.5, 1.5, size=len(keep))
+    psi, data = s0.solve_adjoint(Phib, method="sibk", rtol=1e-13)
+    ed = prob.elem_dofs
+    if mode == "buckling":
+        dAdx = ElementBilinear(ctx, ed, Ge_unit, scale=prob.p * rho0 ** (prob.p - 1.0))
+        dBdx = ElementBilinear(ctx, ed, prob.Ke0, scale=prob.p * rho0 ** (prob.p - 1.0))
+    else:
+        dAdx = ElementBilinear(ctx, ed, prob.Ke0, scale=prob.p * rho0 ** (prob.p - 1.0))
+        dBdx = ElementBilinear(ctx, ed, prob.Me0, scale=np.full(len(rho0), prob.density))
+    dfdx = s0.add_total_derivative(lamb, Phib, psi, dAdx, dBdx, np.zeros(len(rho0)), adj_corr_data=data,
+                                   deriv_type="tensor")
+    pert = rng.uniform(size=len(rho0))
+    h = 1e-5
+    sp, _, _ = solve(rho0 + h * pert, sigma)
+    sm, _, _ = solve(rho0 - h * pert, sigma)
+    fp = _fd_functional(np.asarray(sp._lamN()), sp.Phi, lamb, Phib, s0.Phi, mode)
+    fm = _fd_functional(np.asarray(sm._lamN()), sm.Phi, lamb, Phib, s0.Phi, mode)
+    fd = (fp - fm) / (2 * h)
+    ans = float(pert @ dfdx)
+    assert abs(ans - fd) <= 2e-6 * max(abs(fd), 1e-12), (ans, fd)
