@@ -59,6 +59,7 @@ _SIGNATURES = {
     "eigd_factor_refactor": [c_vp, c_vp],
     "eigd_factor_free": [c_vp],
     "eigd_factor_solve": [c_vp, c_vp, c_int, c_int, c_dbl],
+    "eigd_factor_solve_to": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl],
     "eigd_factor_stats": [c_vp, c_vp, c_int],
     "eigd_factor_solve_bytes": [c_vp, c_int, P(c_dbl)],
     "eigd_gemm_tn": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_int, c_vp],

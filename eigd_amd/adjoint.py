@@ -476,8 +476,7 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
         kp = j - 1
         lo, hi = _active_range(done)
         Zk, Ta = Z[kp].cols(lo, hi), T.cols(lo, hi)
-        Zk.copy_from(W[kp].cols(lo, hi))
-        prob.fac(Zk, count=int(np.count_nonzero(~done)))  # ref 1248: one multi-column sweep
+        prob.fac.apply_to(W[kp].cols(lo, hi), Zk, count=int(np.count_nonzero(~done)))  # ref 1248: one multi-column sweep
         Kop.apply(Zk, Ta)                                # ref 1250 / 1252
         prob.project_r(Ta)
         h = _cgs2(W, Ta, j, c0=lo)                       # ref 1254-1256 (Gram-Schmidt vs all previous W)

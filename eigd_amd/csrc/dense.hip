@@ -196,16 +196,24 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(int n, int ku, int kx
   }
 }
 
-// X[r][b] = beta * X[r][b] + alpha * sum_a U(r,a) C[a][b], C on the device (ku x kx)
+// X[r][b] = beta * X[r][b] + alpha * sum_a U(r,a) C[a][b], C on the device (ku x kx).
+// A 64-row chunk of U is staged in LDS with all its loads in flight; wave w owns rows 16w..16w+15 and
+// forms each 16 x 16 output tile with v_mfma_f64_16x16x4_f64 (A = U rows from LDS, B = C from LDS with a
+// conflict-free row stride), so the LDS traffic per flop is an eighth of a scalar inner loop.
+__device__ __forceinline__ int cs_stride(int kx) { return (kx % 32 == 0) ? kx + 16 : kx; }
+
 __global__ __launch_bounds__(kThreads) void gemm_nn_kernel(int n, int ku, int kx, const double* __restrict__ U,
                                                           int64_t rsu, int64_t csu, const double* __restrict__ C,
                                                           double* __restrict__ X, int ldx, double alpha, double beta) {
   __shared__ double Us[kRB][kMaxK + 1];
-  extern __shared__ double Cs[];  // ku * kx
+  extern __shared__ double Cs[];  // ku x cs_stride(kx)
   const int tid = threadIdx.x;
-  for (int q = tid; q < ku * kx; q += kThreads) Cs[q] = C[q];
-  const int cpt = (kx + 3) / 4;          // columns per thread (<= 16)
-  const int r = tid / 4, b0 = (tid % 4) * cpt;
+  const int cld = cs_stride(kx);
+  for (int q = tid; q < ku * kx; q += kThreads) Cs[(q / kx) * cld + q % kx] = C[q];
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ntb = (kx + 15) >> 4;
+  const int ku4 = (ku + 3) & ~3;
   for (int64_t base = static_cast<int64_t>(blockIdx.x) * kRB; base < n; base += static_cast<int64_t>(gridDim.x) * kRB) {
     const int rows = static_cast<int>((n - base) < kRB ? (n - base) : kRB);
     __syncthreads();
@@ -237,20 +245,25 @@ __global__ __launch_bounds__(kThreads) void gemm_nn_kernel(int n, int ku, int kx
       }
     }
     __syncthreads();
-    if (r < rows) {
-      double acc[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = 0.0;
-      for (int a = 0; a < ku; ++a) {
-        const double u = Us[r][a];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (j < cpt && b0 + j < kx) acc[j] += u * Cs[a * kx + b0 + j];
+    if (16 * wave >= rows) continue;  // wave-uniform
+    for (int tb = 0; tb < ntb; ++tb) {
+      const int b = tb * 16 + li;
+      const bool okb = b < kx;
+      double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+      for (int k0 = 0; k0 < ku4; k0 += 4) {
+        const int k = k0 + lk;
+        const double av = (k < ku) ? Us[16 * wave + li][k] : 0.0;
+        const double bv = (k < ku && okb) ? Cs[k * cld + b] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
       }
-      double* xp = X + (base + r) * ldx;
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (j < cpt && b0 + j < kx) xp[b0 + j] = (beta == 0.0) ? alpha * acc[j] : beta * xp[b0 + j] + alpha * acc[j];
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = 16 * wave + lk + 4 * reg;  // f64 MFMA result map: row = (l>>4) + 4*reg, col = l&15
+        if (r < rows && okb) {
+          double* xp = X + (base + r) * ldx + b;
+          *xp = (beta == 0.0) ? alpha * acc[reg] : beta * (*xp) + alpha * acc[reg];
+        }
+      }
     }
   }
 }
@@ -323,8 +336,9 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
 static int gemm_nn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu,
                           const double* dC, double* dX, int ldx, double alpha, double beta) {
   const int nb = grid_for_rows(n, kRB);
-  hipLaunchKernelGGL(gemm_nn_kernel, dim3(nb), dim3(kThreads), sizeof(double) * ku * kx, ctx->stream, n, ku, kx, dU, rsu,
-                     csu, dC, dX, ldx, alpha, beta);
+  const size_t cs_bytes = sizeof(double) * ku * ((kx % 32 == 0) ? kx + 16 : kx);
+  hipLaunchKernelGGL(gemm_nn_kernel, dim3(nb), dim3(kThreads), cs_bytes, ctx->stream, n, ku, kx, dU, rsu, csu, dC, dX,
+                     ldx, alpha, beta);
   EIGD_LAUNCH_CHECK();
   return EIGD_OK;
 }

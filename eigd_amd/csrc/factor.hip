@@ -768,14 +768,14 @@ int numeric(eigd_factor* f, const double* hdata) {
 }
 
 template <int KPT>
-int sweep(eigd_factor* f, double* dX, int ldx, int kb, double alpha) {
+int sweep(eigd_factor* f, const double* dIn, int ldin, double* dX, int ldx, int kb, double alpha) {
   const Symbolic& s = *f->sym;
   hipStream_t st = f->ctx->stream;
   const FrontArrays fa = f->fa();
   const int64_t total = s.sumd * kb;
   const int gb = static_cast<int>(std::min<int64_t>((total + 255) / 256, 16384));
-  hipLaunchKernelGGL(solve_init_kernel, dim3(std::max(gb, 1)), dim3(256), 0, st, s.sumd, kb, f->d_v_src, dX, ldx, alpha,
-                     f->d_V);
+  hipLaunchKernelGGL(solve_init_kernel, dim3(std::max(gb, 1)), dim3(256), 0, st, s.sumd, kb, f->d_v_src, dIn, ldin,
+                     alpha, f->d_V);
   EIGD_LAUNCH_CHECK();
   auto step_args = [&](int l, int step) {
     const int rec = s.ls_ptr[l] + step;
@@ -1040,19 +1040,23 @@ int eigd_factor_refactor(eigd_factor* f, const double* hdata) {
 }
 
 int eigd_factor_solve(eigd_factor* f, double* dX, int ldx, int k, double alpha) {
-  EIGD_REQUIRE(f && dX, "null argument");
-  EIGD_REQUIRE(k >= 1 && ldx >= k, "bad block shape k=%d ldx=%d", k, ldx);
+  return eigd_factor_solve_to(f, dX, ldx, dX, ldx, k, alpha);
+}
+
+int eigd_factor_solve_to(eigd_factor* f, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha) {
+  EIGD_REQUIRE(f && dIn && dOut, "null argument");
+  EIGD_REQUIRE(k >= 1 && ldin >= k && ldout >= k, "bad block shape k=%d ldin=%d ldout=%d", k, ldin, ldout);
   for (int c0 = 0; c0 < k; c0 += KBMAX) {
     const int kb = std::min(KBMAX, k - c0);
     int rc;
     if (kb <= 4)
-      rc = sweep<1>(f, dX + c0, ldx, kb, alpha);
+      rc = sweep<1>(f, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else if (kb <= 8)
-      rc = sweep<2>(f, dX + c0, ldx, kb, alpha);
+      rc = sweep<2>(f, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else if (kb <= 16)
-      rc = sweep<4>(f, dX + c0, ldx, kb, alpha);
+      rc = sweep<4>(f, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else
-      rc = sweep<8>(f, dX + c0, ldx, kb, alpha);
+      rc = sweep<8>(f, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     if (rc != EIGD_OK) return rc;
   }
   return EIGD_OK;

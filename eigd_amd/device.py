@@ -471,6 +471,13 @@ class Factor:
         call("eigd_factor_solve", self.h, X.ptr, X.ld, X.k, float(alpha))
         return X
 
+    def solve_to(self, Xin, Xout, alpha=1.0):
+        """Xout <- alpha * M^{-1} Xin (Xin untouched)"""
+        if Xin.n != self.n or (Xout.n, Xout.k) != (Xin.n, Xin.k):
+            raise ValueError("shape mismatch in factor solve")
+        call("eigd_factor_solve_to", self.h, Xin.ptr, Xin.ld, Xout.ptr, Xout.ld, Xin.k, float(alpha))
+        return Xout
+
     def stats(self):
         out = np.zeros(4)
         call("eigd_factor_stats", self.h, hptr(out), 4)

@@ -56,6 +56,11 @@ class SpLuOperator(LinearOperator):
         self.count += X.k if count is None else int(count)
         return self.factor.solve_inplace(X, alpha)
 
+    def solve_device_to(self, Xin, Xout, alpha=1.0, count=None):
+        """Xout <- alpha * mat^{-1} Xin on device blocks, Xin untouched"""
+        self.count += Xin.k if count is None else int(count)
+        return self.factor.solve_to(Xin, Xout, alpha)
+
     def refactor(self, mat):
         """numeric refactorisation with new values on the same sparsity pattern"""
         self.factor.refactor(mat.tocsr().astype(np.float64))
@@ -119,6 +124,14 @@ class FactorApply:
         out = np.asarray(self.factor(X.get()))  # honours a user-supplied operator
         X.set(alpha * out.reshape(X.n, X.k))
         return X
+
+    def apply_to(self, Xin, Xout, alpha=1.0, count=None):
+        """Xout <- alpha factor(Xin)"""
+        if self.native:
+            return self.factor.solve_device_to(Xin, Xout, alpha, count)
+        out = np.asarray(self.factor(Xin.get()))
+        Xout.set(alpha * out.reshape(Xin.n, Xin.k))
+        return Xout
 
 
 def is_native_factor(factor):

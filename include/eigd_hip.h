@@ -101,6 +101,8 @@ int eigd_factor_refactor(eigd_factor* f, const double* hdata);
 int eigd_factor_free(eigd_factor* f);
 /* X (n x k row-major, ld) <- alpha * M^{-1} X ; any k >= 1 (processed in column blocks of <= 32) */
 int eigd_factor_solve(eigd_factor* f, double* dX, int ldx, int k, double alpha);
+/* out of place: Out <- alpha * M^{-1} In (In is not modified; In == Out is allowed) -- Z[:, kp] = factor(W[:, kp]) (1248) */
+int eigd_factor_solve_to(eigd_factor* f, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha);
 /* stats: [0]=nnz(L) [1]=device bytes held [2]=factor flops [3]=min pivot*1e300? (unused) */
 int eigd_factor_stats(eigd_factor* f, double* out, int nout);
 /* bytes of L streamed by one k-column solve (algorithmic, for the roofline) */
