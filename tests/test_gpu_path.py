@@ -541,3 +541,69 @@ def test_total_derivative_matches_central_difference(kind):
     fd = (fp - fm) / (2 * h)
     ans = float(pert @ dfdx)
     assert abs(ans - fd) <= 2e-6 * max(abs(fd), 1e-12), (ans, fd)
+
+
+def test_c2_like_natural_frequency_properties_at_scale():
+    """
+    Natural-frequency configuration (BASELINE configs[1] shape, 160 x 160 elements = 51 842 dof here to keep the
+    suite short): size-independent properties of the whole path -- eigen-residuals, B-orthonormality, the three
+    rigid-body modes, adjoint residuals and orthogonality, and IRAM / BasicLanczos agreement.
+    """
+    import eigd_amd as eg
+    from eigd_amd.problems import FreePlate
+
+    prob = FreePlate(160, 160, seed=1)
+    K, M = prob.stiffness(), prob.mass()
+    sigma, N = -10.0, 13
+    fac = eg.SpLuOperator((K - sigma * M).tocsc(), coords=prob.dof_coords())
+    s = eg.IRAM(N=N, m=60)
+    lam, Phi = s.solve(K, M, fac, sigma)
+    assert np.all(np.abs(lam[:3]) < 1e-7) and lam[3] > 1e-3               # free-free plate: 3 rigid-body modes
+    R = K @ Phi - (M @ Phi) * lam
+    assert np.linalg.norm(R, axis=0).max() < 1e-8 * np.abs(K).max()
+    assert np.linalg.norm(Phi.T @ (M @ Phi) - np.eye(N)) < 1e-9
+    s2 = eg.BasicLanczos(N=N, m=80, tol=1e-13)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lam2, _ = s2.solve(K, M, fac, sigma)
+    assert relerr(lam2[3:], lam[3:]) < 1e-9
+    rng = np.random.default_rng(1)
+    Phib = np.zeros((K.shape[0], N))
+    Phib[:, 3:] = rng.uniform(size=(K.shape[0], N - 3))                  # harness convention: no weight on rigid modes
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-10)
+    res, _ = s.eval_adjoint_residual_norm(Phib, psi, b_ortho=True)       # residual in the complement of span(B Phi)
+    _, ortho = s.eval_adjoint_residual_norm(Phib, psi, b_ortho=False)    # |phi_i^T B psi_i| (own mode)
+    rn0 = np.sqrt(np.max(np.sum(Phib**2, axis=0)))
+    assert res[3:].max() < 1e-7 * rn0
+    assert ortho[3:].max() < 1e-7 * np.abs(psi).max()
+    assert set(data.keys()) <= {0, 1, 2}                                   # only the rigid-body cluster is repeated
+
+
+def test_c4_like_thermal_repeated_eigenvalues_at_scale():
+    """square thermal plate (exactly repeated pairs by symmetry): index sets and adjoint orthogonality, 40 401 dof"""
+    import eigd_amd as eg
+    from eigd_amd.problems import ThermalPlate
+
+    prob = ThermalPlate(200, epsilon=0.0)
+    K, M = prob.stiffness(), prob.mass()
+    sigma, N = -0.1, 8
+    fac = eg.SpLuOperator((K - sigma * M).tocsc(), coords=prob.dof_coords())
+    s = eg.BasicLanczos(N=N, m=90, tol=1e-13)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lam, Phi = s.solve(K, M, fac, sigma)
+    assert abs(lam[1] - lam[2]) < 1e-8 * lam[2] and abs(lam[4] - lam[5]) < 1e-8 * lam[5]
+    assert np.linalg.norm(Phi.T @ (M @ Phi) - np.eye(N)) < 1e-9
+    vec = np.random.default_rng(0).uniform(size=K.shape[0])
+    Phib = np.zeros_like(Phi)
+    for i in range(1, N):                                                   # thermal compliance (thermal.py:436-442)
+        Phib[:, i] = 2.0 * (Phi[:, i] @ vec) * vec / lam[i]
+    psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-12)
+    sets = index_sets(data)
+    assert sets.get(1) == [2] and sets.get(2) == [1] and sets.get(4) == [5] and sets.get(5) == [4]
+    res, _ = s.eval_adjoint_residual_norm(Phib, psi, b_ortho=True)
+    _, ortho = s.eval_adjoint_residual_norm(Phib, psi, b_ortho=False)
+    assert res.max() < 1e-7 * max(np.linalg.norm(Phib, axis=0).max(), 1.0)
+    assert ortho.max() < 1e-7 * max(np.abs(psi).max(), 1.0)
