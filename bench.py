@@ -241,15 +241,20 @@ def main():
                   f"({time.perf_counter() - t0:.1f}s)")
 
     # ------------------------------------------------------------------ roofline of the SpMV kernel (HIP events)
+    # K and G (same sparsity, 235 MB of traffic each) are applied alternately so that consecutive launches
+    # cannot be served from the 256 MiB Infinity Cache: this is the HBM-streaming rate of the kernel.
     x = ctx.from_host(rng.normal(size=n))
     y = ctx.empty(n, 1)
-    for _ in range(10):
+    y2 = ctx.empty(n, 1)
+    for _ in range(5):
         dK.apply(x, y)
+        dG.apply(x, y2)
     ctx.sync()
     ctx.timer_start()
-    for _ in range(args.spmv_reps):
+    for _ in range(args.spmv_reps // 2):
         dK.apply(x, y)
-    spmv_ms = ctx.timer_stop_ms() / args.spmv_reps
+        dG.apply(x, y2)
+    spmv_ms = ctx.timer_stop_ms() / (2 * (args.spmv_reps // 2))
     spmv_bytes = dK.spmv_bytes(1)
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled as the guide

@@ -460,8 +460,8 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     dpsi = ctx.zeros(prob.n, k)
     if done.all():
         return dpsi, converged, info
-    W = ctx.stack(maxiter + 1, prob.n, k)
-    Z = ctx.stack(maxiter, prob.n, k).zero()             # finished columns keep zero (never NaN) entries
+    W = ctx.workspace_stack("krylov_W", maxiter + 1, prob.n, k)
+    Z = ctx.workspace_stack("krylov_Z", maxiter, prob.n, k).zero()  # finished columns keep zero (never NaN) entries
     W0 = W[0]
     W0.copy_from(R0)
     prob.project_r(W0)                                   # ref 1232
@@ -689,8 +689,8 @@ def _pgmres_device(prob, dPhib, dpsi, lam_c, rtol, atol, maxiter, callback, rnor
             info[c] = 0
             done[c] = True
     if not done.all():
-        W = ctx.stack(maxiter + 1, prob.n, k)
-        Z = ctx.stack(maxiter, prob.n, k).zero()
+        W = ctx.workspace_stack("krylov_W", maxiter + 1, prob.n, k)
+        Z = ctx.workspace_stack("krylov_Z", maxiter, prob.n, k).zero()
         scale = np.where(done | (beta == 0.0), 0.0, 1.0 / np.where(beta == 0.0, 1.0, beta))
         W[0].assign_lincomb([(scale, R)])
         H = np.zeros((k, maxiter + 1, maxiter))

@@ -51,8 +51,41 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(const int32_t* __
   const int tid = threadIdx.x;
   const int r0 = rowblocks[b], r1 = rowblocks[b + 1];
   const int e0 = indptr[r0], e1 = indptr[r1];
-  if (e1 - e0 <= kNnzTile) {
-    for (int e = e0 + tid; e < e1; e += kThreads) prod[e - e0] = __dmul_rn(vals[e], x[indices[e]]);
+  if (e1 - e0 <= kNnzTile - 2) {
+    // Lane p owns the non-zero PAIR (eb + 2p, eb + 2p + 1), eb = e0 rounded down to even: values come in as
+    // one 16-byte load and indices as one 8-byte load per lane (non-temporal: streamed once, they should not
+    // evict x from L2).  All loads of the tile are issued first, then the gathers of x, then the LDS stores:
+    // three memory latencies per tile.  Row blocks hold at most kNnzTile - 2 non-zeros so the pairs fit.
+    constexpr int IT = kNnzTile / (2 * kThreads);
+    const int eb = e0 & ~1;
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    typedef int int2v __attribute__((ext_vector_type(2)));
+    dbl2 v[IT];
+    int2v col[IT];
+    double xa[IT], xb[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = eb + 2 * (tid + it * kThreads);
+      if (e < e1) {  // e + 1 may equal e1: the pair load stays inside the allocation (padded by one entry)
+        v[it] = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(vals + e));
+        col[it] = __builtin_nontemporal_load(reinterpret_cast<const int2v*>(indices + e));
+      } else {
+        v[it] = dbl2{0.0, 0.0};
+        col[it] = int2v{0, 0};
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = eb + 2 * (tid + it * kThreads);
+      xa[it] = (e >= e0 && e < e1) ? x[col[it][0]] : 0.0;
+      xb[it] = (e + 1 < e1) ? x[col[it][1]] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = eb + 2 * (tid + it * kThreads);
+      if (e >= e0 && e < e1) prod[e - e0] = __dmul_rn(v[it][0], xa[it]);
+      if (e + 1 < e1) prod[e + 1 - e0] = __dmul_rn(v[it][1], xb[it]);
+    }
     __syncthreads();
     for (int r = r0 + tid; r < r1; r += kThreads) {
       const int a = indptr[r] - e0, z = indptr[r + 1] - e0;
@@ -133,7 +166,7 @@ int eigd_csr_upload(eigd_ctx* ctx, int n, int64_t nnz, const int32_t* hindptr, c
       int64_t cnt = 0;
       while (r < n && (r - start) < kMaxRowsTile) {
         int64_t len = hindptr[r + 1] - hindptr[r];
-        if (cnt + len > kNnzTile) break;
+        if (cnt + len > kNnzTile - 2) break;
         cnt += len;
         ++r;
       }
@@ -148,8 +181,8 @@ int eigd_csr_upload(eigd_ctx* ctx, int n, int64_t nnz, const int32_t* hindptr, c
   A->nnz = nnz;
   A->nblocks = static_cast<int>(rb.size()) - 1;
   hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&A->indptr), sizeof(int32_t) * (n + 1));
-  hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&A->indices), sizeof(int32_t) * std::max<int64_t>(nnz, 1));
-  hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&A->data), sizeof(double) * std::max<int64_t>(nnz, 1));
+  hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&A->indices), sizeof(int32_t) * (nnz + 4));
+  hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&A->data), sizeof(double) * (nnz + 4));
   hipError_t e4 = hipMalloc(reinterpret_cast<void**>(&A->rowblocks), sizeof(int32_t) * rb.size());
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
     eigd_mat_free(A);

@@ -68,6 +68,22 @@ class Context:
     def stack(self, ns, n, k=1):
         return DeviceStack(self, ns, n, k)
 
+    def workspace_stack(self, tag, ns, n, k=1):
+        """
+        A stack that is kept alive between calls and handed out again for the same (tag, shape): the Krylov
+        histories are tens of GB at 1 M dof and hipMalloc / hipFree of such blocks costs up to a second.
+        """
+        cache = self.__dict__.setdefault("_ws", {})
+        st = cache.get(tag)
+        if st is None or (st.ns, st.n, st.k) != (int(ns), int(n), int(k)):
+            cache.pop(tag, None)
+            st = DeviceStack(self, ns, n, k)
+            cache[tag] = st
+        return st
+
+    def release_workspaces(self):
+        self.__dict__.pop("_ws", None)
+
 
 def default_context():
     """Context on the device named by EIGD_DEVICE / LOCAL_RANK (default 0)."""
