@@ -260,7 +260,7 @@ def main():
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled as the guide
     # prescribes for gfx950 -- calibrated there on an 8-byte-per-lane stream of known size -- plus WRITE_SIZE);
     # only valid for the default C3 matrix
-    traffic = 238946880 if (args.nx, args.ny) == (706, 706) else None
+    traffic = 237996096 if (args.nx, args.ny) == (706, 706) else None
     roofline = {"kernel": "spmv_stream_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": "profiles/r01_pmc_fetch_spmv_coldot.csv + r01_pmc_write_spmv_coldot.csv",
