@@ -69,6 +69,7 @@ _SIGNATURES = {
     "eigd_lincomb": [c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp],
     "eigd_stack_dot": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_int, c_vp],
     "eigd_stack_axpy": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_dbl],
+    "eigd_stack_axpy_dot": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_dbl, c_vp],
     "eigd_copy_block": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_gather_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
     "eigd_scatter_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],

@@ -423,8 +423,11 @@ def solve_shifted_lstsq(alpha, H, r):
 def _cgs2(Wst, T, ns, c0=0):
     """T <- (I - W W^T) T twice over the first ns slabs (columns c0.. of the stack); returns the summed coefficients"""
     h1 = Wst.dot(T, ns=ns, c0=c0)
-    Wst.axpy_into(T, h1, alpha=-1.0, c0=c0)
-    h2 = Wst.dot(T, ns=ns, c0=c0)
+    if ns <= 32:  # fused: subtract the first projection and measure what is left in one pass over W
+        h2 = Wst.axpy_dot_into(T, h1, alpha=-1.0, c0=c0)
+    else:
+        Wst.axpy_into(T, h1, alpha=-1.0, c0=c0)
+        h2 = Wst.dot(T, ns=ns, c0=c0)
     Wst.axpy_into(T, h2, alpha=-1.0, c0=c0)
     return h1 + h2
 

@@ -119,6 +119,55 @@ __global__ __launch_bounds__(kThreads) void stack_axpy_kernel(int n, int k, int 
   }
 }
 
+// Fused middle section of CGS2:  T <- T + alpha * sum_j S_j H1[j]  and, on the updated T,
+// H2[j] = S_j . T  -- one pass over the slab stack (its values stay in registers between the two
+// uses) instead of an axpy pass plus a dot pass.  ns <= JMAX <= 32.
+template <int KP, int JMAX>
+__global__ __launch_bounds__(kThreads) void stack_axpy_dot_kernel(int n, int k, int ns, const double* __restrict__ S,
+                                                                 int64_t slab, int lds, const double* __restrict__ H1,
+                                                                 double* __restrict__ T, int ldt, double alpha,
+                                                                 double* __restrict__ partial) {
+  constexpr int RP = kThreads / KP;
+  extern __shared__ double Hs[];  // ns * k
+  __shared__ double red[kThreads];
+  for (int q = threadIdx.x; q < ns * k; q += kThreads) Hs[q] = H1[q];
+  __syncthreads();
+  const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
+  double acc[JMAX];
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) acc[j] = 0.0;
+  if (c < k) {
+    double hc[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) hc[j] = (j < ns) ? alpha * Hs[j * k + c] : 0.0;
+    for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
+      const double* sp = S + r * lds + c;
+      double sv[JMAX];
+#pragma unroll
+      for (int j = 0; j < JMAX; ++j) sv[j] = (j < ns) ? sp[j * slab] : 0.0;
+      double t = T[r * ldt + c];
+#pragma unroll
+      for (int j = 0; j < JMAX; ++j) t += sv[j] * hc[j];
+      T[r * ldt + c] = t;
+#pragma unroll
+      for (int j = 0; j < JMAX; ++j) acc[j] += sv[j] * t;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) {
+    if (j < ns) {  // ns is uniform: no divergence around the barriers
+      red[threadIdx.x] = acc[j];
+      __syncthreads();
+      if (rr == 0 && c < k) {
+        double t = 0.0;
+        for (int q = 0; q < RP; ++q) t += red[q * KP + c];
+        partial[(static_cast<int64_t>(blockIdx.x) * ns + j) * k + c] = t;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // lincomb
 // ---------------------------------------------------------------------------
@@ -470,6 +519,40 @@ int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();
   return EIGD_OK;
+}
+
+int eigd_stack_axpy_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* hH1,
+                        double* dT, int ldt, double alpha, double* hH2) {
+  EIGD_REQUIRE(ctx && dS && dT && hH1 && hH2, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ns <= 32 && ldt >= k && lds >= k &&
+                   slab >= static_cast<int64_t>(n - 1) * lds + k,
+               "bad shape n=%d k=%d ns=%d", n, k, ns);
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 8);
+  int rc = ctx->ensure_coef(sizeof(double) * ns * k);
+  if (rc) return rc;
+  rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) + 1) * ns * k);
+  if (rc) return rc;
+  EIGD_HIP(hipMemcpyAsync(ctx->coef, hH1, sizeof(double) * ns * k, hipMemcpyHostToDevice, ctx->stream));
+  EIGD_HIP(hipStreamSynchronize(ctx->stream));
+  double* res = ctx->scratch;
+  double* partial = ctx->scratch + static_cast<size_t>(ns) * k;
+  const size_t shm = sizeof(double) * ns * k;
+  rc = dispatch_kp(k, [&](auto KP) {
+    constexpr int kpv = decltype(KP)::value;
+    if (ns <= 8)
+      hipLaunchKernelGGL((stack_axpy_dot_kernel<kpv, 8>), dim3(nb), dim3(kThreads), shm, ctx->stream, n, k, ns, dS, slab,
+                         lds, ctx->coef, dT, ldt, alpha, partial);
+    else if (ns <= 16)
+      hipLaunchKernelGGL((stack_axpy_dot_kernel<kpv, 16>), dim3(nb), dim3(kThreads), shm, ctx->stream, n, k, ns, dS, slab,
+                         lds, ctx->coef, dT, ldt, alpha, partial);
+    else
+      hipLaunchKernelGGL((stack_axpy_dot_kernel<kpv, 32>), dim3(nb), dim3(kThreads), shm, ctx->stream, n, k, ns, dS, slab,
+                         lds, ctx->coef, dT, ldt, alpha, partial);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  return reduce_to_host(ctx, partial, nb, ns * k, res, hH2);
 }
 
 static int copy_cols(eigd_ctx* ctx, int n, int k, const double* dSrc, int lds, double* dDst, int ldd, int mode,

@@ -390,7 +390,7 @@ bool analyze(int n, const int32_t* ip, const int32_t* ix, int leaf_size, int pan
              const double* dof_coords) {
   s = Symbolic();
   s.n = n;
-  s.leaf_size = leaf_size > 0 ? leaf_size : 48;
+  s.leaf_size = leaf_size > 0 ? leaf_size : 64;
   s.W = panel_width > 0 ? panel_width : 64;
   if (s.W > 64 || s.W < 8) {
     s.error = "panel width must be in [8, 64]";

@@ -309,6 +309,15 @@ class DeviceStack:
                  self.slab, self.k, hptr(np.ascontiguousarray(H[a:b])), T.ptr, T.ld, float(alpha))
         return T
 
+    def axpy_dot_into(self, T, H1, alpha=1.0, j0=0, c0=0):
+        """T += alpha * sum_j S_j H1[j]; returns H2[j, c] = S_j[:, c] . T[:, c] on the updated T (ns <= 32)"""
+        H1 = np.ascontiguousarray(H1, dtype=np.float64).reshape(-1, T.k)
+        ns = H1.shape[0]
+        H2 = np.empty((ns, T.k))
+        call("eigd_stack_axpy_dot", self.ctx.h, self.n, T.k, ns, c_vp(self.buf.ptr + 8 * (j0 * self.slab + c0)),
+             self.slab, self.k, hptr(H1), T.ptr, T.ld, float(alpha), hptr(H2))
+        return H2
+
     # k == 1 stacks double as column-major n x ns matrices (the Lanczos basis)
     def tdot_block(self, X, ns=None):
         """V[:, :ns]^T X -> host (ns x X.k); only for k == 1 stacks"""

@@ -139,6 +139,9 @@ int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_
                    int ldt, double* hH);
 int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* hH,
                     double* dT, int ldt, double alpha);
+/* fused middle of the twice-applied Gram-Schmidt: T += alpha * sum_j S_j hH1[j]; then hH2[j] = S_j . T (ns <= 32) */
+int eigd_stack_axpy_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* hH1,
+                        double* dT, int ldt, double alpha, double* hH2);
 /* copy an n x k block between buffers with different leading dimensions / column offsets */
 int eigd_copy_block(eigd_ctx* ctx, int n, int k, const double* dSrc, int lds, double* dDst, int ldd);
 /* gather columns: Dst[r, j] = Src[r, cols[j]] (compaction of the active modes) */

@@ -118,6 +118,14 @@ def test_stack_kernels(ctx, n, k, ns):
     assert np.allclose(H, Href, rtol=1e-12, atol=1e-11 * np.sqrt(n))
     st.axpy_into(dT, Href, alpha=-1.0)
     assert relerr(dT.get(), T - np.einsum("jrc,jc->rc", S, Href)) < 1e-13
+    if ns <= 32:  # fused axpy + dot
+        T2 = rng.normal(size=(n, k))
+        dT2 = ctx.from_host(T2)
+        H1 = rng.normal(size=(ns, k))
+        H2 = st.axpy_dot_into(dT2, H1, alpha=-0.5)
+        Tn = T2 - 0.5 * np.einsum("jrc,jc->rc", S, H1)
+        assert relerr(dT2.get(), Tn) < 1e-13
+        assert np.allclose(H2, np.einsum("jrc,rc->jc", S, Tn), rtol=1e-11, atol=1e-10 * np.sqrt(n))
     if k == 1:  # column-major view of a k = 1 stack: V^T X and V @ C
         X = rng.normal(size=(n, 7))
         V = S[:, :, 0].T  # n x ns
