@@ -475,17 +475,18 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     Ycoef = np.zeros((maxiter, k))
     T = ctx.empty(prob.n, k)
     jlast = 0
-    for j in range(1, maxiter + 1):
-        kp = j - 1
-        lo, hi = _active_range(done)
+
+    def enqueue_operator(kp, lo, hi, nlive):
+        """device work of one Krylov step up to the first host-visible result (no synchronisation)"""
         Zk, Ta = Z[kp].cols(lo, hi), T.cols(lo, hi)
-        prob.fac.apply_to(W[kp].cols(lo, hi), Zk, count=int(np.count_nonzero(~done)))  # ref 1248: one multi-column sweep
+        prob.fac.apply_to(W[kp].cols(lo, hi), Zk, count=nlive)   # ref 1248: one multi-column sweep
         Kop.apply(Zk, Ta)                                # ref 1250 / 1252
         prob.project_r(Ta)
-        h = _cgs2(W, Ta, j, c0=lo)                       # ref 1254-1256 (Gram-Schmidt vs all previous W)
-        prob.project_r(Ta)                               # ref 1257
-        hn = Ta.colnorms()                               # ref 1259
-        jlast = j
+        return Ta
+
+    def small_solves(j, lo, hi, h, hn):
+        """host side of step j: Hessenberg least squares and convergence tests of the live modes (ref 1262-1321)"""
+        kp = j - 1
         for c in range(lo, hi):
             if done[c]:
                 continue
@@ -502,11 +503,38 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
             elif j == maxiter:                           # ref 1312-1313: keep the best iterate
                 Ycoef[:j, c] = y
                 done[c] = True
+
+    # Software pipeline: the device work of step j+1 (sweep, SpMM, projection) is enqueued BEFORE the host does
+    # the least-squares problems of step j, so the small dense solves overlap the triangular sweep.  A mode that
+    # turns out to have converged at step j rides along for one extra step (its coefficients there are zero).
+    lo, hi = _active_range(done)
+    Ta = enqueue_operator(0, lo, hi, int(np.count_nonzero(~done)))
+    for j in range(1, maxiter + 1):
+        h = _cgs2(W, Ta, j, c0=lo)                       # ref 1254-1256 (Gram-Schmidt vs all previous W)
+        prob.project_r(Ta)                               # ref 1257
+        hn = Ta.colnorms()                               # ref 1259
+        jlast = j
+        cur = (lo, hi)
+        nxt = None
+        if j < maxiter:
+            dn = done[lo:hi]
+            scale = np.where(dn | (hn == 0.0), 0.0, 1.0 / np.where(hn == 0.0, 1.0, hn))
+            W[j].cols(lo, hi).assign_lincomb([(scale, Ta)])  # ref 1260
+            nxt = enqueue_operator(j, lo, hi, 0)
+        small_solves(j, cur[0], cur[1], h, hn)
         if done.all():
             break
-        dn = done[lo:hi]
-        scale = np.where(dn | (hn == 0.0), 0.0, 1.0 / np.where(hn == 0.0, 1.0, hn))
-        W[j].cols(lo, hi).assign_lincomb([(scale, Ta)])  # ref 1260
+        if nxt is not None and prob.fac.native:          # count the sweep in flight for the modes that go on
+            prob.fac.factor.count += int(np.count_nonzero(~done))
+        if nxt is not None:
+            # the step in flight keeps the range it was launched with; narrower ranges apply from the step after.
+            # Columns that finished meanwhile are zeroed when the next basis vector is formed (scale above).
+            nlo, nhi = _active_range(done)
+            if (nlo, nhi) != (lo, hi):
+                Ta = nxt.cols(nlo - lo, nhi - lo)
+                lo, hi = nlo, nhi
+            else:
+                Ta = nxt
     Z.axpy_into(dpsi, Ycoef[:jlast], alpha=1.0)          # ref 1277 / 1313: psi += Z y
     return dpsi, converged, info
 
