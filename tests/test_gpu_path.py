@@ -607,3 +607,46 @@ def test_c4_like_thermal_repeated_eigenvalues_at_scale():
     _, ortho = s.eval_adjoint_residual_norm(Phib, psi, b_ortho=False)
     assert res.max() < 1e-7 * max(np.linalg.norm(Phib, axis=0).max(), 1.0)
     assert ortho.max() < 1e-7 * max(np.abs(psi).max(), 1.0)
+
+
+def test_foreign_factor_and_operators_are_honoured():
+    """
+    `factor`, A, B may be any LinearOperator (reference 1492-1497, 1933-1936): a foreign factor is applied by the
+    caller's own code (block copied to the host and back), everything else stays on the device.
+    """
+    import eigd_amd as eg
+    from scipy.sparse.linalg import LinearOperator, aslinearoperator, splu
+
+    g = load_golden("g4_laplace900_basiclanczos")
+    K, M = csr_from(g, "K"), csr_from(g, "M")
+    sigma = -0.1
+    lu = splu((K - sigma * M).tocsc())
+    calls = {"n": 0}
+
+    def mv(x):
+        calls["n"] += 1
+        return lu.solve(x)
+
+    foreign = LinearOperator(K.shape, matvec=mv, matmat=mv, dtype=float)
+    s = eg.BasicLanczos(N=6, m=60)
+    lam, Phi = s.solve(aslinearoperator(K), M, foreign, sigma)   # A as a scipy MatrixLinearOperator, B sparse
+    assert relerr(lam, g["normal_lam"]) < RTOL
+    assert calls["n"] > 10
+    psi, data = s.solve_adjoint(g["Phib"].copy(), method="sibk", rtol=1e-12)
+    s.Phi, s.lam0 = g["normal_Phi"].copy(), g["normal_lam"].copy()
+    _adopt_reference_lanczos(s, g, "normal_")
+    psi, data = s.solve_adjoint(g["Phib"].copy(), method="sibk", rtol=1e-12)
+    assert relerr(psi, g["normal_sibk_psi"]) < RTOL
+
+
+def test_iram_reports_non_convergence():
+    import eigd_amd as eg
+    from scipy.sparse.linalg import ArpackNoConvergence
+
+    g = load_golden("g4_laplace900_basiclanczos")
+    K, M = csr_from(g, "K"), csr_from(g, "M")
+    fac = eg.SpLuOperator((K + 0.1 * M).tocsc())
+    with pytest.raises(ArpackNoConvergence):
+        eg.IRAM(N=12, m=25, maxiter=0).solve(K, M, fac, -0.1)
+    with pytest.raises(ValueError):
+        eg.IRAM(N=6, m=2000).solve(K, M, fac, -0.1)   # ncv must not exceed n
