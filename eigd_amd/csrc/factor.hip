@@ -413,7 +413,7 @@ __device__ __forceinline__ void load_inverse(double* As, const double* __restric
 #pragma unroll
   for (int it = 0; it < TILE_IT; ++it) {
     const int j = jb + it * (kThreads / TW);
-    tmp[it] = (j < w && i < w) ? Ig[j * W + i] : 0.0;
+    tmp[it] = (j < w && i < w && i >= j) ? Ig[j * W + i] : 0.0;  // lower triangular: the zero half is not fetched
   }
 #pragma unroll
   for (int it = 0; it < TILE_IT; ++it) As[(jb + it * (kThreads / TW)) * TLD + i] = tmp[it];
