@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--cpu-sample", choices=("full", "none"), default="full",
                     help="CPU baseline: SuperLU factor of the same matrix + the oracle's sibk on two of the modes")
     ap.add_argument("--spmv-reps", type=int, default=200)
+    ap.add_argument("--streams", type=int, default=None,
+                    help="mode groups solved concurrently on separate HIP streams (default: EIGD_STREAMS or 1)")
     ap.add_argument("--ordering", choices=("geometric", "algebraic"), default="geometric",
                     help="nested dissection with the mesh coordinates as a hint, or purely from the matrix graph")
     ap.add_argument("--pyprofile", default=None, help="write a cProfile summary of one extra step to this file")
@@ -154,7 +156,7 @@ def main():
     def step():
         factor.count = 0
         dpsi, data = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1,
-                                          comm=comm)
+                                          comm=comm, streams=args.streams)
         dfdx = solver.add_total_derivative(lamb, dPhib, dpsi, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data,
                                            deriv_type="tensor", comm=comm)
         return dpsi, data, dfdx

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "eigd_version": [],
     "eigd_device_count": [P(c_int)],
     "eigd_ctx_create": [c_int, P(c_vp)],
+    "eigd_ctx_fork": [c_vp, P(c_vp)],
     "eigd_ctx_destroy": [c_vp],
     "eigd_sync": [c_vp],
     "eigd_malloc": [c_vp, c_sz, P(c_vp)],
@@ -49,6 +50,7 @@ _SIGNATURES = {
     "eigd_csr_update_values": [c_vp, c_vp],
     "eigd_mat_free": [c_vp],
     "eigd_spmm": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_dbl],
+    "eigd_spmm_on": [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_dbl],
     "eigd_symbolic_create": [c_int, c_vp, c_vp, c_int, c_int, P(c_vp)],
     "eigd_symbolic_create_geom": [c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, P(c_vp)],
     "eigd_symbolic_free": [c_vp],
@@ -60,6 +62,9 @@ _SIGNATURES = {
     "eigd_factor_free": [c_vp],
     "eigd_factor_solve": [c_vp, c_vp, c_int, c_int, c_dbl],
     "eigd_factor_solve_to": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl],
+    "eigd_factor_lane_create": [c_vp, c_vp, P(c_vp)],
+    "eigd_factor_lane_free": [c_vp],
+    "eigd_factor_lane_solve_to": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl],
     "eigd_factor_stats": [c_vp, c_vp, c_int],
     "eigd_factor_solve_bytes": [c_vp, c_int, P(c_dbl)],
     "eigd_gemm_tn": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_int, c_vp],

@@ -54,6 +54,14 @@ class DeviceProblem:
         self.Phi = None
         self.BPhi = None
 
+    def on(self, ctx):
+        """the same problem (shared device data) with work enqueued on another context / stream of the device"""
+        import copy
+
+        other = copy.copy(self)
+        other.ctx = ctx
+        return other
+
     def set_phi(self, Phi_host=None, Phi_dev=None):
         self.Phi = Phi_dev if Phi_dev is not None else self.ctx.from_host(Phi_host)
         self.BPhi = self.opB.apply(self.Phi)
@@ -525,7 +533,8 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
         if done.all():
             break
         if nxt is not None and prob.fac.native:          # count the sweep in flight for the modes that go on
-            prob.fac.factor.count += int(np.count_nonzero(~done))
+            with prob.fac.factor._count_lock:
+                prob.fac.factor.count += int(np.count_nonzero(~done))
         if nxt is not None:
             # the step in flight keeps the range it was launched with; narrower ranges apply from the step after.
             # Columns that finished meanwhile are zeroed when the next basis vector is formed (scale above).
@@ -539,7 +548,62 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     return dpsi, converged, info
 
 
-def _sibk_device(prob, dPhib, dpsi, lam_c, sigma, rtol, atol, maxiter, nrestart, callback, rnorm0=None):
+def _default_streams():
+    import os
+
+    return max(1, int(os.environ.get("EIGD_STREAMS", "1")))
+
+
+def _run_groups(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist, streams):
+    """
+    One attempt for the columns of Rc, optionally split into `streams` interleaved mode groups that run
+    concurrently: each group has its own context (HIP stream), Krylov workspaces and sweep lane, and is driven
+    by its own host thread (ctypes releases the GIL inside the library), so the dependent launch chain of one
+    group's triangular sweep overlaps the other groups' work.  Groups never exchange data.
+    """
+    k = Rc.k
+    groups = max(1, min(int(streams), k))
+    if groups == 1:
+        return _sibk_round(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist)
+    import threading
+
+    parts = [np.arange(g, k, groups) for g in range(groups)]
+    Rg = [Rc.gather_cols(part) for part in parts]
+    prob.ctx.sync()
+    out = [None] * groups
+    errors = []
+
+    def work(g):
+        try:
+            ctxg = prob.ctx.fork(g)
+            pg = prob.on(ctxg)
+            R0 = ctxg.empty(Rc.n, len(parts[g])).copy_from(Rg[g])
+            out[g] = _sibk_round(pg, R0, lam_p[parts[g]], sigma, rnorm0, rtol, atol, maxiter,
+                                 [sub_hist[c] for c in parts[g]])
+            ctxg.sync()
+        except BaseException as exc:  # re-raised on the calling thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(g,)) for g in range(groups)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    upd = prob.ctx.zeros(Rc.n, k)
+    conv = np.zeros(k, dtype=bool)
+    info = [None] * k
+    for g, part in enumerate(parts):
+        ug, cg, ig = out[g]
+        prob.ctx.empty(Rc.n, len(part)).copy_from(ug).scatter_cols_into(upd, part)
+        conv[part] = cg
+        for q, c in enumerate(part):
+            info[c] = ig[q]
+    return upd, conv, info
+
+
+def _sibk_device(prob, dPhib, dpsi, lam_c, sigma, rtol, atol, maxiter, nrestart, callback, rnorm0=None, streams=None):
     """
     Lock-step sibk (bs_target = 1, update_guess = False) on the columns of dPhib / dpsi.
     dpsi is updated in place; returns the info list.
@@ -548,6 +612,8 @@ def _sibk_device(prob, dPhib, dpsi, lam_c, sigma, rtol, atol, maxiter, nrestart,
     lam_c = np.asarray(lam_c, dtype=float)
     if rnorm0 is None:
         rnorm0 = _rnorm0(dPhib)
+    if streams is None:
+        streams = _default_streams()
     R = prob.residual(dPhib, dpsi, lam_c)                # ref 1189-1192
     prob.project_r(R)                                    # ref 1193
     hist = [[] for _ in range(k)]
@@ -556,7 +622,7 @@ def _sibk_device(prob, dPhib, dpsi, lam_c, sigma, rtol, atol, maxiter, nrestart,
     for attempt in range(nrestart + 1):                  # ref 1312-1321: restarts reuse the same residual
         Rc = R if len(pending) == k else R.gather_cols(pending)
         sub_hist = [hist[c] for c in pending]
-        upd, conv, inf = _sibk_round(prob, Rc, lam_c[pending], sigma, rnorm0, rtol, atol, maxiter, sub_hist)
+        upd, conv, inf = _run_groups(prob, Rc, lam_c[pending], sigma, rnorm0, rtol, atol, maxiter, sub_hist, streams)
         if len(pending) == k:
             dpsi.assign_lincomb([(1.0, dpsi), (1.0, upd)])
         else:

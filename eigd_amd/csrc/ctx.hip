@@ -76,6 +76,11 @@ int eigd_ctx_create(int device, eigd_ctx** out) {
   return EIGD_OK;
 }
 
+int eigd_ctx_fork(eigd_ctx* parent, eigd_ctx** out) {
+  EIGD_REQUIRE(parent && out, "null argument");
+  return eigd_ctx_create(parent->device, out);
+}
+
 int eigd_ctx_destroy(eigd_ctx* ctx) {
   if (!ctx) return EIGD_OK;
   (void)hipSetDevice(ctx->device);

@@ -768,14 +768,14 @@ int numeric(eigd_factor* f, const double* hdata) {
 }
 
 template <int KPT>
-int sweep(eigd_factor* f, const double* dIn, int ldin, double* dX, int ldx, int kb, double alpha) {
+int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, const double* dIn, int ldin, double* dX,
+          int ldx, int kb, double alpha) {
   const Symbolic& s = *f->sym;
-  hipStream_t st = f->ctx->stream;
   const FrontArrays fa = f->fa();
   const int64_t total = s.sumd * kb;
   const int gb = static_cast<int>(std::min<int64_t>((total + 255) / 256, 16384));
   hipLaunchKernelGGL(solve_init_kernel, dim3(std::max(gb, 1)), dim3(256), 0, st, s.sumd, kb, f->d_v_src, dIn, ldin,
-                     alpha, f->d_V);
+                     alpha, wV);
   EIGD_LAUNCH_CHECK();
   auto step_args = [&](int l, int step) {
     const int rec = s.ls_ptr[l] + step;
@@ -797,14 +797,14 @@ int sweep(eigd_factor* f, const double* dIn, int ldin, double* dX, int ldx, int 
       if (cnt == 0) continue;
       const int split = std::max(1, std::min(64, f->ea_split[rec] / 8));
       hipLaunchKernelGGL(vec_extend_add_kernel, dim3(cnt, split), dim3(kThreads), 0, st, fa,
-                         f->d_cs_child + s.cs_ptr[rec], kb, f->d_V);
+                         f->d_cs_child + s.cs_ptr[rec], kb, wV);
       EIGD_LAUNCH_CHECK();
     }
     for (int step = 0; step < s.lvl_nsteps[l]; ++step) {
       const StepArgs sa = step_args(l, step);
       const int nwork = s.pref_work[s.ls_pref_ptr[s.ls_ptr[l] + step] + sa.na];
-      hipLaunchKernelGGL(fwd_step_kernel<KPT>, dim3(nwork), dim3(kThreads), 0, st, fa, sa, f->d_F, f->d_Inv, f->d_V,
-                         f->d_Y);
+      hipLaunchKernelGGL(fwd_step_kernel<KPT>, dim3(nwork), dim3(kThreads), 0, st, fa, sa, f->d_F, f->d_Inv, wV,
+                         wY);
       EIGD_LAUNCH_CHECK();
     }
   }
@@ -815,21 +815,21 @@ int sweep(eigd_factor* f, const double* dIn, int ldin, double* dX, int ldx, int 
     const int npan = s.pref_panels[pp + nf];
     const int nbw = s.pref_bwork[pp + nf];
     hipLaunchKernelGGL(bwd_border_kernel<KPT>, dim3(nbw), dim3(kThreads), 0, st, fa, f->d_lvl_fronts + s.lvl_ptr[l],
-                       nf, f->d_pref_bwork + pp, kb, f->d_F, f->d_Inv, f->d_V, f->d_Y, f->d_P);
+                       nf, f->d_pref_bwork + pp, kb, f->d_F, f->d_Inv, wV, wY, wP);
     EIGD_LAUNCH_CHECK();
     if (nbw > npan) {  // some front of the level has more than one tile group
       hipLaunchKernelGGL(bwd_fold_kernel, dim3(npan), dim3(kThreads), 0, st, fa, f->d_lvl_fronts + s.lvl_ptr[l], nf,
-                         f->d_pref_panels + pp, kb, f->d_P, f->d_Y);
+                         f->d_pref_panels + pp, kb, wP, wY);
       EIGD_LAUNCH_CHECK();
     }
     for (int step = s.lvl_nsteps[l] - 1; step >= 0; --step) {
       const StepArgs sa = step_args(l, step);
       hipLaunchKernelGGL(bwd_step_kernel<KPT>, dim3(sa.na * std::max(1, step)), dim3(kThreads), 0, st, fa, sa, f->d_F,
-                         f->d_Inv, f->d_V, f->d_Y);
+                         f->d_Inv, wV, wY);
       EIGD_LAUNCH_CHECK();
     }
   }
-  hipLaunchKernelGGL(solve_out_kernel, dim3(std::max(gb, 1)), dim3(256), 0, st, s.sumd, kb, f->d_v_src, f->d_V, dX, ldx);
+  hipLaunchKernelGGL(solve_out_kernel, dim3(std::max(gb, 1)), dim3(256), 0, st, s.sumd, kb, f->d_v_src, wV, dX, ldx);
   EIGD_LAUNCH_CHECK();
   return EIGD_OK;
 }
@@ -1043,23 +1043,74 @@ int eigd_factor_solve(eigd_factor* f, double* dX, int ldx, int k, double alpha) 
   return eigd_factor_solve_to(f, dX, ldx, dX, ldx, k, alpha);
 }
 
-int eigd_factor_solve_to(eigd_factor* f, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha) {
+static int solve_blocks(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, const double* dIn, int ldin,
+                        double* dOut, int ldout, int k, double alpha) {
   EIGD_REQUIRE(f && dIn && dOut, "null argument");
   EIGD_REQUIRE(k >= 1 && ldin >= k && ldout >= k, "bad block shape k=%d ldin=%d ldout=%d", k, ldin, ldout);
   for (int c0 = 0; c0 < k; c0 += KBMAX) {
     const int kb = std::min(KBMAX, k - c0);
     int rc;
     if (kb <= 4)
-      rc = sweep<1>(f, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
+      rc = sweep<1>(f, st, wV, wY, wP, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else if (kb <= 8)
-      rc = sweep<2>(f, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
+      rc = sweep<2>(f, st, wV, wY, wP, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else if (kb <= 16)
-      rc = sweep<4>(f, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
+      rc = sweep<4>(f, st, wV, wY, wP, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else
-      rc = sweep<8>(f, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
+      rc = sweep<8>(f, st, wV, wY, wP, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     if (rc != EIGD_OK) return rc;
   }
   return EIGD_OK;
+}
+
+int eigd_factor_solve_to(eigd_factor* f, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha) {
+  EIGD_REQUIRE(f, "null argument");
+  return solve_blocks(f, f->ctx->stream, f->d_V, f->d_Y, f->d_P, dIn, ldin, dOut, ldout, k, alpha);
+}
+
+// A lane = a second set of sweep workspaces bound to another context (stream) of the same device: sweeps of
+// different lanes run concurrently on the one factor (independent mode groups overlap each other's latency).
+struct eigd_lane {
+  eigd_factor* f = nullptr;
+  eigd_ctx* ctx = nullptr;
+  double *V = nullptr, *Y = nullptr, *P = nullptr;
+};
+
+int eigd_factor_lane_create(eigd_factor* f, eigd_ctx* ctx, eigd_lane** out) {
+  EIGD_REQUIRE(f && ctx && out, "null argument");
+  EIGD_REQUIRE(ctx->device == f->ctx->device, "lane context must live on the factor's device");
+  *out = nullptr;
+  const Symbolic& s = *f->sym;
+  eigd_lane* l = new eigd_lane();
+  l->f = f;
+  l->ctx = ctx;
+  const size_t vb = sizeof(double) * std::max<size_t>(static_cast<size_t>(s.sumd) * KBMAX, 1);
+  const size_t pb = sizeof(double) * static_cast<size_t>(std::max<int64_t>(s.nslabs, 1)) * TW * KBMAX;
+  hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&l->V), vb);
+  hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&l->Y), vb);
+  hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&l->P), pb);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    eigd_factor_lane_free(l);
+    set_error("hipMalloc failed for a sweep lane");
+    return EIGD_E_HIP;
+  }
+  *out = l;
+  return EIGD_OK;
+}
+
+int eigd_factor_lane_free(eigd_lane* l) {
+  if (!l) return EIGD_OK;
+  if (l->ctx && l->ctx->stream) (void)hipStreamSynchronize(l->ctx->stream);
+  if (l->V) (void)hipFree(l->V);
+  if (l->Y) (void)hipFree(l->Y);
+  if (l->P) (void)hipFree(l->P);
+  delete l;
+  return EIGD_OK;
+}
+
+int eigd_factor_lane_solve_to(eigd_lane* l, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha) {
+  EIGD_REQUIRE(l, "null argument");
+  return solve_blocks(l->f, l->ctx->stream, l->V, l->Y, l->P, dIn, ldin, dOut, ldout, k, alpha);
 }
 
 int eigd_factor_stats(eigd_factor* f, double* out, int nout) {

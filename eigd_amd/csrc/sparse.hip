@@ -218,10 +218,17 @@ int eigd_mat_free(eigd_mat* A) {
 }
 
 int eigd_spmm(eigd_mat* A, const double* dX, int ldx, double* dY, int ldy, int k, double alpha, double beta) {
-  EIGD_REQUIRE(A && dX && dY, "null argument");
+  EIGD_REQUIRE(A, "null argument");
+  return eigd_spmm_on(A->ctx, A, dX, ldx, dY, ldy, k, alpha, beta);
+}
+
+int eigd_spmm_on(eigd_ctx* ctx, eigd_mat* A, const double* dX, int ldx, double* dY, int ldy, int k, double alpha,
+                 double beta) {
+  EIGD_REQUIRE(ctx && A && dX && dY, "null argument");
+  EIGD_REQUIRE(ctx->device == A->ctx->device, "context and matrix live on different devices");
   EIGD_REQUIRE(k >= 1 && ldx >= k && ldy >= k, "bad block shape k=%d ldx=%d ldy=%d", k, ldx, ldy);
   EIGD_REQUIRE(dX != dY, "spmm cannot run in place");
-  hipStream_t st = A->ctx->stream;
+  hipStream_t st = ctx->stream;
   if (k == 1 && ldx == 1 && ldy == 1) {
     const int nbp = (A->nblocks + 7) & ~7;
     hipLaunchKernelGGL(spmv_stream_kernel, dim3(nbp), dim3(kThreads), 0, st, A->rowblocks, A->nblocks, nbp, A->indptr,

@@ -18,11 +18,22 @@ _default_ctx = None
 class Context:
     """One device + one stream."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _parent=None):
         h = c_vp()
-        call("eigd_ctx_create", int(device), C.byref(h))
+        if _parent is None:
+            call("eigd_ctx_create", int(device), C.byref(h))
+        else:
+            call("eigd_ctx_fork", _parent.h, C.byref(h))
         self.h = h
         self.device = int(device)
+        self.parent = _parent
+
+    def fork(self, index=0):
+        """child context number `index` on the same device (own stream); created once and kept"""
+        kids = self.__dict__.setdefault("_children", {})
+        if index not in kids:
+            kids[index] = Context(self.device, _parent=self)
+        return kids[index]
 
     def sync(self):
         call("eigd_sync", self.h)
@@ -387,7 +398,7 @@ class CSRMatrix:
             Y = self.ctx.empty(X.n, X.k)
         if X.n != self.n or (Y.n, Y.k) != (X.n, X.k):
             raise ValueError("shape mismatch in SpMM")
-        call("eigd_spmm", self.h, X.ptr, X.ld, Y.ptr, Y.ld, X.k, float(alpha), float(beta))
+        call("eigd_spmm_on", X.ctx.h, self.h, X.ptr, X.ld, Y.ptr, Y.ld, X.k, float(alpha), float(beta))  # on X's stream
         return Y
 
     def spmv_bytes(self, k=1):
@@ -476,6 +487,8 @@ class Factor:
 
     def __del__(self):
         try:
+            for h, _ in self.__dict__.get("_lanes", {}).values():
+                _ffi.lib().eigd_factor_lane_free(h)
             if getattr(self, "h", None) is not None and self.ctx.h is not None:
                 _ffi.lib().eigd_factor_free(self.h)
                 self.h = None
@@ -493,15 +506,30 @@ class Factor:
     def solve_inplace(self, X, alpha=1.0):
         if X.n != self.n:
             raise ValueError("shape mismatch in factor solve")
+        if X.ctx is not self.ctx:
+            return self.solve_to(X, X, alpha)
         call("eigd_factor_solve", self.h, X.ptr, X.ld, X.k, float(alpha))
         return X
 
     def solve_to(self, Xin, Xout, alpha=1.0):
-        """Xout <- alpha * M^{-1} Xin (Xin untouched)"""
+        """Xout <- alpha * M^{-1} Xin (Xin untouched); runs on the stream of Xout's context"""
         if Xin.n != self.n or (Xout.n, Xout.k) != (Xin.n, Xin.k):
             raise ValueError("shape mismatch in factor solve")
-        call("eigd_factor_solve_to", self.h, Xin.ptr, Xin.ld, Xout.ptr, Xout.ld, Xin.k, float(alpha))
+        if Xout.ctx is self.ctx:
+            call("eigd_factor_solve_to", self.h, Xin.ptr, Xin.ld, Xout.ptr, Xout.ld, Xin.k, float(alpha))
+        else:
+            call("eigd_factor_lane_solve_to", self._lane(Xout.ctx), Xin.ptr, Xin.ld, Xout.ptr, Xout.ld, Xin.k,
+                 float(alpha))
         return Xout
+
+    def _lane(self, ctx):
+        lanes = self.__dict__.setdefault("_lanes", {})
+        key = id(ctx)
+        if key not in lanes:
+            h = c_vp()
+            call("eigd_factor_lane_create", self.h, ctx.h, C.byref(h))
+            lanes[key] = (h, ctx)
+        return lanes[key][0]
 
     def stats(self):
         out = np.zeros(4)

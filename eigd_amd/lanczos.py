@@ -170,6 +170,7 @@ class _AdjointAPI:
         if method == "sibk":
             maxiter = kw.pop("maxiter", 50)
             nrestart = kw.pop("nrestart", 2)
+            streams = kw.pop("streams", None)
             bs_target = kw.pop("bs_target", 1)
             update_guess = kw.pop("update_guess", False)
             kw.pop("eig_atol", None)
@@ -181,7 +182,7 @@ class _AdjointAPI:
                                                       bs_target, update_guess, callback, nrestart)
             else:
                 self.last_info = adj._sibk_device(prob, dPhib_c, psi_c, lam_c, self.sigma, rtol, atol, maxiter,
-                                                  nrestart, callback, rnorm0=rnorm0)
+                                                  nrestart, callback, rnorm0=rnorm0, streams=streams)
         elif method == "pgmres":
             maxiter = kw.pop("maxiter", 50)
             if kw:

@@ -3,6 +3,7 @@ Operator layer: the drop-in ``SpLuOperator`` (reference eigd/eigenvector_derivat
 and the adapters that let the device drivers apply A, B and ``factor`` to device blocks.
 """
 
+import threading
 import weakref
 
 import numpy as np
@@ -34,6 +35,7 @@ class SpLuOperator(LinearOperator):
         self.shape = mat.shape
         self.dtype = np.dtype(np.float64)
         self.count = 0
+        self._count_lock = threading.Lock()  # mode groups on different streams share the counter
         csr = mat.tocsr().astype(np.float64)  # for a symmetric matrix CSC and CSR coincide
         csr.sort_indices()
         if check_symmetry:
@@ -53,12 +55,14 @@ class SpLuOperator(LinearOperator):
         that carry a live right-hand side (finished modes of a lock-step block are zero columns);
         the counter then means what the reference's does: applications per mode (ref 19-22).
         """
-        self.count += X.k if count is None else int(count)
+        with self._count_lock:
+            self.count += X.k if count is None else int(count)
         return self.factor.solve_inplace(X, alpha)
 
     def solve_device_to(self, Xin, Xout, alpha=1.0, count=None):
         """Xout <- alpha * mat^{-1} Xin on device blocks, Xin untouched"""
-        self.count += Xin.k if count is None else int(count)
+        with self._count_lock:
+            self.count += Xin.k if count is None else int(count)
         return self.factor.solve_to(Xin, Xout, alpha)
 
     def refactor(self, mat):

@@ -41,6 +41,7 @@ typedef struct eigd_ctx eigd_ctx;
 typedef struct eigd_mat eigd_mat;           /* device CSR matrix                     */
 typedef struct eigd_symbolic eigd_symbolic; /* host ordering + symbolic factorisation */
 typedef struct eigd_factor eigd_factor;     /* device numeric factor                 */
+typedef struct eigd_lane eigd_lane;         /* extra sweep workspaces of a factor, bound to another stream */
 
 const char* eigd_last_error(void);
 int eigd_version(void);
@@ -48,6 +49,9 @@ int eigd_version(void);
 /* ---- context, memory, transfers ---------------------------------------- */
 int eigd_device_count(int* count);
 int eigd_ctx_create(int device, eigd_ctx** out);
+/* a second context (own stream, events, scratch) on the parent's device: independent mode groups of the
+ * lock-step solvers run on forked contexts so that their launch chains overlap */
+int eigd_ctx_fork(eigd_ctx* parent, eigd_ctx** out);
 int eigd_ctx_destroy(eigd_ctx* ctx);
 int eigd_sync(eigd_ctx* ctx);
 int eigd_malloc(eigd_ctx* ctx, size_t bytes, void** dptr);
@@ -72,6 +76,9 @@ int eigd_csr_upload(eigd_ctx* ctx, int n, int64_t nnz, const int32_t* hindptr, c
 int eigd_csr_update_values(eigd_mat* A, const double* hdata);
 int eigd_mat_free(eigd_mat* A);
 int eigd_spmm(eigd_mat* A, const double* dX, int ldx, double* dY, int ldy, int k, double alpha, double beta);
+/* same product enqueued on another context of the same device */
+int eigd_spmm_on(eigd_ctx* ctx, eigd_mat* A, const double* dX, int ldx, double* dY, int ldy, int k, double alpha,
+                 double beta);
 
 /* ---- sparse shift-invert factorisation ------------------------------------
  * replaces SuperLU behind SpLuOperator (11-23): splu(mat) -> analyse + factor,
@@ -103,6 +110,10 @@ int eigd_factor_free(eigd_factor* f);
 int eigd_factor_solve(eigd_factor* f, double* dX, int ldx, int k, double alpha);
 /* out of place: Out <- alpha * M^{-1} In (In is not modified; In == Out is allowed) -- Z[:, kp] = factor(W[:, kp]) (1248) */
 int eigd_factor_solve_to(eigd_factor* f, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha);
+/* concurrent sweeps on one factor: a lane owns its own vector workspaces and runs on `ctx`'s stream */
+int eigd_factor_lane_create(eigd_factor* f, eigd_ctx* ctx, eigd_lane** out);
+int eigd_factor_lane_free(eigd_lane* lane);
+int eigd_factor_lane_solve_to(eigd_lane* lane, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha);
 /* stats: [0]=nnz(L) [1]=device bytes held [2]=factor flops [3]=min pivot*1e300? (unused) */
 int eigd_factor_stats(eigd_factor* f, double* out, int nout);
 /* bytes of L streamed by one k-column solve (algorithmic, for the roofline) */

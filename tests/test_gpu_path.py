@@ -650,3 +650,24 @@ def test_iram_reports_non_convergence():
         eg.IRAM(N=12, m=25, maxiter=0).solve(K, M, fac, -0.1)
     with pytest.raises(ValueError):
         eg.IRAM(N=6, m=2000).solve(K, M, fac, -0.1)   # ncv must not exceed n
+
+
+def test_concurrent_mode_groups_on_streams_match_single_stream():
+    """streams=3: the modes are split into three groups on three HIP streams / host threads; same psi, data, counts"""
+    import eigd_amd as eg
+
+    g = load_golden("g4_laplace900_basiclanczos")
+    K, M = csr_from(g, "K"), csr_from(g, "M")
+    fac = eg.SpLuOperator((K + 0.1 * M).tocsc())
+    s = eg.BasicLanczos(N=6, m=60)
+    s.solve(K, M, fac, -0.1)
+    fac.count = 0
+    hist1, hist3 = [], []
+    psi1, data1 = s.solve_adjoint(g["Phib"], method="sibk", rtol=1e-12, callback=hist1.append, streams=1)
+    c1 = fac.count
+    fac.count = 0
+    psi3, data3 = s.solve_adjoint(g["Phib"], method="sibk", rtol=1e-12, callback=hist3.append, streams=3)
+    assert relerr(psi3, psi1) < 1e-11
+    assert index_sets(data3) == index_sets(data1)
+    assert fac.count == c1 and len(hist3) == len(hist1)
+    assert np.allclose(hist3, hist1, rtol=1e-6, atol=1e-14)
