@@ -680,7 +680,6 @@ struct eigd_factor {
   double *d_data = nullptr, *d_F = nullptr, *d_Inv = nullptr, *d_V = nullptr, *d_Y = nullptr;
   int* d_flag = nullptr;
   size_t bytes = 0;
-  int64_t max_chunks = 0;
   std::vector<int> ea_split;  // per (level, slot): grid.y of the extend-add launches
   int64_t data_len = 0;
 
@@ -947,9 +946,6 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   EIGD_HIP(hipSetDevice(ctx->device));
   size_t free_b = 0, total_b = 0;
   EIGD_HIP(hipMemGetInfo(&free_b, &total_b));
-  int64_t max_chunks = 1;
-  for (size_t rec = 0; rec < s.ls_nactive.size(); ++rec)
-    max_chunks = std::max<int64_t>(max_chunks, s.pref_chunks[s.ls_pref_ptr[rec] + s.ls_nactive[rec]]);
   const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + 2 * s.sumd * KBMAX + s.nslabs * TW * KBMAX) +
                       16 * s.a_src.size() + (size_t(64) << 20);
   if (need > free_b) {
@@ -959,7 +955,6 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   eigd_factor* f = new eigd_factor();
   f->ctx = ctx;
   f->sym = &h->s;
-  f->max_chunks = max_chunks;
   int rc = EIGD_OK;
 #define UP(dst, vec)                          \
   if (rc == EIGD_OK) rc = upload(f, &f->dst, vec);

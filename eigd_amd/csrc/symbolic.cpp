@@ -52,12 +52,7 @@ void compress(int n, const int32_t* ip, const int32_t* ix, Graph& g) {
     for (int i = 0; i < n; ++i) g.cv_dofs[pos[g.cv_of[i]]++] = i;
   }
   // adjacency of the compressed graph = union over member rows, symmetrised
-  std::vector<std::pair<int, int>> edges;
   std::vector<int> stamp(nv, -1);
-  // first pass: directed edges from the rows as given
-  std::vector<int64_t> cnt(nv + 1, 0);
-  std::vector<int> tmp;
-  std::vector<std::vector<int>> dummy;  // unused
   // collect unique neighbours per compressed vertex (from all member rows)
   std::vector<int64_t> xa(nv + 1, 0);
   std::vector<int> ad;

@@ -469,8 +469,6 @@ class IRAM(_AdjointAPI):
             if scratch is None:
                 scratch = (ctx.stack(m, n, 1), ctx.stack(m, n, 1))
             nV, nBV = scratch
-            from ._ffi import call, hptr
-
             # new basis = V S_k (column-major k=1 stacks): one product per kept vector block
             for src, dst in ((dev.V, nV), (dev.BV, nBV)):
                 blk = ctx.empty(n, keep)
@@ -484,10 +482,8 @@ class IRAM(_AdjointAPI):
             dev.BV[keep].copy_from(dev.BV[m])
             T = np.zeros((m, m))
             T[np.arange(keep), np.arange(keep)] = theta[selk]
-            arrow = beta_m * Sk[m - 1, :]
-            # the next step recomputes column `keep` in full (arrow + diagonal) by Gram-Schmidt
+            # the next step recomputes column `keep` in full (arrow beta_m * S[m-1, sel] + diagonal) by Gram-Schmidt
             j0 = keep
-            self._arrow = arrow
             self.n_restarts += 1
         if nconv < k:
             from scipy.sparse.linalg import ArpackNoConvergence

@@ -4,13 +4,12 @@ and the adapters that let the device drivers apply A, B and ``factor`` to device
 """
 
 import threading
-import weakref
 
 import numpy as np
 from scipy import sparse
 from scipy.sparse.linalg import LinearOperator
 
-from .device import CSRMatrix, Factor, Symbolic, default_context
+from .device import CSRMatrix, Factor, default_context
 
 
 class SpLuOperator(LinearOperator):
@@ -82,9 +81,6 @@ class SpLuOperator(LinearOperator):
 
 
 # ---------------------------------------------------------------------------
-_csr_cache = weakref.WeakKeyDictionary()
-
-
 class DeviceOperator:
     """y = A x on device blocks for a scipy sparse matrix (device CSR) or a host LinearOperator."""
 
@@ -137,6 +133,3 @@ class FactorApply:
         Xout.set(alpha * out.reshape(Xin.n, Xin.k))
         return Xout
 
-
-def is_native_factor(factor):
-    return isinstance(factor, SpLuOperator)

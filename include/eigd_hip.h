@@ -114,7 +114,7 @@ int eigd_factor_solve_to(eigd_factor* f, const double* dIn, int ldin, double* dO
 int eigd_factor_lane_create(eigd_factor* f, eigd_ctx* ctx, eigd_lane** out);
 int eigd_factor_lane_free(eigd_lane* lane);
 int eigd_factor_lane_solve_to(eigd_lane* lane, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha);
-/* stats: [0]=nnz(L) [1]=device bytes held [2]=factor flops [3]=min pivot*1e300? (unused) */
+/* stats: [0]=nnz(L) [1]=device bytes held [2]=flops of the numeric factorisation [3]=number of fronts */
 int eigd_factor_stats(eigd_factor* f, double* out, int nout);
 /* bytes of L streamed by one k-column solve (algorithmic, for the roofline) */
 int eigd_factor_solve_bytes(eigd_factor* f, int k, double* bytes);
