@@ -123,14 +123,13 @@ def main():
     log(rank, f"G assembled ({timing['assemble_G_s']:.1f}s); BLF_1 ~ {blf_est:.4f}; shift sigma = {sigma:.4f}")
     t0 = time.perf_counter()
     while True:
-        try:
-            mat = (K + sigma * G).tocsr()
-            factor = eg.SpLuOperator(mat, ctx=ctx, symbolic=Kfac.symbolic if mat.nnz == K.nnz else None,
-                                     check_symmetry=False, coords=coords)
+        mat = (K + sigma * G).tocsr()
+        factor = eg.SpLuOperator(mat, ctx=ctx, symbolic=Kfac.symbolic if mat.nnz == K.nnz else None,
+                                 check_symmetry=False, coords=coords)
+        if factor.negative_pivots == 0:  # inertia: no buckling load below the shift
             break
-        except np.linalg.LinAlgError:
-            sigma *= 0.5
-            log(rank, f"shift not below BLF_1, retrying with sigma = {sigma:.4f}")
+        sigma *= 0.5
+        log(rank, f"shift not below BLF_1 ({factor.negative_pivots} negative pivots), retrying with sigma = {sigma:.4f}")
     ctx.sync()
     timing["factor_shifted_s"] = time.perf_counter() - t0
     fstats = factor.factor.stats()
@@ -298,8 +297,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "buckling 1M-dof Q4 column (706x706 elements), 32 modes, IRAM m=65 + sibk rtol=1e-10 "
-                               "+ tensor total derivative w.r.t. element densities",
+        "config": {"workload": f"buckling {n / 1e6:.1f}M-dof Q4 column ({args.nx}x{args.ny} elements), {N} modes, "
+                               f"IRAM m={args.m} + sibk rtol=1e-10 + tensor total derivative w.r.t. element densities",
                    "n_dof": int(n), "nnz": int(K.nnz), "modes": N, "m": args.m, "sigma": round(float(sigma), 6),
                    "ordering": args.ordering,
                    "parallelism": f"modes sharded over {world} GPU(s), one df/dx all-reduce"},

@@ -44,6 +44,7 @@ struct FrontArrays {
   const int64_t* bptr;
   const int* rel;
   const int* poff;  // first partial slab of the front's border products, -1 if it has a single tile group
+  double* sgn;      // +-1 per (permuted) column: A = L S L^T with S = diag(sgn); all +1 for a positive definite matrix
   int W;
   int BG;           // border tiles per group
 };
@@ -105,26 +106,32 @@ __global__ __launch_bounds__(kThreads) void potrf_inv_kernel(FrontArrays fa, con
     S[j * TLD + i] = (i >= j) ? Fd[static_cast<int64_t>(j) * d + i] : 0.0;
   }
   __syncthreads();
+  __shared__ double sg[TW];
   for (int j = 0; j < w; ++j) {
     if (tid == 0) {
       double p = S[j * TLD + j];
-      if (!(p > 0.0) || !(p < 1.0e300)) {
+      const double ap = fabs(p);
+      if (!(ap > 0.0) || !(ap < 1.0e300)) {  // zero / NaN / inf pivot: the matrix is singular to working precision
         atomicCAS(flag, 0, f + 1);
         p = 1.0;
       }
-      S[j * TLD + j] = sqrt(p);
+      if (p < 0.0) atomicAdd(flag + 1, 1);   // inertia: number of negative pivots
+      sg[j] = (p < 0.0) ? -1.0 : 1.0;
+      S[j * TLD + j] = sqrt(fabs(p));
     }
     __syncthreads();
-    const double dj = S[j * TLD + j];
+    const double dj = S[j * TLD + j] * sg[j];   // a_ij = l_ij * s_j * l_jj
     for (int i = j + 1 + tid; i < w; i += kThreads) S[j * TLD + i] /= dj;
     __syncthreads();
     const int m = w - j - 1;
+    const double sj = sg[j];
     for (int idx = tid; idx < m * m; idx += kThreads) {
       const int cc = idx / m, ii = idx - cc * m;
-      if (ii >= cc) S[(j + 1 + cc) * TLD + j + 1 + ii] -= S[j * TLD + j + 1 + ii] * S[j * TLD + j + 1 + cc];
+      if (ii >= cc) S[(j + 1 + cc) * TLD + j + 1 + ii] -= sj * S[j * TLD + j + 1 + ii] * S[j * TLD + j + 1 + cc];
     }
     __syncthreads();
   }
+  if (tid < w) fa.sgn[fa.c0[f] + j0 + tid] = sg[tid];
   // inverse of the lower triangular block, one column per lane
   if (tid < w) {
     const int c = tid;
@@ -187,11 +194,12 @@ __global__ __launch_bounds__(kThreads) void trsm_kernel(FrontArrays fa, const in
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[i][c] += a[i] * b[c];
   }
+  const double* sgp = fa.sgn + fa.c0[f] + j0;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (r0 + i < rows && c0 + c < w) Fp[static_cast<int64_t>(c0 + c) * d + r0 + i] = acc[i][c];
+      if (r0 + i < rows && c0 + c < w) Fp[static_cast<int64_t>(c0 + c) * d + r0 + i] = acc[i][c] * sgp[c0 + c];
 }
 
 // trailing update C(ti, tj) -= L21(ti) * L21(tj)^T on 64 x 64 tiles of the lower triangle
@@ -217,10 +225,11 @@ __global__ __launch_bounds__(kThreads) void syrk_kernel(FrontArrays fa, const in
   double* Fb = F + fa.foff[f];
   const double* Lp = Fb + static_cast<int64_t>(j0) * d;  // panel columns
   const int tid = threadIdx.x;
+  const double* sgp = fa.sgn + fa.c0[f] + j0;
   for (int idx = tid; idx < TW * TW; idx += kThreads) {
     const int k = idx / TW, r = idx - k * TW;
     As[k * TLD + r] = (k < w && r < rows_i) ? Lp[static_cast<int64_t>(k) * d + Ri + r] : 0.0;
-    Bs[k * TLD + r] = (k < w && r < rows_j) ? Lp[static_cast<int64_t>(k) * d + Rj + r] : 0.0;
+    Bs[k * TLD + r] = (k < w && r < rows_j) ? sgp[k] * Lp[static_cast<int64_t>(k) * d + Rj + r] : 0.0;  // S folded in
   }
   __syncthreads();
   const int i0 = (tid % 16) * 4, jj0 = (tid / 16) * 4;
@@ -474,12 +483,13 @@ __global__ __launch_bounds__(kThreads) void fwd_step_kernel(FrontArrays fa, Step
   T::template mac<false>(As, Bs, w, acc);
   __syncthreads();
   double* Yf = Y + (fa.voff[f] + j0) * kb;
+  const double* sgp = fa.sgn + fa.c0[f] + j0;
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) {
     int o, c;
     T::coords(t, o, c);
     Bs[o * T::BLD + c] = (o < w) ? acc[t] : 0.0;
-    if (chunk == 0 && o < w && c < kb) Yf[static_cast<int64_t>(o) * kb + c] = acc[t];
+    if (chunk == 0 && o < w && c < kb) Yf[static_cast<int64_t>(o) * kb + c] = sgp[o] * acc[t];  // L^T x = S z
   }
   if (nch == 0) return;
   const int row0 = j1 + chunk * TW;
@@ -677,7 +687,8 @@ struct eigd_factor {
   double* d_P = nullptr;
   int64_t *d_a_src = nullptr, *d_a_dst = nullptr;
   int* d_v_src = nullptr;
-  double *d_data = nullptr, *d_F = nullptr, *d_Inv = nullptr, *d_V = nullptr, *d_Y = nullptr;
+  double *d_data = nullptr, *d_F = nullptr, *d_Inv = nullptr, *d_V = nullptr, *d_Y = nullptr, *d_sgn = nullptr;
+  int n_negative = 0;
   int* d_flag = nullptr;
   size_t bytes = 0;
   std::vector<int> ea_split;  // per (level, slot): grid.y of the extend-add launches
@@ -695,6 +706,7 @@ struct eigd_factor {
     a.bptr = d_bptr;
     a.rel = d_rel;
     a.poff = d_poff;
+    a.sgn = d_sgn;
     a.W = sym->W;
     a.BG = sym->BG;
     return a;
@@ -717,7 +729,7 @@ int numeric(eigd_factor* f, const double* hdata) {
   hipStream_t st = f->ctx->stream;
   EIGD_HIP(hipMemcpyAsync(f->d_data, hdata, sizeof(double) * f->data_len, hipMemcpyHostToDevice, st));
   EIGD_HIP(hipMemsetAsync(f->d_F, 0, sizeof(double) * s.front_doubles, st));
-  EIGD_HIP(hipMemsetAsync(f->d_flag, 0, sizeof(int), st));
+  EIGD_HIP(hipMemsetAsync(f->d_flag, 0, 2 * sizeof(int), st));
   {
     const int nb = static_cast<int>(std::min<int64_t>((s.nlower + 255) / 256, 65536));
     hipLaunchKernelGGL(scatter_a_kernel, dim3(std::max(nb, 1)), dim3(256), 0, st, s.nlower, f->d_a_src, f->d_a_dst,
@@ -754,13 +766,14 @@ int numeric(eigd_factor* f, const double* hdata) {
       }
     }
   }
-  int flag = 0;
-  EIGD_HIP(hipMemcpyAsync(&flag, f->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  int flag[2] = {0, 0};
+  EIGD_HIP(hipMemcpyAsync(flag, f->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   EIGD_HIP(hipStreamSynchronize(st));
-  if (flag != 0) {
-    set_error("matrix is not positive definite (non-positive pivot in front %d): the shift must lie below the "
-              "lowest eigenvalue",
-              flag - 1);
+  f->n_negative = flag[1];
+  if (flag[0] != 0) {
+    set_error("zero or non-finite pivot in front %d: the (shifted) matrix is singular to working precision -- move the "
+              "shift away from an eigenvalue",
+              flag[0] - 1);
     return EIGD_E_NOTSPD;
   }
   return EIGD_OK;
@@ -932,7 +945,7 @@ int eigd_factor_free(eigd_factor* f) {
                   f->d_voff,      f->d_ioff,        f->d_bptr,       f->d_lvl_fronts, f->d_pref_chunks,
                   f->d_pref_tiles, f->d_cs_child,   f->d_a_src,      f->d_a_dst,    f->d_v_src, f->d_data,
                   f->d_F,         f->d_Inv,         f->d_V,          f->d_Y,        f->d_flag,  f->d_pref_work,
-                  f->d_pref_panels, f->d_pref_bwork, f->d_poff,     f->d_P};
+                  f->d_pref_panels, f->d_pref_bwork, f->d_poff,     f->d_P,      f->d_sgn};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;
@@ -999,9 +1012,10 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   rc = dmalloc(&f->d_Inv, s.inv_doubles);
   rc = dmalloc(&f->d_V, static_cast<size_t>(s.sumd) * KBMAX);
   rc = dmalloc(&f->d_Y, static_cast<size_t>(s.sumd) * KBMAX);
+  rc = dmalloc(&f->d_sgn, static_cast<size_t>(s.n));
   rc = dmalloc(&f->d_P, static_cast<size_t>(std::max<int64_t>(s.nslabs, 1)) * TW * KBMAX);
   if (rc == EIGD_OK) {
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_flag), sizeof(int));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_flag), 2 * sizeof(int));
     if (e != hipSuccess) {
       set_error("hipMalloc failed: %s", hipGetErrorString(e));
       rc = EIGD_E_HIP;
@@ -1110,9 +1124,9 @@ int eigd_factor_lane_solve_to(eigd_lane* l, const double* dIn, int ldin, double*
 
 int eigd_factor_stats(eigd_factor* f, double* out, int nout) {
   EIGD_REQUIRE(f && out && nout >= 1, "null argument");
-  const double v[4] = {static_cast<double>(f->sym->nnzL), static_cast<double>(f->bytes), f->sym->flops,
-                       static_cast<double>(f->sym->nfronts)};
-  for (int i = 0; i < nout && i < 4; ++i) out[i] = v[i];
+  const double v[5] = {static_cast<double>(f->sym->nnzL), static_cast<double>(f->bytes), f->sym->flops,
+                       static_cast<double>(f->sym->nfronts), static_cast<double>(f->n_negative)};
+  for (int i = 0; i < nout && i < 5; ++i) out[i] = v[i];
   return EIGD_OK;
 }
 

@@ -532,9 +532,10 @@ class Factor:
         return lanes[key][0]
 
     def stats(self):
-        out = np.zeros(4)
-        call("eigd_factor_stats", self.h, hptr(out), 4)
-        return {"nnzL": int(out[0]), "device_bytes": int(out[1]), "flops": float(out[2]), "nfronts": int(out[3])}
+        out = np.zeros(5)
+        call("eigd_factor_stats", self.h, hptr(out), 5)
+        return {"nnzL": int(out[0]), "device_bytes": int(out[1]), "flops": float(out[2]), "nfronts": int(out[3]),
+                "negative_pivots": int(out[4])}
 
     def solve_bytes(self, k):
         b = C.c_double()

@@ -17,10 +17,13 @@ class SpLuOperator(LinearOperator):
     Shift-invert operator ``x -> mat^{-1} x`` factored and applied on the MI355X.
 
     Same surface as the reference class (``shape``, ``dtype``, ``count``, callable on
-    ``(n,)`` and ``(n, k)`` numpy arrays).  ``mat`` must be symmetric positive definite,
-    which is what every shift of the reference's examples produces (K - sigma M with sigma
-    below the spectrum, K + sigma G with sigma below the first buckling load); an indefinite
-    matrix raises ``NotPositiveDefiniteError`` (a ``numpy.linalg.LinAlgError``).
+    ``(n,)`` and ``(n, k)`` numpy arrays).  ``mat`` must be symmetric.  The factorisation is
+    ``P mat P^T = L S L^T`` with ``S = diag(+-1)``: plain Cholesky for the positive definite
+    shifts of the reference's examples (K - sigma M below the spectrum, K + sigma G below the
+    first buckling load), a sign-tracked LDL^T without pivoting for a shift inside the spectrum
+    (``negative_pivots`` = number of eigenvalues of the pencil below the shift); in that case every
+    application is followed by one step of iterative refinement.  A zero / non-finite pivot raises
+    ``NotPositiveDefiniteError`` (a ``numpy.linalg.LinAlgError``): the shift sits on an eigenvalue.
     """
 
     def __init__(self, mat, ctx=None, symbolic=None, leaf_size=0, panel_width=0, check_symmetry=True, coords=None):
@@ -46,6 +49,17 @@ class SpLuOperator(LinearOperator):
         self.factor = Factor(self.ctx, csr, symbolic=symbolic, leaf_size=leaf_size, panel_width=panel_width,
                              coords=coords)
         self.symbolic = self.factor.symbolic
+        self.negative_pivots = self.factor.stats()["negative_pivots"]
+        # indefinite: LDL^T without pivoting is only conditionally stable -> one refinement step per application
+        self._mat_dev = CSRMatrix(self.ctx, csr) if self.negative_pivots > 0 else None
+
+    def _refine(self, B, X, alpha):
+        """X <- X + alpha * mat^{-1} (B - mat X / alpha) ... one step of iterative refinement on device blocks"""
+        R = self._mat_dev.apply(X)                       # mat X   (X = alpha * approx(mat^{-1} B))
+        R.assign_lincomb([(alpha, B), (-1.0, R)])        # alpha B - mat X
+        self.factor.solve_inplace(R, 1.0)
+        X.assign_lincomb([(1.0, X), (1.0, R)])
+        return X
 
     # -- device path (used by the drivers) ------------------------------------
     def solve_device(self, X, alpha=1.0, count=None):
@@ -56,17 +70,28 @@ class SpLuOperator(LinearOperator):
         """
         with self._count_lock:
             self.count += X.k if count is None else int(count)
-        return self.factor.solve_inplace(X, alpha)
+        if self._mat_dev is None:
+            return self.factor.solve_inplace(X, alpha)
+        B = X.copy()
+        self.factor.solve_inplace(X, alpha)
+        return self._refine(B, X, alpha)
 
     def solve_device_to(self, Xin, Xout, alpha=1.0, count=None):
         """Xout <- alpha * mat^{-1} Xin on device blocks, Xin untouched"""
         with self._count_lock:
             self.count += Xin.k if count is None else int(count)
-        return self.factor.solve_to(Xin, Xout, alpha)
+        self.factor.solve_to(Xin, Xout, alpha)
+        if self._mat_dev is not None:
+            self._refine(Xin, Xout, alpha)
+        return Xout
 
     def refactor(self, mat):
         """numeric refactorisation with new values on the same sparsity pattern"""
-        self.factor.refactor(mat.tocsr().astype(np.float64))
+        csr = mat.tocsr().astype(np.float64)
+        csr.sort_indices()
+        self.factor.refactor(csr)
+        self.negative_pivots = self.factor.stats()["negative_pivots"]
+        self._mat_dev = CSRMatrix(self.ctx, csr) if self.negative_pivots > 0 else None
 
     # -- host path (reference call surface) ------------------------------------
     def _matvec(self, x):

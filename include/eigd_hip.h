@@ -34,7 +34,7 @@ extern "C" {
 #define EIGD_OK 0
 #define EIGD_E_INVALID (-1)  /* bad argument / shape mismatch            */
 #define EIGD_E_HIP (-2)      /* HIP runtime error (no device, OOM, ...)  */
-#define EIGD_E_NOTSPD (-3)   /* shifted matrix not positive definite     */
+#define EIGD_E_NOTSPD (-3)   /* zero / non-finite pivot: singular shift  */
 #define EIGD_E_INTERNAL (-4) /* violated internal invariant              */
 
 typedef struct eigd_ctx eigd_ctx;
@@ -114,7 +114,8 @@ int eigd_factor_solve_to(eigd_factor* f, const double* dIn, int ldin, double* dO
 int eigd_factor_lane_create(eigd_factor* f, eigd_ctx* ctx, eigd_lane** out);
 int eigd_factor_lane_free(eigd_lane* lane);
 int eigd_factor_lane_solve_to(eigd_lane* lane, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha);
-/* stats: [0]=nnz(L) [1]=device bytes held [2]=flops of the numeric factorisation [3]=number of fronts */
+/* stats: [0]=nnz(L) [1]=device bytes held [2]=flops of the numeric factorisation [3]=number of fronts
+          [4]=negative pivots of P M P^T = L S L^T (inertia: eigenvalues of the pencil below the shift; 0 = SPD) */
 int eigd_factor_stats(eigd_factor* f, double* out, int nout);
 /* bytes of L streamed by one k-column solve (algorithmic, for the roofline) */
 int eigd_factor_solve_bytes(eigd_factor* f, int k, double* bytes);

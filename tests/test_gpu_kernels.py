@@ -194,14 +194,32 @@ def test_factor_column_independence_and_refactor(ctx):
     assert np.linalg.norm(A2 @ X - B) / np.linalg.norm(B) < 1e-12
 
 
-def test_factor_rejects_indefinite(ctx):
+def test_indefinite_shift_ldlt_and_singular_matrix(ctx):
+    """a shift inside the spectrum: sign-tracked LDL^T, inertia = eigenvalues below the shift, SuperLU-level accuracy"""
+    import eigd_amd as eg
     from eigd_amd._ffi import NotPositiveDefiniteError
     from eigd_amd.device import Factor
 
-    A = grid_matrix(20, 20, 1, seed=1)
-    Aind = (A - sparse.identity(A.shape[0]) * 100.0).tocsr()
+    A = grid_matrix(14, 13, 1, seed=1)
+    ev = np.linalg.eigvalsh(A.toarray())
+    shift = 0.5 * (ev[6] + ev[7])                      # 7 eigenvalues below the shift
+    Aind = (A - sparse.identity(A.shape[0]) * shift).tocsr()
+    F = Factor(ctx, Aind, leaf_size=8, panel_width=8)
+    assert F.stats()["negative_pivots"] == 7
+    rng = np.random.default_rng(0)
+    B = rng.normal(size=(A.shape[0], 5))
+    X = F.solve_inplace(ctx.from_host(B)).get()
+    assert relerr(X, splu(Aind.tocsc()).solve(B)) < 1e-9
+    # larger problem through the operator (one refinement step per application)
+    A2 = grid_matrix(60, 50, 2, seed=3)
+    A2i = (A2 - sparse.identity(A2.shape[0]) * A2.diagonal().mean()).tocsr()  # shift in the middle of the spectrum
+    op = eg.SpLuOperator(A2i.tocsc())
+    assert op.negative_pivots > 0
+    B2 = rng.normal(size=(A2.shape[0], 3))
+    X2 = op(B2)
+    assert np.linalg.norm(A2i @ X2 - B2) / np.linalg.norm(B2) < 1e-11
     with pytest.raises(NotPositiveDefiniteError):
-        Factor(ctx, Aind)
+        Factor(ctx, sparse.kron(sparse.identity(20), np.ones((2, 2))).tocsr())  # exactly singular: zero pivot
 
 
 def test_fem_like_ill_conditioned_factor(ctx):

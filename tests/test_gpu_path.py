@@ -671,3 +671,22 @@ def test_concurrent_mode_groups_on_streams_match_single_stream():
     assert index_sets(data3) == index_sets(data1)
     assert fac.count == c1 and len(hist3) == len(hist1)
     assert np.allclose(hist3, hist1, rtol=1e-6, atol=1e-14)
+
+
+def test_interior_shift_finds_eigenvalues_on_both_sides():
+    """shift-invert around an interior shift (indefinite factor): the Ritz values nearest to sigma, residual-checked"""
+    import eigd_amd as eg
+
+    g = load_golden("g4_laplace900_basiclanczos")
+    K, M = csr_from(g, "K"), csr_from(g, "M")
+    lam_ref = g["normal_lam"]
+    sigma = 0.5 * (lam_ref[2] + lam_ref[3])
+    fac = eg.SpLuOperator((K - sigma * M).tocsc())
+    assert fac.negative_pivots == 3
+    s = eg.BasicLanczos(N=4, m=60, tol=1e-12)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lam, Phi = s.solve(K, M, fac, sigma)
+    R = K @ Phi - (M @ Phi) * lam
+    assert np.linalg.norm(R, axis=0).max() < 1e-8
+    assert np.all(np.isin(np.round(lam, 8), np.round(lam_ref, 8)))
