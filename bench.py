@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--ordering", choices=("geometric", "algebraic"), default="geometric",
                     help="nested dissection with the mesh coordinates as a hint, or purely from the matrix graph")
     ap.add_argument("--pyprofile", default=None, help="write a cProfile summary of one extra step to this file")
+    ap.add_argument("--trace", default=None, help="write the per-iteration host timeline of one extra step to this file")
     ap.add_argument("--no-fd-check", action="store_true", help="skip the directional finite-difference check of df/dx")
     args = ap.parse_args()
 
@@ -188,6 +189,29 @@ def main():
 
     if rank != 0:
         return
+    if args.trace:
+        import eigd_amd.adjoint as adj
+
+        events, orig = [], adj._active_range
+
+        def traced(done):
+            r = orig(done)
+            events.append((time.perf_counter(), r[0], r[1], int(np.count_nonzero(~done))))
+            return r
+
+        adj._active_range = traced
+        ctx.sync()
+        t_begin = time.perf_counter()
+        step()
+        ctx.sync()
+        t_end = time.perf_counter()
+        adj._active_range = orig
+        with open(args.trace, "w") as fh:
+            prev = t_begin
+            for it, (t, lo, hi, live) in enumerate(events):
+                fh.write(f"iter {it:3d}  +{1e3 * (t - prev):7.3f} ms  range [{lo:2d},{hi:2d})  live {live}\n")
+                prev = t
+            fh.write(f"tail (psi update, correction, derivative) {1e3 * (t_end - prev):.3f} ms; total {1e3 * (t_end - t_begin):.3f} ms\n")
     if args.pyprofile:
         import cProfile
         import pstats

@@ -10,9 +10,11 @@
 //             bottom-up, all fronts of a level batched in the same launches.  Per panel
 //             step of W columns: potrf (+ explicit inverse of the W x W diagonal block),
 //             trsm as a product with that inverse, trailing update tile by tile.
-//   solve   : the same (level, step) schedule.  Each front owns a d x k slice of a vector
-//             workspace; forward substitution passes border contributions child -> parent
-//             (extend-add of vectors), backward substitution pulls them parent -> child.
+//   inverses: T = inv(L11) and M21 = L21 inv(L11) per front (two launches over all fronts).
+//   solve   : ONE launch per level of the assembly tree and direction.  Each front owns a d x k
+//             slice of a vector workspace; the forward sweep multiplies by [T; M21] and passes
+//             border carries child -> parent (gathered by the parent, fixed order), the
+//             backward sweep multiplies by the transpose and pulls x parent -> child.
 //             No atomics anywhere: the sweeps are bitwise reproducible.
 //
 // Per solve the kernels stream nnz(L) doubles twice (forward + backward) plus
@@ -43,11 +45,16 @@ struct FrontArrays {
   const int64_t* ioff;
   const int64_t* bptr;
   const int* rel;
-  const int* poff;  // first partial slab of the front's border products, -1 if it has a single tile group
-  double* sgn;      // +-1 per (permuted) column: A = L S L^T with S = diag(sgn); all +1 for a positive definite matrix
-  int W;
-  int BG;           // border tiles per group
+  const int64_t* toff;  // offset of the front's inverted triangle T = inv(L11) (ns x ns, column-major)
+  const int* gsrc;      // kGS rows of V per row of V: the children's carries that add into it (forward sweep), -1 = none
+  const int* v_src;     // per row of V: the row of the caller's block it holds (own rows), -1 for border rows
+  double* sgn;          // +-1 per (permuted) column: A = L S L^T with S = diag(sgn); all +1 for a positive definite matrix
+  const double* zero;   // one 0.0 and ...
+  const int* neg1;      // ... one -1 in device memory: masked-off lanes of the sweeps load from here (address select)
+  int W;                // instead of branching around the load, which would serialise the loads of a tile
 };
+
+constexpr int kGS = 3;  // gather slots per row of V
 
 __device__ __forceinline__ int find_slot(const int* __restrict__ pref, int na, int idx) {
   int lo = 0, hi = na;
@@ -258,59 +265,174 @@ __global__ __launch_bounds__(kThreads) void syrk_kernel(FrontArrays fa, const in
     }
 }
 
+
+// ------------------------------------------------------------------ explicit inverses
+// The sweeps never substitute: after the numeric factorisation every front's triangle is inverted,
+//   T   = inv(L11)            (dense lower triangular ns x ns, column-major, own buffer)
+//   M21 = L21 * inv(L11)      (bs x ns, overwrites L21 inside the front)
+// so that a front's share of a sweep is ONE product with [T; M21] (forward) or its transpose (backward):
+// one launch per level of the assembly tree and direction instead of one per 64-column panel.  The
+// diagonal blocks of an FE separator are well conditioned (cond(L11) ~ 1e1..1e2 at the 1M-dof benchmark),
+// the residuals match the substitution form to the last digits.
+
+// T, column block j of one front per workgroup (blocks of the panel width W); rows top-down:
+//   X_jj = inv(L_jj) (from the factorisation),  X_ij = -inv(L_ii) * sum_{k=j}^{i-1} L_ik X_kj
+__global__ __launch_bounds__(kThreads) void trinv_kernel(FrontArrays fa, const int* __restrict__ tri_pref, int nfronts,
+                                                        const double* __restrict__ F, const double* __restrict__ Inv,
+                                                        double* Tb) {
+  __shared__ double As[TW * TLD];
+  __shared__ double Bs[TW * TLD];
+  const int f = find_slot(tri_pref, nfronts, blockIdx.x);
+  const int j = blockIdx.x - tri_pref[f];
+  const int W = fa.W;
+  const int ns = fa.ns[f];
+  const int64_t d = ns + fa.bs[f];
+  const int nb = (ns + W - 1) / W;
+  const int j0 = j * W, wj = min(W, ns - j0);
+  const double* Ff = F + fa.foff[f];
+  const double* If = Inv + fa.ioff[f];
+  double* Tf = Tb + fa.toff[f];
+  const int tid = threadIdx.x;
+  const int r0 = (tid % 16) * 4, c0 = (tid / 16) * 4;
+  for (int idx = tid; idx < W * W; idx += kThreads) {
+    const int c = idx / W, i = idx - c * W;
+    if (i < wj && c < wj)
+      Tf[static_cast<int64_t>(j0 + c) * ns + j0 + i] = (i >= c) ? If[static_cast<int64_t>(j) * W * W + c * W + i] : 0.0;
+  }
+  __threadfence();
+  __syncthreads();
+  for (int i = j + 1; i < nb; ++i) {
+    const int i0 = i * W, wi = min(W, ns - i0);
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k = j; k < i; ++k) {
+      const int k0 = k * W;  // full block: k < nb - 1
+      for (int idx = tid; idx < W * TW; idx += kThreads) {
+        const int kk = idx / TW, r = idx - kk * TW;
+        As[kk * TLD + r] = (r < wi) ? Ff[static_cast<int64_t>(k0 + kk) * d + i0 + r] : 0.0;        // L(i0 + r, k0 + kk)
+      }
+      for (int idx = tid; idx < W * TW; idx += kThreads) {
+        const int c = idx / W, kk = idx - c * W;
+        Bs[kk * TLD + c] = (c < wj) ? Tf[static_cast<int64_t>(j0 + c) * ns + k0 + kk] : 0.0;       // X(k0 + kk, j0 + c)
+      }
+      __syncthreads();
+      for (int kk = 0; kk < W; ++kk) {
+        double a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = As[kk * TLD + r0 + q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = Bs[kk * TLD + c0 + q];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Bs[(r0 + p) * TLD + c0 + q] = acc[p][q];
+    for (int idx = tid; idx < W * TW; idx += kThreads) {
+      const int kk = idx / TW, r = idx - kk * TW;
+      As[kk * TLD + r] = (kk < wi && r < wi && r >= kk) ? If[static_cast<int64_t>(i) * W * W + kk * W + r] : 0.0;  // inv(L_ii)(r, kk)
+    }
+    __syncthreads();
+    double out[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[p][q] = 0.0;
+    for (int kk = 0; kk < wi; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] = As[kk * TLD + r0 + q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[q] = Bs[kk * TLD + c0 + q];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[p][q] += a[p] * b[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (r0 + p < wi && c0 + q < wj) Tf[static_cast<int64_t>(j0 + c0 + q) * ns + i0 + r0 + p] = -out[p][q];
+    __threadfence();  // the next block row reads these entries back through global memory
+    __syncthreads();
+  }
+}
+
+// M21 = L21 * T in place, one 64-row tile of the border per workgroup, 64-column blocks left to right
+// (block jt of the result needs blocks kt >= jt of L21 only, so overwriting block jt is safe).
+__global__ __launch_bounds__(kThreads) void m21_kernel(FrontArrays fa, const int* __restrict__ m_pref, int nfronts,
+                                                      double* F, const double* __restrict__ Tb) {
+  __shared__ double As[TW * TLD];
+  __shared__ double Bs[TW * TLD];
+  const int f = find_slot(m_pref, nfronts, blockIdx.x);
+  const int bt = blockIdx.x - m_pref[f];
+  const int ns = fa.ns[f];
+  const int64_t d = ns + fa.bs[f];
+  const int rb0 = ns + bt * TW;
+  const int rows = min(TW, static_cast<int>(d) - rb0);
+  const int nct = (ns + TW - 1) / TW;
+  double* Ff = F + fa.foff[f];
+  const double* Tf = Tb + fa.toff[f];
+  const int tid = threadIdx.x;
+  const int r0 = (tid % 16) * 4, c0 = (tid / 16) * 4;
+  for (int jt = 0; jt < nct; ++jt) {
+    const int j0 = jt * TW, wj = min(TW, ns - j0);
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int kt = jt; kt < nct; ++kt) {
+      const int k0 = kt * TW, wk = min(TW, ns - k0);
+      for (int idx = tid; idx < TW * TW; idx += kThreads) {
+        const int kk = idx / TW, r = idx - kk * TW;
+        As[kk * TLD + r] = (kk < wk && r < rows) ? Ff[static_cast<int64_t>(k0 + kk) * d + rb0 + r] : 0.0;   // L21(r, k0 + kk)
+      }
+      for (int idx = tid; idx < TW * TW; idx += kThreads) {
+        const int c = idx / TW, kk = idx - c * TW;
+        Bs[kk * TLD + c] = (kk < wk && c < wj) ? Tf[static_cast<int64_t>(j0 + c) * ns + k0 + kk] : 0.0;      // T(k0 + kk, j0 + c)
+      }
+      __syncthreads();
+      for (int kk = 0; kk < wk; ++kk) {
+        double a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = As[kk * TLD + r0 + q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = Bs[kk * TLD + c0 + q];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (r0 + p < rows && c0 + q < wj) Ff[static_cast<int64_t>(j0 + c0 + q) * d + rb0 + r0 + p] = acc[p][q];
+  }
+}
+
 // ------------------------------------------------------------------ triangular sweeps
-__global__ void solve_init_kernel(int64_t sumd, int kb, const int* __restrict__ v_src, const double* __restrict__ X,
-                                  int ldx, double alpha, double* __restrict__ V) {
-  const int64_t total = sumd * kb;
-  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
-       idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const int64_t q = idx / kb;
-    const int c = static_cast<int>(idx - q * kb);
-    const int src = v_src[q];
-    V[idx] = (src >= 0) ? alpha * X[static_cast<int64_t>(src) * ldx + c] : 0.0;
-  }
-}
-
-__global__ void solve_out_kernel(int64_t sumd, int kb, const int* __restrict__ v_src, const double* __restrict__ V,
-                                 double* __restrict__ X, int ldx) {
-  const int64_t total = sumd * kb;
-  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
-       idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const int64_t q = idx / kb;
-    const int c = static_cast<int>(idx - q * kb);
-    const int src = v_src[q];
-    if (src >= 0) X[static_cast<int64_t>(src) * ldx + c] = V[idx];
-  }
-}
-
-// forward: border part of each child's vector added into its parent's vector
-__global__ __launch_bounds__(kThreads) void vec_extend_add_kernel(FrontArrays fa, const int* __restrict__ children,
-                                                                 int kb, double* __restrict__ V) {
-  const int c = children[blockIdx.x];
-  const int p = fa.parent[c];
-  const int ns = fa.ns[c], bs = fa.bs[c];
-  const int* __restrict__ rel = fa.rel + fa.bptr[c];
-  const double* __restrict__ Vc = V + (fa.voff[c] + ns) * kb;
-  double* Vp = V + fa.voff[p] * kb;
-  const int total = bs * kb;
-  for (int idx = blockIdx.y * kThreads + threadIdx.x; idx < total; idx += gridDim.y * kThreads) {
-    const int i = idx / kb, col = idx - i * kb;
-    Vp[static_cast<int64_t>(rel[i]) * kb + col] += Vc[idx];
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Tile products of the sweeps.  A workgroup produces a 64 x KB block of outputs (KB = 4*KPT >= k)
-// from a 64 x 64 tile As of the factor and a 64 x KB block Bs of right-hand sides, both in LDS:
-//   TRANS == false : out[o][c] += sum_k As[k*TLD + o] * Bs[k*BLD + c]
-//   TRANS == true  : out[o][c] += sum_k As[o*TLD + k] * Bs[k*BLD + c]
+// Tile products.  A workgroup produces a 64 x KB block of outputs (KB = 4*KPT >= k) from a 64 x 64 tile As
+// of [T; M21] and a 64 x KB block Bs of right-hand sides, both in LDS:
+//   out[o][c] += sum_k As[k*TLD + o] * Bs[k*BLD + c]
 //
 //  * k <= 8  (KPT 1, 2): vector FMAs, lane (o = tid/4, cg = tid%4) owns KPT columns of row o.
 //  * k > 8   (KPT 4, 8): v_mfma_f64_16x16x4_f64.  Wave w owns output rows 16w..16w+15 and all KB/16
 //    column tiles; per K-step of 4 a lane feeds ONE double of A and one of B per tile, so the LDS
 //    traffic per flop is ~9x lower than the vector form (which is LDS-bound at KB = 32).  Result map of
 //    the f64 MFMA: acc[reg] <-> (row = (lane>>4) + 4*reg, col = lane&15) inside the 16 x 16 tile.
-// ---------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 template <int KPT>
@@ -332,7 +454,6 @@ struct Tile {
     }
   }
 
-  template <bool TRANS>
   __device__ static __forceinline__ void mac(const double* __restrict__ As, const double* __restrict__ Bs, int kdim,
                                              double (&acc)[NOUT]) {
     if constexpr (kMfma) {
@@ -347,7 +468,7 @@ struct Tile {
 #pragma unroll
         for (int kk = 0; kk < 8; kk += 4) {
           const int k = k0 + kk + lk;
-          const double a = TRANS ? As[o * TLD + k] : As[k * TLD + o];
+          const double a = As[k * TLD + o];
 #pragma unroll
           for (int n = 0; n < NT; ++n)
             c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[k * BLD + 16 * n + li], c[n], 0, 0, 0);
@@ -364,7 +485,7 @@ struct Tile {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
           const int k = k0 + kk;
-          const double a = TRANS ? As[o * TLD + k] : As[k * TLD + o];
+          const double a = As[k * TLD + o];
           const double* b = Bs + k * BLD + cg * KPT;
 #pragma unroll
           for (int q = 0; q < KPT; ++q) acc[q] += a * b[q];
@@ -374,300 +495,257 @@ struct Tile {
   }
 };
 
-struct StepArgs {
-  const int* fronts;       // active fronts of this (level, step), npanels descending
-  const int* pref_chunks;  // na + 1 : row chunks below the panel
-  const int* pref_work;    // na + 1 : max(1, chunks)
-  int na;
-  int step;
+struct LevelArgs {
+  const int2* wg;  // per workgroup of the level: (front, tile); fronts largest first
   int kb;
 };
 
-// Tile loaders.  All global loads of a tile are issued before the first LDS store (register
-// staging, fully unrolled): a 64 x 64 tile costs one memory latency, not sixteen.
-constexpr int TILE_IT = TW * TW / kThreads;  // 16 elements per lane
+constexpr int TILE_IT = TW * TW / kThreads;  // 16 matrix elements per lane and tile
 
-// As[j*TLD + r] = L(row0 + r, j0 + j), zero padded to 64 x 64
-__device__ __forceinline__ void load_panel_chunk(double* As, const double* __restrict__ Lp, int64_t d, int w, int row0,
-                                                 int rows) {
-  double tmp[TILE_IT];
-  const int r = threadIdx.x & (TW - 1), jb = threadIdx.x >> 6;  // lane -> (row, first column); columns step by 4
-#pragma unroll
-  for (int it = 0; it < TILE_IT; ++it) {
-    const int j = jb + it * (kThreads / TW);
-    tmp[it] = (j < w && r < rows) ? Lp[static_cast<int64_t>(j) * d + row0 + r] : 0.0;
-  }
-#pragma unroll
-  for (int it = 0; it < TILE_IT; ++it) As[(jb + it * (kThreads / TW)) * TLD + r] = tmp[it];
+// rows of the forward carry with more than kGS - 1 ... contributors: the surplus children are summed into an
+// extra row first (fixed order), which the last gather slot of the destination row then points to
+__global__ void overflow_sum_kernel(int nrows, const int* __restrict__ ov_ptr, const int* __restrict__ ov_src,
+                                    int64_t first_row, int kb, double* V) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nrows * kb) return;
+  const int x = idx / kb, c = idx - x * kb;
+  double s = 0.0;
+  for (int e = ov_ptr[x]; e < ov_ptr[x + 1]; ++e) s += V[static_cast<int64_t>(ov_src[e]) * kb + c];
+  V[(first_row + x) * kb + c] = s;
 }
 
-// As[r*TLD + c] = M(r, c) for a tile stored with element (r, c) at c*ld + r (rows contiguous), zero padded
-__device__ __forceinline__ void load_tile_transposed(double* As, const double* __restrict__ M, int64_t ld, int nrows,
-                                                     int ncols) {
-  double tmp[TILE_IT];
-  const int r = threadIdx.x & (TW - 1), cb = threadIdx.x >> 6;
-#pragma unroll
-  for (int it = 0; it < TILE_IT; ++it) {
-    const int c = cb + it * (kThreads / TW);
-    tmp[it] = (c < ncols && r < nrows) ? M[static_cast<int64_t>(c) * ld + r] : 0.0;
-  }
-#pragma unroll
-  for (int it = 0; it < TILE_IT; ++it) As[r * TLD + cb + it * (kThreads / TW)] = tmp[it];
-}
-
-// As[j*TLD + i] = inv(i, j) of the step's diagonal block, zero padded
-__device__ __forceinline__ void load_inverse(double* As, const double* __restrict__ Ig, int W, int w) {
-  double tmp[TILE_IT];
-  const int i = threadIdx.x & (TW - 1), jb = threadIdx.x >> 6;
-#pragma unroll
-  for (int it = 0; it < TILE_IT; ++it) {
-    const int j = jb + it * (kThreads / TW);
-    tmp[it] = (j < w && i < w && i >= j) ? Ig[j * W + i] : 0.0;  // lower triangular: the zero half is not fetched
-  }
-#pragma unroll
-  for (int it = 0; it < TILE_IT; ++it) As[(jb + it * (kThreads / TW)) * TLD + i] = tmp[it];
-}
-
-// Bs[r*BLD + c] = Vrows[rowmap(r)*kb + c] (r < rows), zero padded to 64 x KB; rel == nullptr: rowmap(r) = r.
-// Optionally mirrored into Vdst[r*kb + c].
+// Forward sweep, one level: workgroup (front f, row tile rt) forms
+//   rt <  ns/64 : z(rt)   =  sum_{ct <= rt} T(rt, ct)  v1(ct)            -> Y = S z  (right-hand side of L^T x = S z)
+//   rt >= ns/64 : carry   =  children's carries - sum_ct M21(rt, ct) v1(ct)  -> border rows of the front's V slice
+// with v1 = alpha * X[own rows] + the children's carries on the front's own rows, gathered on the fly through
+// gsrc (kGS source rows per row of V, -1 = none; fixed summation order, no atomics).  Matrix tiles and vector
+// blocks are register staged one tile ahead (the gather indices two tiles ahead), so the loads of step t+1 are
+// in flight while step t multiplies.
 template <int KPT>
-__device__ __forceinline__ void load_vec_rows(double* Bs, const double* Vsrc, const int* __restrict__ rel, int kb,
-                                              int rows, double* Vdst) {
+__global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
+                                                            const double* __restrict__ Tb, const double* X, int ldx,
+                                                            double alpha, double* V, double* __restrict__ Y) {
   using T = Tile<KPT>;
-  constexpr int IT = TW * T::KB / kThreads;  // KPT elements per lane
-  double tmp[IT];
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
-    const int idx = threadIdx.x + it * kThreads;
-    const int r = idx / T::KB, c = idx - r * T::KB;
-    const int64_t src = (rel != nullptr && r < rows) ? rel[r] : r;
-    tmp[it] = (r < rows && c < kb) ? Vsrc[src * kb + c] : 0.0;
-  }
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
-    const int idx = threadIdx.x + it * kThreads;
-    const int r = idx / T::KB, c = idx - r * T::KB;
-    Bs[r * T::BLD + c] = tmp[it];
-    if (Vdst != nullptr && r < rows && c < kb) Vdst[static_cast<int64_t>(r) * kb + c] = tmp[it];
-  }
-}
-
-// Forward step of one panel, fused: every workgroup recomputes y1 = inv(L11) v1 (64 x 64 x k
-// flops, the inverse block comes from L2) and then updates ITS chunk of the rows below,
-// v2 -= L21 y1.  y1 goes to the Y workspace (chunk 0 writes it) so v1 stays read-only during the
-// launch: one launch per (level, step) instead of a diagonal launch plus an update launch.
-template <int KPT>
-__global__ __launch_bounds__(kThreads) void fwd_step_kernel(FrontArrays fa, StepArgs sa, const double* __restrict__ F,
-                                                           const double* __restrict__ Inv, double* __restrict__ V,
-                                                           double* __restrict__ Y) {
-  using T = Tile<KPT>;
+  constexpr int IT = KPT;  // vector elements per lane: (64 x KB) / 256
   __shared__ double As[TW * TLD];
   __shared__ double Bs[TW * T::BLD];
-  const int q = find_slot(sa.pref_work, sa.na, blockIdx.x);
-  const int chunk = blockIdx.x - sa.pref_work[q];
-  const int f = sa.fronts[q];
-  const int nch = sa.pref_chunks[q + 1] - sa.pref_chunks[q];
-  const int W = fa.W, kb = sa.kb;
+  const int2 wg = la.wg[blockIdx.x];
+  const int f = wg.x, rt = wg.y;
+  const int kb = la.kb;
   const int ns = fa.ns[f];
-  const int64_t d = ns + fa.bs[f];
-  const int j0 = sa.step * W;
-  const int w = min(W, ns - j0);
-  const int j1 = j0 + w;
-  double* Vf = V + fa.voff[f] * kb;
-  load_inverse(As, Inv + fa.ioff[f] + static_cast<int64_t>(sa.step) * W * W, W, w);
-  load_vec_rows<KPT>(Bs, Vf + static_cast<int64_t>(j0) * kb, nullptr, kb, w, nullptr);
-  __syncthreads();
+  const int d = ns + fa.bs[f];
+  const int nst = (ns + TW - 1) / TW;
+  const bool own = rt < nst;
+  const int row0 = own ? rt * TW : ns + (rt - nst) * TW;
+  const int rows = min(TW, (own ? ns : d) - row0);
+  const int nct = own ? rt + 1 : nst;
+  const int64_t ld = own ? ns : d;
+  const double* Rp = (own ? Tb + fa.toff[f] : F + fa.foff[f]) + row0;  // element (r, col) at col*ld + r
+  const int64_t vbase = fa.voff[f];
+  const int ar = threadIdx.x & (TW - 1), ajb = threadIdx.x >> 6;       // lane -> (row, first column) of a matrix tile
+
+  int gi[IT][kGS], xi[IT];
+  double bv[IT], av[TILE_IT];
+
+  auto fetch_idx = [&](int ct) {
+    const int w = min(TW, ns - ct * TW);
+#pragma unroll
+    for (int e = 0; e < IT; ++e) {
+      const int r = (threadIdx.x + e * kThreads) / T::KB;
+      const int64_t vrow = vbase + ct * TW + r;
+      const bool ok = r < w;
+      xi[e] = *(ok ? fa.v_src + vrow : fa.neg1);
+#pragma unroll
+      for (int s = 0; s < kGS; ++s) gi[e][s] = *(ok ? fa.gsrc + vrow * kGS + s : fa.neg1);
+    }
+  };
+  auto fetch_val = [&](int ct) {
+#pragma unroll
+    for (int e = 0; e < IT; ++e) {
+      const int c = (threadIdx.x + e * kThreads) & (T::KB - 1);
+      const bool cok = c < kb;
+      double v = alpha * *((cok && xi[e] >= 0) ? X + static_cast<int64_t>(xi[e]) * ldx + c : fa.zero);
+#pragma unroll
+      for (int s = 0; s < kGS; ++s) v += *((cok && gi[e][s] >= 0) ? V + static_cast<int64_t>(gi[e][s]) * kb + c : fa.zero);
+      bv[e] = v;
+    }
+    const int w = min(TW, ns - ct * TW);
+    const double* Ap = Rp + static_cast<int64_t>(ct) * TW * ld + ar;
+#pragma unroll
+    for (int it = 0; it < TILE_IT; ++it) {
+      const int j = ajb + it * (kThreads / TW);
+      av[it] = *((j < w && ar < rows) ? Ap + static_cast<int64_t>(j) * ld : fa.zero);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < TILE_IT; ++it) As[(ajb + it * (kThreads / TW)) * TLD + ar] = av[it];  // As[k][o] = R(row0 + o, ct*64 + k)
+#pragma unroll
+    for (int e = 0; e < IT; ++e) {
+      const int idx = threadIdx.x + e * kThreads;
+      Bs[(idx / T::KB) * T::BLD + (idx & (T::KB - 1))] = bv[e];
+    }
+  };
+
   double acc[T::NOUT];
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
-  T::template mac<false>(As, Bs, w, acc);
-  __syncthreads();
-  double* Yf = Y + (fa.voff[f] + j0) * kb;
-  const double* sgp = fa.sgn + fa.c0[f] + j0;
-#pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) {
-    int o, c;
-    T::coords(t, o, c);
-    Bs[o * T::BLD + c] = (o < w) ? acc[t] : 0.0;
-    if (chunk == 0 && o < w && c < kb) Yf[static_cast<int64_t>(o) * kb + c] = sgp[o] * acc[t];  // L^T x = S z
+  fetch_idx(0);
+  fetch_val(0);
+  if (nct > 1) fetch_idx(1);
+  for (int ct = 0; ct < nct; ++ct) {
+    commit();
+    __syncthreads();
+    if (ct + 1 < nct) {
+      fetch_val(ct + 1);
+      if (ct + 2 < nct) fetch_idx(ct + 2);
+    }
+    T::mac(As, Bs, min(TW, ns - ct * TW), acc);
+    __syncthreads();
   }
-  if (nch == 0) return;
-  const int row0 = j1 + chunk * TW;
-  const int rows = min(TW, static_cast<int>(d) - row0);
-  load_panel_chunk(As, F + fa.foff[f] + static_cast<int64_t>(j0) * d, d, w, row0, rows);
-  __syncthreads();
+  if (own) {
+    const double* sgp = fa.sgn + fa.c0[f] + row0;
+    double* Yf = Y + (vbase + row0) * kb;
 #pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
-  T::template mac<false>(As, Bs, w, acc);
+    for (int t = 0; t < T::NOUT; ++t) {
+      int o, c;
+      T::coords(t, o, c);
+      if (o < rows && c < kb) Yf[static_cast<int64_t>(o) * kb + c] = sgp[o] * acc[t];
+    }
+  } else {
 #pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) {
-    int o, c;
-    T::coords(t, o, c);
-    if (o < rows && c < kb) Vf[static_cast<int64_t>(row0 + o) * kb + c] -= acc[t];
+    for (int t = 0; t < T::NOUT; ++t) {
+      int o, c;
+      T::coords(t, o, c);
+      const bool ok = o < rows && c < kb;
+      const int64_t vrow = vbase + row0 + o;
+      double v = 0.0;
+#pragma unroll
+      for (int s = 0; s < kGS; ++s) {
+        const int g = *(ok ? fa.gsrc + vrow * kGS + s : fa.neg1);
+        v += *((g >= 0) ? V + static_cast<int64_t>(g) * kb + c : fa.zero);
+      }
+      if (ok) V[vrow * kb + c] = v - acc[t];
+    }
   }
 }
 
-// Backward, border rows: y(own columns) -= L21(border)^T x(border).  A workgroup owns one
-// 64-column chunk of a front and one group of BG border tiles, which it walks in order; the border
-// values of x are read straight from the parent's slice of V through the relative index list (group 0
-// of chunk 0 also mirrors them into the front's own slice for its children).  Fronts whose border
-// fits one group subtract directly (and single-panel ones are finished here); the others write a
-// partial slab that bwd_fold_kernel adds in fixed order -- no atomics.
+// Backward sweep, one level: workgroup (front f, column tile ct) forms
+//   x1(ct) = sum_{rt >= ct} T(rt, ct)^T y(rt)  -  sum_bt M21(bt, ct)^T x_border(bt)
+// y = S z from the forward sweep (Y), x_border read from the parent's slice of V through the relative index
+// list (workgroup ct = 0 mirrors it into the front's own border rows for its children).  The solution goes to
+// the front's own rows of V and straight to the caller's block Out.
 template <int KPT>
-__global__ __launch_bounds__(kThreads) void bwd_border_kernel(FrontArrays fa, const int* __restrict__ fronts, int nf,
-                                                             const int* __restrict__ pref_bwork, int kb,
-                                                             const double* __restrict__ F,
-                                                             const double* __restrict__ Inv, double* V,
-                                                             double* __restrict__ Y, double* __restrict__ P) {
+__global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
+                                                            const double* __restrict__ Tb,
+                                                            const double* __restrict__ Y, double* V, double* Out,
+                                                            int ldo) {
   using T = Tile<KPT>;
-  const int q = find_slot(pref_bwork, nf, blockIdx.x);
-  const int f = fronts[q];
-  const int p = fa.parent[f];
-  const int bs = fa.bs[f];
-  const int W = fa.W;
-  const int ns = fa.ns[f];
-  if ((p < 0 || bs == 0) && ns > W) return;  // nothing to fold in; the step kernels do the rest
+  constexpr int IT = KPT;
   __shared__ double As[TW * TLD];
   __shared__ double Bs[TW * T::BLD];
-  const int ntiles = (bs + TW - 1) / TW;
-  const int ngroups = max(1, (ntiles + fa.BG - 1) / fa.BG);
-  const int local = blockIdx.x - pref_bwork[q];
-  const int cc = local / ngroups, rg = local - cc * ngroups;
-  const int64_t d = ns + bs;
-  const int c0 = cc * W;
-  const int wc = min(W, ns - c0);
+  const int2 wg = la.wg[blockIdx.x];
+  const int f = wg.x, ct = wg.y;
+  const int kb = la.kb;
+  const int ns = fa.ns[f], bs = fa.bs[f];
+  const int d = ns + bs;
+  const int p = fa.parent[f];
+  const int nst = (ns + TW - 1) / TW;
+  const int c0t = ct * TW;
+  const int wc = min(TW, ns - c0t);
+  const int nown = nst - ct;
+  const int nbt = (p >= 0) ? (bs + TW - 1) / TW : 0;
+  const int ntile = nown + nbt;
+  const int64_t vbase = fa.voff[f];
+  const double* Tp = Tb + fa.toff[f] + static_cast<int64_t>(c0t) * ns;   // T(r, c0t + o) at o*ns + r
+  const double* Mp = F + fa.foff[f] + static_cast<int64_t>(c0t) * d;     // M21 / L(r, c0t + o) at o*d + r
   const int* __restrict__ rel = fa.rel + fa.bptr[f];
   const double* Vp = V + fa.voff[p >= 0 ? p : f] * kb;
-  double* Vb = V + (fa.voff[f] + ns) * kb;
-  const double* Fc = F + fa.foff[f] + static_cast<int64_t>(c0) * d + ns;  // element (border r, col c) at c*d + r
+  const int ar = threadIdx.x & (TW - 1), ajb = threadIdx.x >> 6;
+
+  int ri[IT];
+  double bv[IT], av[TILE_IT];
+  int pend_rbase = 0, pend_rows = 0;
+  bool pend_border = false;
+
+  auto fetch_idx = [&](int t) {  // border tiles only: rows of the parent's slice
+    if (t < nown) return;
+    const int b0 = (t - nown) * TW;
+    const int rows = min(TW, bs - b0);
+#pragma unroll
+    for (int e = 0; e < IT; ++e) {
+      const int r = (threadIdx.x + e * kThreads) / T::KB;
+      ri[e] = *((r < rows) ? rel + b0 + r : fa.neg1);
+    }
+  };
+  auto fetch_val = [&](int t) {
+    const bool border = t >= nown;
+    const int rbase = border ? ns + (t - nown) * TW : (ct + t) * TW;
+    const int rows = min(TW, (border ? d : ns) - rbase);
+    if (!border) {
+      const double* Yp = Y + (vbase + rbase) * kb;
+#pragma unroll
+      for (int e = 0; e < IT; ++e) {
+        const int idx = threadIdx.x + e * kThreads;
+        const int r = idx / T::KB, c = idx & (T::KB - 1);
+        bv[e] = *((r < rows && c < kb) ? Yp + static_cast<int64_t>(r) * kb + c : fa.zero);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < IT; ++e) {
+        const int c = (threadIdx.x + e * kThreads) & (T::KB - 1);
+        bv[e] = -*((ri[e] >= 0 && c < kb) ? Vp + static_cast<int64_t>(ri[e]) * kb + c : fa.zero);
+      }
+    }
+    const double* Ap = (border ? Mp : Tp) + rbase + ar;
+    const int64_t ld = border ? d : ns;
+#pragma unroll
+    for (int it = 0; it < TILE_IT; ++it) {
+      const int j = ajb + it * (kThreads / TW);
+      av[it] = *((j < wc && ar < rows) ? Ap + static_cast<int64_t>(j) * ld : fa.zero);
+    }
+    pend_border = border;
+    pend_rbase = rbase;
+    pend_rows = rows;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < TILE_IT; ++it) As[ar * TLD + ajb + it * (kThreads / TW)] = av[it];  // As[k][o] = R(rbase + k, c0t + o)
+#pragma unroll
+    for (int e = 0; e < IT; ++e) {
+      const int idx = threadIdx.x + e * kThreads;
+      const int r = idx / T::KB, c = idx & (T::KB - 1);
+      Bs[r * T::BLD + c] = bv[e];
+      if (pend_border && ct == 0 && r < pend_rows && c < kb) V[(vbase + pend_rbase + r) * kb + c] = -bv[e];
+    }
+  };
+
   double acc[T::NOUT];
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
-  const int rbeg = rg * fa.BG * TW, rend = min(bs, (rg + 1) * fa.BG * TW);
-  for (int r0 = rbeg; r0 < rend; r0 += TW) {
-    const int rows = min(TW, bs - r0);
-    load_tile_transposed(As, Fc + r0, d, rows, wc);  // As[r*TLD + c] = L(ns + r0 + r, c0 + c)
-    load_vec_rows<KPT>(Bs, Vp, rel + r0, kb, rows, cc == 0 ? Vb + static_cast<int64_t>(r0) * kb : nullptr);
+  fetch_idx(0);
+  fetch_val(0);
+  if (ntile > 1) fetch_idx(1);
+  for (int t = 0; t < ntile; ++t) {
+    const int kdim = pend_rows;
+    commit();
     __syncthreads();
-    T::template mac<false>(As, Bs, rows, acc);
+    if (t + 1 < ntile) {
+      fetch_val(t + 1);
+      if (t + 2 < ntile) fetch_idx(t + 2);
+    }
+    T::mac(As, Bs, kdim, acc);
     __syncthreads();
   }
-  double* Yf = Y + (fa.voff[f] + c0) * kb;
-  if (ngroups > 1) {  // partial slab [cc][rg], 64 x KBMAX
-    double* Pp = P + (static_cast<int64_t>(fa.poff[f]) + local) * (TW * KBMAX);
+  double* Vf = V + (vbase + c0t) * kb;
 #pragma unroll
-    for (int t = 0; t < T::NOUT; ++t) {
-      int o, c;
-      T::coords(t, o, c);
-      Pp[o * KBMAX + c] = acc[t];
+  for (int t = 0; t < T::NOUT; ++t) {
+    int o, c;
+    T::coords(t, o, c);
+    if (o < wc && c < kb) {
+      Vf[static_cast<int64_t>(o) * kb + c] = acc[t];
+      Out[static_cast<int64_t>(fa.v_src[vbase + c0t + o]) * ldo + c] = acc[t];
     }
-    return;
-  }
-  if (ns > W) {  // multi-panel front, single group: fold into the right-hand side directly
-#pragma unroll
-    for (int t = 0; t < T::NOUT; ++t) {
-      int o, c;
-      T::coords(t, o, c);
-      if (o < wc && c < kb) Yf[static_cast<int64_t>(o) * kb + c] -= acc[t];
-    }
-    return;
-  }
-  // single-panel front with a single group (the leaves and small separators): finish here
-#pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) {
-    int o, c;
-    T::coords(t, o, c);
-    Bs[o * T::BLD + c] = (o < wc && c < kb) ? Yf[static_cast<int64_t>(o) * kb + c] - acc[t] : 0.0;
-  }
-  load_inverse(As, Inv + fa.ioff[f], W, wc);
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
-  T::template mac<true>(As, Bs, wc, acc);
-  double* Vf = V + fa.voff[f] * kb;
-#pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) {
-    int o, c;
-    T::coords(t, o, c);
-    if (o < wc && c < kb) Vf[static_cast<int64_t>(o) * kb + c] = acc[t];
-  }
-}
-
-
-// y(chunk) -= sum over groups of the partial slabs, groups in ascending order
-__global__ __launch_bounds__(kThreads) void bwd_fold_kernel(FrontArrays fa, const int* __restrict__ fronts, int nf,
-                                                           const int* __restrict__ pref_panels, int kb,
-                                                           const double* __restrict__ P, double* __restrict__ Y) {
-  const int q = find_slot(pref_panels, nf, blockIdx.x);
-  const int f = fronts[q];
-  const int po = fa.poff[f];
-  if (po < 0) return;
-  const int cc = blockIdx.x - pref_panels[q];
-  const int W = fa.W;
-  const int ns = fa.ns[f], bs = fa.bs[f];
-  const int ntiles = (bs + TW - 1) / TW;
-  const int ngroups = (ntiles + fa.BG - 1) / fa.BG;
-  const int wc = min(W, ns - cc * W);
-  double* Yf = Y + (fa.voff[f] + cc * W) * kb;
-  const double* Pp = P + (static_cast<int64_t>(po) + cc * ngroups) * (TW * KBMAX);
-  for (int idx = threadIdx.x; idx < wc * kb; idx += kThreads) {
-    const int o = idx / kb, c = idx - o * kb;
-    double s = 0.0;
-    for (int g = 0; g < ngroups; ++g) s += Pp[static_cast<int64_t>(g) * (TW * KBMAX) + o * KBMAX + c];
-    Yf[idx] -= s;
-  }
-}
-
-// Backward step of one panel, fused and right-looking: every workgroup recomputes
-// x1 = inv(L11)^T y1, workgroup 0 stores it in V, and workgroup cc folds it into the 64 earlier
-// columns it owns: y(cc) -= L(panel rows, cc columns)^T x1.  No partial sums, one launch per step.
-template <int KPT>
-__global__ __launch_bounds__(kThreads) void bwd_step_kernel(FrontArrays fa, StepArgs sa, const double* __restrict__ F,
-                                                           const double* __restrict__ Inv, double* __restrict__ V,
-                                                           double* __restrict__ Y) {
-  using T = Tile<KPT>;
-  __shared__ double As[TW * TLD];
-  __shared__ double Bs[TW * T::BLD];
-  const int wpf = max(1, sa.step);  // workgroups per front: one per earlier 64-column chunk
-  const int q = blockIdx.x / wpf;
-  const int cc = blockIdx.x - q * wpf;
-  const int f = sa.fronts[q];
-  const int W = fa.W, kb = sa.kb;
-  const int ns = fa.ns[f];
-  if (ns <= W && fa.poff[f] < 0) return;  // single-panel, single-group fronts are finished by bwd_border_kernel
-  const int64_t d = ns + fa.bs[f];
-  const int j0 = sa.step * W;
-  const int w = min(W, ns - j0);
-  double* Yf = Y + fa.voff[f] * kb;
-  load_inverse(As, Inv + fa.ioff[f] + static_cast<int64_t>(sa.step) * W * W, W, w);
-  load_vec_rows<KPT>(Bs, Yf + static_cast<int64_t>(j0) * kb, nullptr, kb, w, nullptr);
-  __syncthreads();
-  double acc[T::NOUT];
-#pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
-  T::template mac<true>(As, Bs, w, acc);  // x1[o] = sum_i inv(i, o) y1[i]
-  __syncthreads();
-  double* Vf = V + (fa.voff[f] + j0) * kb;
-#pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) {
-    int o, c;
-    T::coords(t, o, c);
-    Bs[o * T::BLD + c] = (o < w) ? acc[t] : 0.0;
-    if (cc == 0 && o < w && c < kb) Vf[static_cast<int64_t>(o) * kb + c] = acc[t];
-  }
-  if (sa.step == 0) return;
-  // As[r*TLD + c] = L(j0 + r, cc*W + c): the panel's rows in the columns of chunk cc (full width W)
-  load_tile_transposed(As, F + fa.foff[f] + static_cast<int64_t>(cc) * W * d + j0, d, w, W);
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
-  T::template mac<false>(As, Bs, w, acc);
-  double* Yc = Yf + static_cast<int64_t>(cc) * W * kb;
-#pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) {
-    int o, c;
-    T::coords(t, o, c);
-    if (o < W && c < kb) Yc[static_cast<int64_t>(o) * kb + c] -= acc[t];
   }
 }
 
@@ -683,8 +761,16 @@ struct eigd_factor {
   int *d_c0 = nullptr, *d_ns = nullptr, *d_bs = nullptr, *d_parent = nullptr, *d_rel = nullptr;
   int64_t *d_foff = nullptr, *d_voff = nullptr, *d_ioff = nullptr, *d_bptr = nullptr;
   int *d_lvl_fronts = nullptr, *d_pref_chunks = nullptr, *d_pref_tiles = nullptr, *d_cs_child = nullptr;
-  int *d_pref_work = nullptr, *d_pref_panels = nullptr, *d_pref_bwork = nullptr, *d_poff = nullptr;
-  double* d_P = nullptr;
+  // sweeps: per-level workgroup prefixes (forward: row tiles of [T; M21], backward: column tiles), gather lists
+  int2 *d_fwd_wg = nullptr, *d_bwd_wg = nullptr;
+  int *d_tri_pref = nullptr, *d_m_pref = nullptr;
+  int *d_gsrc = nullptr, *d_ov_ptr = nullptr, *d_ov_src = nullptr;
+  int64_t* d_toff = nullptr;
+  double *d_T = nullptr, *d_aux = nullptr;  // aux: {0.0, (int) -1}
+  std::vector<int> h_fwd_ptr, h_bwd_ptr;  // per level: first workgroup record
+  std::vector<int> ov_lvl_ptr;       // per level: range of overflow rows (extra rows of V after the sumd front rows)
+  int64_t t_doubles = 0, v_rows = 0;
+  int n_tri = 0, n_m21 = 0;
   int64_t *d_a_src = nullptr, *d_a_dst = nullptr;
   int* d_v_src = nullptr;
   double *d_data = nullptr, *d_F = nullptr, *d_Inv = nullptr, *d_V = nullptr, *d_Y = nullptr, *d_sgn = nullptr;
@@ -705,10 +791,13 @@ struct eigd_factor {
     a.ioff = d_ioff;
     a.bptr = d_bptr;
     a.rel = d_rel;
-    a.poff = d_poff;
+    a.toff = d_toff;
+    a.gsrc = d_gsrc;
+    a.v_src = d_v_src;
     a.sgn = d_sgn;
+    a.zero = d_aux;
+    a.neg1 = reinterpret_cast<const int*>(d_aux + 1);
     a.W = sym->W;
-    a.BG = sym->BG;
     return a;
   }
 };
@@ -766,6 +855,15 @@ int numeric(eigd_factor* f, const double* hdata) {
       }
     }
   }
+  if (f->n_tri > 0) {
+    hipLaunchKernelGGL(trinv_kernel, dim3(f->n_tri), dim3(kThreads), 0, st, fa, f->d_tri_pref, s.nfronts, f->d_F,
+                       f->d_Inv, f->d_T);
+    EIGD_LAUNCH_CHECK();
+  }
+  if (f->n_m21 > 0) {
+    hipLaunchKernelGGL(m21_kernel, dim3(f->n_m21), dim3(kThreads), 0, st, fa, f->d_m_pref, s.nfronts, f->d_F, f->d_T);
+    EIGD_LAUNCH_CHECK();
+  }
   int flag[2] = {0, 0};
   EIGD_HIP(hipMemcpyAsync(flag, f->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   EIGD_HIP(hipStreamSynchronize(st));
@@ -780,69 +878,39 @@ int numeric(eigd_factor* f, const double* hdata) {
 }
 
 template <int KPT>
-int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, const double* dIn, int ldin, double* dX,
-          int ldx, int kb, double alpha) {
+int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, const double* dIn, int ldin, double* dX, int ldx,
+          int kb, double alpha) {
   const Symbolic& s = *f->sym;
   const FrontArrays fa = f->fa();
-  const int64_t total = s.sumd * kb;
-  const int gb = static_cast<int>(std::min<int64_t>((total + 255) / 256, 16384));
-  hipLaunchKernelGGL(solve_init_kernel, dim3(std::max(gb, 1)), dim3(256), 0, st, s.sumd, kb, f->d_v_src, dIn, ldin,
-                     alpha, wV);
-  EIGD_LAUNCH_CHECK();
-  auto step_args = [&](int l, int step) {
-    const int rec = s.ls_ptr[l] + step;
-    const int64_t po = s.ls_pref_ptr[rec];
-    StepArgs sa;
-    sa.fronts = f->d_lvl_fronts + s.lvl_ptr[l];
-    sa.pref_chunks = f->d_pref_chunks + po;
-    sa.pref_work = f->d_pref_work + po;
-    sa.na = s.ls_nactive[rec];
-    sa.step = step;
-    sa.kb = kb;
-    return sa;
+  auto level_args = [&](const int2* wg) {
+    LevelArgs la;
+    la.wg = wg;
+    la.kb = kb;
+    return la;
   };
-  // ---- forward: leaves -> root
+  // ---- forward: leaves -> root.  Y receives S z, the border rows of V the carries.
   for (int l = 0; l < s.nlevels; ++l) {
-    for (int slot = 0; slot < s.maxslots; ++slot) {
-      const size_t rec = static_cast<size_t>(l) * s.maxslots + slot;
-      const int cnt = s.cs_ptr[rec + 1] - s.cs_ptr[rec];
-      if (cnt == 0) continue;
-      const int split = std::max(1, std::min(64, f->ea_split[rec] / 8));
-      hipLaunchKernelGGL(vec_extend_add_kernel, dim3(cnt, split), dim3(kThreads), 0, st, fa,
-                         f->d_cs_child + s.cs_ptr[rec], kb, wV);
+    const int nov = f->ov_lvl_ptr[l + 1] - f->ov_lvl_ptr[l];
+    if (nov > 0) {
+      const int first = f->ov_lvl_ptr[l];
+      hipLaunchKernelGGL(overflow_sum_kernel, dim3((nov * kb + 255) / 256), dim3(256), 0, st, nov, f->d_ov_ptr + first,
+                         f->d_ov_src, s.sumd + first, kb, wV);
       EIGD_LAUNCH_CHECK();
     }
-    for (int step = 0; step < s.lvl_nsteps[l]; ++step) {
-      const StepArgs sa = step_args(l, step);
-      const int nwork = s.pref_work[s.ls_pref_ptr[s.ls_ptr[l] + step] + sa.na];
-      hipLaunchKernelGGL(fwd_step_kernel<KPT>, dim3(nwork), dim3(kThreads), 0, st, fa, sa, f->d_F, f->d_Inv, wV,
-                         wY);
-      EIGD_LAUNCH_CHECK();
-    }
-  }
-  // ---- backward: root -> leaves.  Y holds the right-hand sides, V receives the solution.
-  for (int l = s.nlevels - 1; l >= 0; --l) {
-    const int nf = s.lvl_ptr[l + 1] - s.lvl_ptr[l];
-    const int64_t pp = s.lvl_pp_ptr[l];
-    const int npan = s.pref_panels[pp + nf];
-    const int nbw = s.pref_bwork[pp + nf];
-    hipLaunchKernelGGL(bwd_border_kernel<KPT>, dim3(nbw), dim3(kThreads), 0, st, fa, f->d_lvl_fronts + s.lvl_ptr[l],
-                       nf, f->d_pref_bwork + pp, kb, f->d_F, f->d_Inv, wV, wY, wP);
+    const int nwg = f->h_fwd_ptr[l + 1] - f->h_fwd_ptr[l];
+    if (nwg == 0) continue;
+    hipLaunchKernelGGL(fwd_level_kernel<KPT>, dim3(nwg), dim3(kThreads), 0, st, fa,
+                       level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
     EIGD_LAUNCH_CHECK();
-    if (nbw > npan) {  // some front of the level has more than one tile group
-      hipLaunchKernelGGL(bwd_fold_kernel, dim3(npan), dim3(kThreads), 0, st, fa, f->d_lvl_fronts + s.lvl_ptr[l], nf,
-                         f->d_pref_panels + pp, kb, wP, wY);
-      EIGD_LAUNCH_CHECK();
-    }
-    for (int step = s.lvl_nsteps[l] - 1; step >= 0; --step) {
-      const StepArgs sa = step_args(l, step);
-      hipLaunchKernelGGL(bwd_step_kernel<KPT>, dim3(sa.na * std::max(1, step)), dim3(kThreads), 0, st, fa, sa, f->d_F,
-                         f->d_Inv, wV, wY);
-      EIGD_LAUNCH_CHECK();
-    }
   }
-  hipLaunchKernelGGL(solve_out_kernel, dim3(std::max(gb, 1)), dim3(256), 0, st, s.sumd, kb, f->d_v_src, wV, dX, ldx);
-  EIGD_LAUNCH_CHECK();
+  // ---- backward: root -> leaves.  V receives the solution front by front, dX the caller's rows.
+  for (int l = s.nlevels - 1; l >= 0; --l) {
+    const int nwg = f->h_bwd_ptr[l + 1] - f->h_bwd_ptr[l];
+    if (nwg == 0) continue;
+    hipLaunchKernelGGL(bwd_level_kernel<KPT>, dim3(nwg), dim3(kThreads), 0, st, fa,
+                       level_args(f->d_bwd_wg + f->h_bwd_ptr[l]), f->d_F, f->d_T, wY, wV, dX, ldx);
+    EIGD_LAUNCH_CHECK();
+  }
   return EIGD_OK;
 }
 
@@ -944,8 +1012,9 @@ int eigd_factor_free(eigd_factor* f) {
   void* ptrs[] = {f->d_c0,        f->d_ns,          f->d_bs,         f->d_parent,   f->d_rel,   f->d_foff,
                   f->d_voff,      f->d_ioff,        f->d_bptr,       f->d_lvl_fronts, f->d_pref_chunks,
                   f->d_pref_tiles, f->d_cs_child,   f->d_a_src,      f->d_a_dst,    f->d_v_src, f->d_data,
-                  f->d_F,         f->d_Inv,         f->d_V,          f->d_Y,        f->d_flag,  f->d_pref_work,
-                  f->d_pref_panels, f->d_pref_bwork, f->d_poff,     f->d_P,      f->d_sgn};
+                  f->d_F,         f->d_Inv,         f->d_V,          f->d_Y,        f->d_flag,  f->d_fwd_wg,
+                  f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_gsrc,     f->d_ov_ptr, f->d_ov_src,
+                  f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;
@@ -957,10 +1026,73 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   *out = nullptr;
   const Symbolic& s = h->s;
   EIGD_HIP(hipSetDevice(ctx->device));
+  // ---- host tables of the sweeps
+  const int nf = s.nfronts;
+  std::vector<int64_t> toff(static_cast<size_t>(nf) + 1, 0);
+  std::vector<int> tri_pref(static_cast<size_t>(nf) + 1, 0), m_pref(static_cast<size_t>(nf) + 1, 0);
+  for (int q = 0; q < nf; ++q) {
+    const int64_t ns = s.f_ns[q];
+    toff[q + 1] = toff[q] + ns * ns;
+    tri_pref[q + 1] = tri_pref[q] + static_cast<int>((ns + s.W - 1) / s.W);
+    m_pref[q + 1] = m_pref[q] + (s.f_bs[q] + TW - 1) / TW;
+  }
+  // workgroup records (front, tile) per level; within a front the longest reductions first
+  std::vector<int2> fwd_wg, bwd_wg;
+  std::vector<int> h_fwd_ptr(static_cast<size_t>(s.nlevels) + 1, 0), h_bwd_ptr(static_cast<size_t>(s.nlevels) + 1, 0);
+  for (int l = 0; l < s.nlevels; ++l) {
+    for (int q = s.lvl_ptr[l]; q < s.lvl_ptr[l + 1]; ++q) {
+      const int fr = s.lvl_fronts[q];
+      const int nst = (s.f_ns[fr] + TW - 1) / TW, nbt = (s.f_bs[fr] + TW - 1) / TW;
+      for (int t = nst + nbt - 1; t >= 0; --t) fwd_wg.push_back(make_int2(fr, t));  // border tiles (nst products) first
+      for (int t = 0; t < nst; ++t) bwd_wg.push_back(make_int2(fr, t));              // ct = 0 walks the most tiles
+    }
+    h_fwd_ptr[l + 1] = static_cast<int>(fwd_wg.size());
+    h_bwd_ptr[l + 1] = static_cast<int>(bwd_wg.size());
+  }
+  // gather lists of the forward carries: row (voff[p] + rel[i]) of the parent receives row (voff[c] + ns_c + i) of
+  // child c; children in ascending front order.  Rows with more than kGS contributors sum the surplus into an
+  // extra row first (overflow_sum_kernel) that the last slot points to.
+  std::vector<int> gsrc(static_cast<size_t>(s.sumd) * kGS, -1), gcnt(static_cast<size_t>(s.sumd), 0);
+  struct Surplus { int level; int64_t dst; std::vector<int> src; };
+  std::vector<Surplus> surplus;
+  std::vector<int64_t> surplus_of;  // dst row -> index into surplus (sparse: linear map only when needed)
+  for (int c = 0; c < nf; ++c) {
+    const int p = s.f_parent[c];
+    if (p < 0) continue;
+    const int64_t b0 = s.f_bptr[c];
+    for (int i = 0; i < s.f_bs[c]; ++i) {
+      const int64_t dst = s.f_voff[p] + s.rel[b0 + i];
+      const int src = static_cast<int>(s.f_voff[c] + s.f_ns[c] + i);
+      int& cnt = gcnt[dst];
+      if (cnt < kGS) {
+        gsrc[dst * kGS + cnt] = src;
+      } else {
+        if (surplus_of.empty()) surplus_of.assign(static_cast<size_t>(s.sumd), -1);
+        if (surplus_of[dst] < 0) {
+          surplus_of[dst] = static_cast<int64_t>(surplus.size());
+          surplus.push_back(Surplus{s.f_level[p], dst, {gsrc[dst * kGS + kGS - 1]}});
+        }
+        surplus[surplus_of[dst]].src.push_back(src);
+      }
+      ++cnt;
+    }
+  }
+  std::stable_sort(surplus.begin(), surplus.end(), [](const Surplus& a, const Surplus& b) { return a.level < b.level; });
+  std::vector<int> ov_ptr(1, 0), ov_src, ov_lvl_ptr(static_cast<size_t>(s.nlevels) + 1, 0);
+  for (size_t x = 0; x < surplus.size(); ++x) {
+    for (int e : surplus[x].src) ov_src.push_back(e);
+    ov_ptr.push_back(static_cast<int>(ov_src.size()));
+    gsrc[surplus[x].dst * kGS + kGS - 1] = static_cast<int>(s.sumd + static_cast<int64_t>(x));
+    ov_lvl_ptr[surplus[x].level + 1] += 1;
+  }
+  for (int l = 0; l < s.nlevels; ++l) ov_lvl_ptr[l + 1] += ov_lvl_ptr[l];
+  const int64_t v_rows = s.sumd + static_cast<int64_t>(surplus.size());
+  EIGD_REQUIRE(v_rows < (int64_t(1) << 31), "vector workspace has too many rows");
+
   size_t free_b = 0, total_b = 0;
   EIGD_HIP(hipMemGetInfo(&free_b, &total_b));
-  const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + 2 * s.sumd * KBMAX + s.nslabs * TW * KBMAX) +
-                      16 * s.a_src.size() + (size_t(64) << 20);
+  const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + toff[nf] + 2 * v_rows * KBMAX) +
+                      16 * s.a_src.size() + 4 * gsrc.size() + (size_t(64) << 20);
   if (need > free_b) {
     set_error("factor needs %.2f GiB of device memory, %.2f GiB free", need / 1073741824.0, free_b / 1073741824.0);
     return EIGD_E_HIP;
@@ -968,6 +1100,13 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   eigd_factor* f = new eigd_factor();
   f->ctx = ctx;
   f->sym = &h->s;
+  f->h_fwd_ptr = h_fwd_ptr;
+  f->h_bwd_ptr = h_bwd_ptr;
+  f->ov_lvl_ptr = ov_lvl_ptr;
+  f->t_doubles = toff[nf];
+  f->v_rows = v_rows;
+  f->n_tri = tri_pref[nf];
+  f->n_m21 = m_pref[nf];
   int rc = EIGD_OK;
 #define UP(dst, vec)                          \
   if (rc == EIGD_OK) rc = upload(f, &f->dst, vec);
@@ -983,10 +1122,14 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   UP(d_lvl_fronts, s.lvl_fronts)
   UP(d_pref_chunks, s.pref_chunks)
   UP(d_pref_tiles, s.pref_tiles)
-  UP(d_pref_work, s.pref_work)
-  UP(d_pref_panels, s.pref_panels)
-  UP(d_pref_bwork, s.pref_bwork)
-  UP(d_poff, s.f_poff)
+  UP(d_fwd_wg, fwd_wg)
+  UP(d_bwd_wg, bwd_wg)
+  UP(d_tri_pref, tri_pref)
+  UP(d_m_pref, m_pref)
+  UP(d_toff, toff)
+  UP(d_gsrc, gsrc)
+  UP(d_ov_ptr, ov_ptr)
+  UP(d_ov_src, ov_src)
   UP(d_cs_child, s.cs_child)
   UP(d_a_src, s.a_src)
   UP(d_a_dst, s.a_dst)
@@ -1010,10 +1153,11 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   rc = dmalloc(&f->d_data, f->data_len);
   rc = dmalloc(&f->d_F, s.front_doubles);
   rc = dmalloc(&f->d_Inv, s.inv_doubles);
-  rc = dmalloc(&f->d_V, static_cast<size_t>(s.sumd) * KBMAX);
+  rc = dmalloc(&f->d_T, static_cast<size_t>(f->t_doubles));
+  rc = dmalloc(&f->d_aux, 2);
+  rc = dmalloc(&f->d_V, static_cast<size_t>(v_rows) * KBMAX);
   rc = dmalloc(&f->d_Y, static_cast<size_t>(s.sumd) * KBMAX);
   rc = dmalloc(&f->d_sgn, static_cast<size_t>(s.n));
-  rc = dmalloc(&f->d_P, static_cast<size_t>(std::max<int64_t>(s.nslabs, 1)) * TW * KBMAX);
   if (rc == EIGD_OK) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_flag), 2 * sizeof(int));
     if (e != hipSuccess) {
@@ -1034,6 +1178,13 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     f->ea_split[rec] = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(split, 512)));
   }
   EIGD_HIP(hipMemsetAsync(f->d_Inv, 0, sizeof(double) * std::max<int64_t>(s.inv_doubles, 1), ctx->stream));
+  EIGD_HIP(hipMemsetAsync(f->d_T, 0, sizeof(double) * std::max<int64_t>(f->t_doubles, 1), ctx->stream));  // upper triangles stay zero
+  {
+    double aux[2] = {0.0, 0.0};
+    const int m1 = -1;
+    std::memcpy(&aux[1], &m1, sizeof(int));
+    EIGD_HIP(hipMemcpy(f->d_aux, aux, sizeof(aux), hipMemcpyHostToDevice));
+  }
   rc = numeric(f, hdata);
   if (rc != EIGD_OK) {
     eigd_factor_free(f);
@@ -1052,7 +1203,7 @@ int eigd_factor_solve(eigd_factor* f, double* dX, int ldx, int k, double alpha) 
   return eigd_factor_solve_to(f, dX, ldx, dX, ldx, k, alpha);
 }
 
-static int solve_blocks(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, const double* dIn, int ldin,
+static int solve_blocks(eigd_factor* f, hipStream_t st, double* wV, double* wY, const double* dIn, int ldin,
                         double* dOut, int ldout, int k, double alpha) {
   EIGD_REQUIRE(f && dIn && dOut, "null argument");
   EIGD_REQUIRE(k >= 1 && ldin >= k && ldout >= k, "bad block shape k=%d ldin=%d ldout=%d", k, ldin, ldout);
@@ -1060,13 +1211,13 @@ static int solve_blocks(eigd_factor* f, hipStream_t st, double* wV, double* wY, 
     const int kb = std::min(KBMAX, k - c0);
     int rc;
     if (kb <= 4)
-      rc = sweep<1>(f, st, wV, wY, wP, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
+      rc = sweep<1>(f, st, wV, wY, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else if (kb <= 8)
-      rc = sweep<2>(f, st, wV, wY, wP, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
+      rc = sweep<2>(f, st, wV, wY, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else if (kb <= 16)
-      rc = sweep<4>(f, st, wV, wY, wP, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
+      rc = sweep<4>(f, st, wV, wY, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else
-      rc = sweep<8>(f, st, wV, wY, wP, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
+      rc = sweep<8>(f, st, wV, wY, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     if (rc != EIGD_OK) return rc;
   }
   return EIGD_OK;
@@ -1074,7 +1225,7 @@ static int solve_blocks(eigd_factor* f, hipStream_t st, double* wV, double* wY, 
 
 int eigd_factor_solve_to(eigd_factor* f, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha) {
   EIGD_REQUIRE(f, "null argument");
-  return solve_blocks(f, f->ctx->stream, f->d_V, f->d_Y, f->d_P, dIn, ldin, dOut, ldout, k, alpha);
+  return solve_blocks(f, f->ctx->stream, f->d_V, f->d_Y, dIn, ldin, dOut, ldout, k, alpha);
 }
 
 // A lane = a second set of sweep workspaces bound to another context (stream) of the same device: sweeps of
@@ -1082,7 +1233,7 @@ int eigd_factor_solve_to(eigd_factor* f, const double* dIn, int ldin, double* dO
 struct eigd_lane {
   eigd_factor* f = nullptr;
   eigd_ctx* ctx = nullptr;
-  double *V = nullptr, *Y = nullptr, *P = nullptr;
+  double *V = nullptr, *Y = nullptr;
 };
 
 int eigd_factor_lane_create(eigd_factor* f, eigd_ctx* ctx, eigd_lane** out) {
@@ -1093,12 +1244,11 @@ int eigd_factor_lane_create(eigd_factor* f, eigd_ctx* ctx, eigd_lane** out) {
   eigd_lane* l = new eigd_lane();
   l->f = f;
   l->ctx = ctx;
-  const size_t vb = sizeof(double) * std::max<size_t>(static_cast<size_t>(s.sumd) * KBMAX, 1);
-  const size_t pb = sizeof(double) * static_cast<size_t>(std::max<int64_t>(s.nslabs, 1)) * TW * KBMAX;
+  const size_t vb = sizeof(double) * std::max<size_t>(static_cast<size_t>(f->v_rows) * KBMAX, 1);
+  const size_t yb = sizeof(double) * std::max<size_t>(static_cast<size_t>(s.sumd) * KBMAX, 1);
   hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&l->V), vb);
-  hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&l->Y), vb);
-  hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&l->P), pb);
-  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+  hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&l->Y), yb);
+  if (e1 != hipSuccess || e2 != hipSuccess) {
     eigd_factor_lane_free(l);
     set_error("hipMalloc failed for a sweep lane");
     return EIGD_E_HIP;
@@ -1112,14 +1262,13 @@ int eigd_factor_lane_free(eigd_lane* l) {
   if (l->ctx && l->ctx->stream) (void)hipStreamSynchronize(l->ctx->stream);
   if (l->V) (void)hipFree(l->V);
   if (l->Y) (void)hipFree(l->Y);
-  if (l->P) (void)hipFree(l->P);
   delete l;
   return EIGD_OK;
 }
 
 int eigd_factor_lane_solve_to(eigd_lane* l, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha) {
   EIGD_REQUIRE(l, "null argument");
-  return solve_blocks(l->f, l->ctx->stream, l->V, l->Y, l->P, dIn, ldin, dOut, ldout, k, alpha);
+  return solve_blocks(l->f, l->ctx->stream, l->V, l->Y, dIn, ldin, dOut, ldout, k, alpha);
 }
 
 int eigd_factor_stats(eigd_factor* f, double* out, int nout) {

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """a few k=32 and k=4 sweeps on the C3 factor, for kernel traces (development aid)"""
+import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eigd_amd.device import Factor, default_context  # noqa: E402
 from eigd_amd.problems import BucklingColumn  # noqa: E402
 
