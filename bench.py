@@ -199,6 +199,14 @@ def main():
             events.append((time.perf_counter(), r[0], r[1], int(np.count_nonzero(~done))))
             return r
 
+        ratios, orig_lstsq = [], adj.solve_shifted_lstsq
+
+        def lstsq_traced(alpha, H, r):
+            j = H.shape[1]
+            ratios.append((j, H[j, j - 1] / max(np.linalg.norm(H[:j, j - 1]), 1e-300)))
+            return orig_lstsq(alpha, H, r)
+
+        adj.solve_shifted_lstsq = lstsq_traced
         adj._active_range = traced
         ctx.sync()
         t_begin = time.perf_counter()
@@ -206,7 +214,11 @@ def main():
         ctx.sync()
         t_end = time.perf_counter()
         adj._active_range = orig
+        adj.solve_shifted_lstsq = orig_lstsq
         with open(args.trace, "w") as fh:
+            for j in sorted({q for q, _ in ratios}):
+                rs = [x for q, x in ratios if q == j]
+                fh.write(f"step {j:3d}: h_next/|h| over live modes: min {min(rs):.3e} median {np.median(rs):.3e} max {max(rs):.3e}\n")
             prev = t_begin
             for it, (t, lo, hi, live) in enumerate(events):
                 fh.write(f"iter {it:3d}  +{1e3 * (t - prev):7.3f} ms  range [{lo:2d},{hi:2d})  live {live}\n")

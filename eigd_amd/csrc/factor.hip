@@ -48,6 +48,7 @@ struct FrontArrays {
   const int64_t* toff;  // offset of the front's inverted triangle T = inv(L11) (ns x ns, column-major)
   const int* gsrc;      // kGS rows of V per row of V: the children's carries that add into it (forward sweep), -1 = none
   const int* v_src;     // per row of V: the row of the caller's block it holds (own rows), -1 for border rows
+  const int* bout;      // per border entry (bptr): its row in the caller's block
   double* sgn;          // +-1 per (permuted) column: A = L S L^T with S = diag(sgn); all +1 for a positive definite matrix
   const double* zero;   // one 0.0 and ...
   const int* neg1;      // ... one -1 in device memory: masked-off lanes of the sweeps load from here (address select)
@@ -495,14 +496,28 @@ struct Tile {
   }
 };
 
+// One workgroup of a level launch.
+//   forward, mode 0 : output row tile `tile` of front f, steps [s0, s1) of the chain over column tiles ct
+//   forward, mode 1 : front with a single column tile: row tiles [s0, s1), the right-hand side block stays in LDS
+//   backward        : output column tile `tile`, steps [s0, s1) of the chain (own row tiles, then border tiles)
+// Long chains of the big fronts near the root are cut into G groups, each its own workgroup: a group stores its
+// partial 64 x KB block in slab `slab + g`, and the group that arrives LAST (atomic ticket `cnt`, nobody waits)
+// adds the G slabs in fixed order and finishes the tile -- bitwise reproducible, no extra launch.
+struct WgRec {
+  int f, tile, s0, s1;
+  int slab, cnt, G, flags;  // flags: bit 0 = mode 1, bit 1 = the front has children (carries to gather), bits 8.. = group
+};
+
 struct LevelArgs {
-  const int2* wg;  // per workgroup of the level: (front, tile); fronts largest first
+  const WgRec* wg;
+  double* P;      // partial slabs, 64 x KBMAX each
+  int* tickets;   // one per split tile, zero between sweeps
   int kb;
 };
 
 constexpr int TILE_IT = TW * TW / kThreads;  // 16 matrix elements per lane and tile
 
-// rows of the forward carry with more than kGS - 1 ... contributors: the surplus children are summed into an
+// rows of the forward carry with more than kGS contributors: the surplus children are summed into an
 // extra row first (fixed order), which the last gather slot of the destination row then points to
 __global__ void overflow_sum_kernel(int nrows, const int* __restrict__ ov_ptr, const int* __restrict__ ov_src,
                                     int64_t first_row, int kb, double* V) {
@@ -514,13 +529,44 @@ __global__ void overflow_sum_kernel(int nrows, const int* __restrict__ ov_ptr, c
   V[(first_row + x) * kb + c] = s;
 }
 
-// Forward sweep, one level: workgroup (front f, row tile rt) forms
-//   rt <  ns/64 : z(rt)   =  sum_{ct <= rt} T(rt, ct)  v1(ct)            -> Y = S z  (right-hand side of L^T x = S z)
-//   rt >= ns/64 : carry   =  children's carries - sum_ct M21(rt, ct) v1(ct)  -> border rows of the front's V slice
-// with v1 = alpha * X[own rows] + the children's carries on the front's own rows, gathered on the fly through
-// gsrc (kGS source rows per row of V, -1 = none; fixed summation order, no atomics).  Matrix tiles and vector
-// blocks are register staged one tile ahead (the gather indices two tiles ahead), so the loads of step t+1 are
-// in flight while step t multiplies.
+// Joins the G partial blocks of a split tile.  Returns false for all but the last group to arrive; for that one
+// acc holds the sum of the slabs 0..G-1 (fixed order) on return.
+template <int KPT>
+__device__ __forceinline__ bool fold_groups(const WgRec& w, const LevelArgs& la, double (&acc)[Tile<KPT>::NOUT]) {
+  using T = Tile<KPT>;
+  __shared__ int last;
+  double* Pp = la.P + static_cast<int64_t>(w.slab) * (TW * KBMAX);
+#pragma unroll
+  for (int t = 0; t < T::NOUT; ++t) {
+    int o, c;
+    T::coords(t, o, c);
+    Pp[static_cast<int64_t>(w.flags >> 8) * (TW * KBMAX) + o * KBMAX + c] = acc[t];
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = (atomicAdd(la.tickets + w.cnt, 1) == w.G - 1) ? 1 : 0;
+  __syncthreads();
+  if (!last) return false;
+  __threadfence();
+  if (threadIdx.x == 0) la.tickets[w.cnt] = 0;  // ready for the next sweep
+#pragma unroll
+  for (int t = 0; t < T::NOUT; ++t) {
+    int o, c;
+    T::coords(t, o, c);
+    double s = 0.0;
+    for (int gg = 0; gg < w.G; ++gg) s += Pp[static_cast<int64_t>(gg) * (TW * KBMAX) + o * KBMAX + c];
+    acc[t] = s;
+  }
+  return true;
+}
+
+// Forward sweep, one level.  For front f with v1 = alpha * X[own rows] + the children's carries on the own rows
+// (gathered on the fly through gsrc: kGS source rows per row of V, -1 = none; fixed summation order):
+//   own row tile rt    : z(rt)  =  sum_{ct <= rt} T(rt, ct) v1(ct)                    -> Y = S z
+//   border row tile rt : carry  =  children's carries - sum_ct M21(rt, ct) v1(ct)     -> border rows of the front's V slice
+// Matrix tiles and vector blocks are register staged one step ahead (the gather indices two), so the loads of
+// step t+1 are in flight while step t multiplies.  Masked lanes load from a zero word (address select): a branch
+// around the load would serialise the loads of a tile.
 template <int KPT>
 __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
                                                             const double* __restrict__ Tb, const double* X, int ldx,
@@ -529,37 +575,34 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
   constexpr int IT = KPT;  // vector elements per lane: (64 x KB) / 256
   __shared__ double As[TW * TLD];
   __shared__ double Bs[TW * T::BLD];
-  const int2 wg = la.wg[blockIdx.x];
-  const int f = wg.x, rt = wg.y;
+  const WgRec w = la.wg[blockIdx.x];
+  const int f = w.f;
   const int kb = la.kb;
   const int ns = fa.ns[f];
   const int d = ns + fa.bs[f];
   const int nst = (ns + TW - 1) / TW;
-  const bool own = rt < nst;
-  const int row0 = own ? rt * TW : ns + (rt - nst) * TW;
-  const int rows = min(TW, (own ? ns : d) - row0);
-  const int nct = own ? rt + 1 : nst;
-  const int64_t ld = own ? ns : d;
-  const double* Rp = (own ? Tb + fa.toff[f] : F + fa.foff[f]) + row0;  // element (r, col) at col*ld + r
+  const bool single = (w.flags & 1) != 0, kids = (w.flags & 2) != 0;
   const int64_t vbase = fa.voff[f];
-  const int ar = threadIdx.x & (TW - 1), ajb = threadIdx.x >> 6;       // lane -> (row, first column) of a matrix tile
+  const double* Tf = Tb + fa.toff[f];
+  const double* Ff = F + fa.foff[f];
+  const int ar = threadIdx.x & (TW - 1), ajb = threadIdx.x >> 6;  // lane -> (row, first column) of a matrix tile
 
   int gi[IT][kGS], xi[IT];
   double bv[IT], av[TILE_IT];
 
   auto fetch_idx = [&](int ct) {
-    const int w = min(TW, ns - ct * TW);
+    const int wd = min(TW, ns - ct * TW);
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
       const int r = (threadIdx.x + e * kThreads) / T::KB;
       const int64_t vrow = vbase + ct * TW + r;
-      const bool ok = r < w;
+      const bool ok = r < wd;
       xi[e] = *(ok ? fa.v_src + vrow : fa.neg1);
 #pragma unroll
-      for (int s = 0; s < kGS; ++s) gi[e][s] = *(ok ? fa.gsrc + vrow * kGS + s : fa.neg1);
+      for (int s = 0; s < kGS; ++s) gi[e][s] = *((ok && kids) ? fa.gsrc + vrow * kGS + s : fa.neg1);
     }
   };
-  auto fetch_val = [&](int ct) {
+  auto fetch_b = [&]() {
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
       const int c = (threadIdx.x + e * kThreads) & (T::KB - 1);
@@ -569,55 +612,41 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
       for (int s = 0; s < kGS; ++s) v += *((cok && gi[e][s] >= 0) ? V + static_cast<int64_t>(gi[e][s]) * kb + c : fa.zero);
       bv[e] = v;
     }
-    const int w = min(TW, ns - ct * TW);
-    const double* Ap = Rp + static_cast<int64_t>(ct) * TW * ld + ar;
+  };
+  // tile (row tile rt, column tile ct) of [T; M21]: element (r, j) at base + j*ld + r
+  auto fetch_a = [&](int rt, int ct) {
+    const bool own = rt < nst;
+    const int row0 = own ? rt * TW : ns + (rt - nst) * TW;
+    const int rows = min(TW, (own ? ns : d) - row0);
+    const int64_t ld = own ? ns : d;
+    const int wd = min(TW, ns - ct * TW);
+    const double* Ap = (own ? Tf : Ff) + static_cast<int64_t>(ct) * TW * ld + row0 + ar;
 #pragma unroll
     for (int it = 0; it < TILE_IT; ++it) {
       const int j = ajb + it * (kThreads / TW);
-      av[it] = *((j < w && ar < rows) ? Ap + static_cast<int64_t>(j) * ld : fa.zero);
+      av[it] = *((j < wd && ar < rows) ? Ap + static_cast<int64_t>(j) * ld : fa.zero);
     }
   };
-  auto commit = [&]() {
+  auto commit_a = [&]() {
 #pragma unroll
     for (int it = 0; it < TILE_IT; ++it) As[(ajb + it * (kThreads / TW)) * TLD + ar] = av[it];  // As[k][o] = R(row0 + o, ct*64 + k)
+  };
+  auto commit_b = [&]() {
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
       const int idx = threadIdx.x + e * kThreads;
       Bs[(idx / T::KB) * T::BLD + (idx & (T::KB - 1))] = bv[e];
     }
   };
-
-  double acc[T::NOUT];
-#pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
-  fetch_idx(0);
-  fetch_val(0);
-  if (nct > 1) fetch_idx(1);
-  for (int ct = 0; ct < nct; ++ct) {
-    commit();
-    __syncthreads();
-    if (ct + 1 < nct) {
-      fetch_val(ct + 1);
-      if (ct + 2 < nct) fetch_idx(ct + 2);
-    }
-    T::mac(As, Bs, min(TW, ns - ct * TW), acc);
-    __syncthreads();
-  }
-  if (own) {
-    const double* sgp = fa.sgn + fa.c0[f] + row0;
-    double* Yf = Y + (vbase + row0) * kb;
+  // children's carries on the rows of output tile rt (border tiles), in the lane's output layout
+  auto fetch_carry = [&](int rt, double (&cg)[T::NOUT]) {
+    const int row0 = ns + (rt - nst) * TW;
+    const int rows = min(TW, d - row0);
 #pragma unroll
     for (int t = 0; t < T::NOUT; ++t) {
       int o, c;
       T::coords(t, o, c);
-      if (o < rows && c < kb) Yf[static_cast<int64_t>(o) * kb + c] = sgp[o] * acc[t];
-    }
-  } else {
-#pragma unroll
-    for (int t = 0; t < T::NOUT; ++t) {
-      int o, c;
-      T::coords(t, o, c);
-      const bool ok = o < rows && c < kb;
+      const bool ok = kids && o < rows && c < kb;
       const int64_t vrow = vbase + row0 + o;
       double v = 0.0;
 #pragma unroll
@@ -625,57 +654,117 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
         const int g = *(ok ? fa.gsrc + vrow * kGS + s : fa.neg1);
         v += *((g >= 0) ? V + static_cast<int64_t>(g) * kb + c : fa.zero);
       }
-      if (ok) V[vrow * kb + c] = v - acc[t];
+      cg[t] = v;
     }
+  };
+  auto store_tile = [&](int rt, const double (&acc)[T::NOUT], const double (&cg)[T::NOUT]) {
+    const bool own = rt < nst;
+    const int row0 = own ? rt * TW : ns + (rt - nst) * TW;
+    const int rows = min(TW, (own ? ns : d) - row0);
+    if (own) {
+      const double* sgp = fa.sgn + fa.c0[f] + row0;
+      double* Yf = Y + (vbase + row0) * kb;
+#pragma unroll
+      for (int t = 0; t < T::NOUT; ++t) {
+        int o, c;
+        T::coords(t, o, c);
+        if (o < rows && c < kb) Yf[static_cast<int64_t>(o) * kb + c] = sgp[o] * acc[t];
+      }
+    } else {
+      double* Vf = V + (vbase + row0) * kb;
+#pragma unroll
+      for (int t = 0; t < T::NOUT; ++t) {
+        int o, c;
+        T::coords(t, o, c);
+        if (o < rows && c < kb) Vf[static_cast<int64_t>(o) * kb + c] = cg[t] - acc[t];
+      }
+    }
+  };
+
+  double acc[T::NOUT], cg[T::NOUT];
+#pragma unroll
+  for (int t = 0; t < T::NOUT; ++t) acc[t] = cg[t] = 0.0;
+
+  if (single) {  // one column tile: v1 is loaded once, the row tiles [s0, s1) are walked with it
+    fetch_idx(0);
+    fetch_b();
+    fetch_a(w.s0, 0);
+    commit_b();
+    for (int rt = w.s0; rt < w.s1; ++rt) {
+      commit_a();
+      __syncthreads();
+      if (rt + 1 < w.s1) fetch_a(rt + 1, 0);
+      if (rt >= nst) fetch_carry(rt, cg);
+#pragma unroll
+      for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
+      T::mac(As, Bs, ns, acc);
+      store_tile(rt, acc, cg);
+      __syncthreads();
+    }
+    return;
   }
+
+  const int rt = w.tile;
+  fetch_idx(w.s0);
+  fetch_b();
+  fetch_a(rt, w.s0);
+  if (w.s0 + 1 < w.s1) fetch_idx(w.s0 + 1);
+  for (int ct = w.s0; ct < w.s1; ++ct) {
+    commit_a();
+    commit_b();
+    __syncthreads();
+    if (ct + 1 < w.s1) {
+      fetch_b();
+      fetch_a(rt, ct + 1);
+      if (ct + 2 < w.s1) fetch_idx(ct + 2);
+    }
+    T::mac(As, Bs, min(TW, ns - ct * TW), acc);
+    __syncthreads();
+  }
+  if (w.G > 1 && !fold_groups<KPT>(w, la, acc)) return;
+  if (rt >= nst) fetch_carry(rt, cg);
+  store_tile(rt, acc, cg);
 }
 
 // Backward sweep, one level: workgroup (front f, column tile ct) forms
 //   x1(ct) = sum_{rt >= ct} T(rt, ct)^T y(rt)  -  sum_bt M21(bt, ct)^T x_border(bt)
-// y = S z from the forward sweep (Y), x_border read from the parent's slice of V through the relative index
-// list (workgroup ct = 0 mirrors it into the front's own border rows for its children).  The solution goes to
-// the front's own rows of V and straight to the caller's block Out.
+// y = S z from the forward sweep (Y); x_border are rows of the caller's block Out that the ancestors' launches
+// have already written (bout = their row numbers).  The solution goes straight to Out.
 template <int KPT>
 __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
                                                             const double* __restrict__ Tb,
-                                                            const double* __restrict__ Y, double* V, double* Out,
-                                                            int ldo) {
+                                                            const double* __restrict__ Y, double* Out, int ldo) {
   using T = Tile<KPT>;
   constexpr int IT = KPT;
   __shared__ double As[TW * TLD];
   __shared__ double Bs[TW * T::BLD];
-  const int2 wg = la.wg[blockIdx.x];
-  const int f = wg.x, ct = wg.y;
+  const WgRec w = la.wg[blockIdx.x];
+  const int f = w.f, ct = w.tile;
   const int kb = la.kb;
   const int ns = fa.ns[f], bs = fa.bs[f];
   const int d = ns + bs;
-  const int p = fa.parent[f];
   const int nst = (ns + TW - 1) / TW;
   const int c0t = ct * TW;
   const int wc = min(TW, ns - c0t);
   const int nown = nst - ct;
-  const int nbt = (p >= 0) ? (bs + TW - 1) / TW : 0;
-  const int ntile = nown + nbt;
   const int64_t vbase = fa.voff[f];
   const double* Tp = Tb + fa.toff[f] + static_cast<int64_t>(c0t) * ns;   // T(r, c0t + o) at o*ns + r
-  const double* Mp = F + fa.foff[f] + static_cast<int64_t>(c0t) * d;     // M21 / L(r, c0t + o) at o*d + r
-  const int* __restrict__ rel = fa.rel + fa.bptr[f];
-  const double* Vp = V + fa.voff[p >= 0 ? p : f] * kb;
+  const double* Mp = F + fa.foff[f] + static_cast<int64_t>(c0t) * d;     // M21(r, c0t + o) at o*d + r
+  const int* __restrict__ bout = fa.bout + fa.bptr[f];
   const int ar = threadIdx.x & (TW - 1), ajb = threadIdx.x >> 6;
 
   int ri[IT];
   double bv[IT], av[TILE_IT];
-  int pend_rbase = 0, pend_rows = 0;
-  bool pend_border = false;
+  int pend_rows = 0;
 
-  auto fetch_idx = [&](int t) {  // border tiles only: rows of the parent's slice
+  auto fetch_idx = [&](int t) {  // border tiles only: rows of Out
     if (t < nown) return;
     const int b0 = (t - nown) * TW;
     const int rows = min(TW, bs - b0);
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
       const int r = (threadIdx.x + e * kThreads) / T::KB;
-      ri[e] = *((r < rows) ? rel + b0 + r : fa.neg1);
+      ri[e] = *((r < rows) ? bout + b0 + r : fa.neg1);
     }
   };
   auto fetch_val = [&](int t) {
@@ -694,7 +783,7 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
 #pragma unroll
       for (int e = 0; e < IT; ++e) {
         const int c = (threadIdx.x + e * kThreads) & (T::KB - 1);
-        bv[e] = -*((ri[e] >= 0 && c < kb) ? Vp + static_cast<int64_t>(ri[e]) * kb + c : fa.zero);
+        bv[e] = -*((ri[e] >= 0 && c < kb) ? Out + static_cast<int64_t>(ri[e]) * ldo + c : fa.zero);
       }
     }
     const double* Ap = (border ? Mp : Tp) + rbase + ar;
@@ -704,8 +793,6 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
       const int j = ajb + it * (kThreads / TW);
       av[it] = *((j < wc && ar < rows) ? Ap + static_cast<int64_t>(j) * ld : fa.zero);
     }
-    pend_border = border;
-    pend_rbase = rbase;
     pend_rows = rows;
   };
   auto commit = [&]() {
@@ -714,38 +801,33 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
       const int idx = threadIdx.x + e * kThreads;
-      const int r = idx / T::KB, c = idx & (T::KB - 1);
-      Bs[r * T::BLD + c] = bv[e];
-      if (pend_border && ct == 0 && r < pend_rows && c < kb) V[(vbase + pend_rbase + r) * kb + c] = -bv[e];
+      Bs[(idx / T::KB) * T::BLD + (idx & (T::KB - 1))] = bv[e];
     }
   };
 
   double acc[T::NOUT];
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
-  fetch_idx(0);
-  fetch_val(0);
-  if (ntile > 1) fetch_idx(1);
-  for (int t = 0; t < ntile; ++t) {
+  fetch_idx(w.s0);
+  fetch_val(w.s0);
+  if (w.s0 + 1 < w.s1) fetch_idx(w.s0 + 1);
+  for (int t = w.s0; t < w.s1; ++t) {
     const int kdim = pend_rows;
     commit();
     __syncthreads();
-    if (t + 1 < ntile) {
+    if (t + 1 < w.s1) {
       fetch_val(t + 1);
-      if (t + 2 < ntile) fetch_idx(t + 2);
+      if (t + 2 < w.s1) fetch_idx(t + 2);
     }
     T::mac(As, Bs, kdim, acc);
     __syncthreads();
   }
-  double* Vf = V + (vbase + c0t) * kb;
+  if (w.G > 1 && !fold_groups<KPT>(w, la, acc)) return;
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) {
     int o, c;
     T::coords(t, o, c);
-    if (o < wc && c < kb) {
-      Vf[static_cast<int64_t>(o) * kb + c] = acc[t];
-      Out[static_cast<int64_t>(fa.v_src[vbase + c0t + o]) * ldo + c] = acc[t];
-    }
+    if (o < wc && c < kb) Out[static_cast<int64_t>(fa.v_src[vbase + c0t + o]) * ldo + c] = acc[t];
   }
 }
 
@@ -762,8 +844,11 @@ struct eigd_factor {
   int64_t *d_foff = nullptr, *d_voff = nullptr, *d_ioff = nullptr, *d_bptr = nullptr;
   int *d_lvl_fronts = nullptr, *d_pref_chunks = nullptr, *d_pref_tiles = nullptr, *d_cs_child = nullptr;
   // sweeps: per-level workgroup prefixes (forward: row tiles of [T; M21], backward: column tiles), gather lists
-  int2 *d_fwd_wg = nullptr, *d_bwd_wg = nullptr;
-  int *d_tri_pref = nullptr, *d_m_pref = nullptr;
+  WgRec *d_fwd_wg = nullptr, *d_bwd_wg = nullptr;
+  int *d_tri_pref = nullptr, *d_m_pref = nullptr, *d_bout = nullptr, *d_tickets = nullptr;
+  double* d_P = nullptr;
+  int64_t n_slabs = 0;
+  int n_tickets = 0;
   int *d_gsrc = nullptr, *d_ov_ptr = nullptr, *d_ov_src = nullptr;
   int64_t* d_toff = nullptr;
   double *d_T = nullptr, *d_aux = nullptr;  // aux: {0.0, (int) -1}
@@ -794,6 +879,7 @@ struct eigd_factor {
     a.toff = d_toff;
     a.gsrc = d_gsrc;
     a.v_src = d_v_src;
+    a.bout = d_bout;
     a.sgn = d_sgn;
     a.zero = d_aux;
     a.neg1 = reinterpret_cast<const int*>(d_aux + 1);
@@ -878,13 +964,15 @@ int numeric(eigd_factor* f, const double* hdata) {
 }
 
 template <int KPT>
-int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, const double* dIn, int ldin, double* dX, int ldx,
-          int kb, double alpha) {
+int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, int* wT, const double* dIn, int ldin,
+          double* dX, int ldx, int kb, double alpha) {
   const Symbolic& s = *f->sym;
   const FrontArrays fa = f->fa();
-  auto level_args = [&](const int2* wg) {
+  auto level_args = [&](const WgRec* wg) {
     LevelArgs la;
     la.wg = wg;
+    la.P = wP;
+    la.tickets = wT;
     la.kb = kb;
     return la;
   };
@@ -903,12 +991,12 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, const double* 
                        level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
     EIGD_LAUNCH_CHECK();
   }
-  // ---- backward: root -> leaves.  V receives the solution front by front, dX the caller's rows.
+  // ---- backward: root -> leaves, straight into the caller's block.
   for (int l = s.nlevels - 1; l >= 0; --l) {
     const int nwg = f->h_bwd_ptr[l + 1] - f->h_bwd_ptr[l];
     if (nwg == 0) continue;
     hipLaunchKernelGGL(bwd_level_kernel<KPT>, dim3(nwg), dim3(kThreads), 0, st, fa,
-                       level_args(f->d_bwd_wg + f->h_bwd_ptr[l]), f->d_F, f->d_T, wY, wV, dX, ldx);
+                       level_args(f->d_bwd_wg + f->h_bwd_ptr[l]), f->d_F, f->d_T, wY, dX, ldx);
     EIGD_LAUNCH_CHECK();
   }
   return EIGD_OK;
@@ -1014,7 +1102,8 @@ int eigd_factor_free(eigd_factor* f) {
                   f->d_pref_tiles, f->d_cs_child,   f->d_a_src,      f->d_a_dst,    f->d_v_src, f->d_data,
                   f->d_F,         f->d_Inv,         f->d_V,          f->d_Y,        f->d_flag,  f->d_fwd_wg,
                   f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_gsrc,     f->d_ov_ptr, f->d_ov_src,
-                  f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux};
+                  f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux,      f->d_bout,  f->d_tickets,
+                  f->d_P};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;
@@ -1036,19 +1125,68 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     tri_pref[q + 1] = tri_pref[q] + static_cast<int>((ns + s.W - 1) / s.W);
     m_pref[q + 1] = m_pref[q] + (s.f_bs[q] + TW - 1) / TW;
   }
-  // workgroup records (front, tile) per level; within a front the longest reductions first
-  std::vector<int2> fwd_wg, bwd_wg;
+  // workgroup records per level (see WgRec).  Levels with few fronts cut their long chains into groups.
+  std::vector<char> has_kids(static_cast<size_t>(nf), 0);
+  for (int c = 0; c < nf; ++c)
+    if (s.f_parent[c] >= 0 && s.f_bs[c] > 0) has_kids[s.f_parent[c]] = 1;
+  std::vector<WgRec> fwd_wg, bwd_wg;
   std::vector<int> h_fwd_ptr(static_cast<size_t>(s.nlevels) + 1, 0), h_bwd_ptr(static_cast<size_t>(s.nlevels) + 1, 0);
+  int64_t fwd_slabs = 0, bwd_slabs = 0;
+  int n_tickets = 0;
+  auto push_chain = [&](std::vector<WgRec>& out, int64_t& slabs, int fr, int tile, int L, bool split, int flags) {
+    const int G = (split && L > 8) ? std::min(8, (L + 5) / 6) : 1;
+    for (int g = 0; g < G; ++g) {
+      WgRec w;
+      w.f = fr;
+      w.tile = tile;
+      w.s0 = static_cast<int>(static_cast<int64_t>(L) * g / G);
+      w.s1 = static_cast<int>(static_cast<int64_t>(L) * (g + 1) / G);
+      w.slab = static_cast<int>(slabs);
+      w.cnt = n_tickets;
+      w.G = G;
+      w.flags = flags | (g << 8);
+      out.push_back(w);
+    }
+    if (G > 1) {
+      slabs += G;
+      ++n_tickets;
+    }
+  };
   for (int l = 0; l < s.nlevels; ++l) {
+    const int nfl = s.lvl_ptr[l + 1] - s.lvl_ptr[l];
+    const bool sparse_level = nfl < 256;  // few fronts: parallelism has to come from inside the fronts
+    const bool split_level = nfl <= 8;    // the join of split chains costs a device-scope fence: only near the root
     for (int q = s.lvl_ptr[l]; q < s.lvl_ptr[l + 1]; ++q) {
       const int fr = s.lvl_fronts[q];
       const int nst = (s.f_ns[fr] + TW - 1) / TW, nbt = (s.f_bs[fr] + TW - 1) / TW;
-      for (int t = nst + nbt - 1; t >= 0; --t) fwd_wg.push_back(make_int2(fr, t));  // border tiles (nst products) first
-      for (int t = 0; t < nst; ++t) bwd_wg.push_back(make_int2(fr, t));              // ct = 0 walks the most tiles
+      const int kids = has_kids[fr] ? 2 : 0;
+      if (nst == 1) {  // single column tile: the right-hand side block is loaded once per workgroup
+        const int per = sparse_level ? 1 : nst + nbt;
+        for (int t = 0; t < nst + nbt; t += per) {
+          WgRec w;
+          w.f = fr;
+          w.tile = 0;
+          w.s0 = t;
+          w.s1 = std::min(nst + nbt, t + per);
+          w.slab = w.cnt = 0;
+          w.G = 1;
+          w.flags = 1 | kids;
+          fwd_wg.push_back(w);
+        }
+      } else {
+        for (int t = nst + nbt - 1; t >= 0; --t)  // border tiles (nst products) first, then the own tiles, longest first
+          push_chain(fwd_wg, fwd_slabs, fr, t, t < nst ? t + 1 : nst, split_level, kids);
+      }
+      const int nbt_b = (s.f_parent[fr] >= 0) ? nbt : 0;
+      for (int t = 0; t < nst; ++t) push_chain(bwd_wg, bwd_slabs, fr, t, nst - t + nbt_b, split_level, 0);
     }
     h_fwd_ptr[l + 1] = static_cast<int>(fwd_wg.size());
     h_bwd_ptr[l + 1] = static_cast<int>(bwd_wg.size());
   }
+  const int64_t n_slabs = std::max<int64_t>(1, std::max(fwd_slabs, bwd_slabs));
+  // rows of the caller's block behind every border entry (backward sweep gathers x there)
+  std::vector<int> bout(s.border.size());
+  for (size_t e = 0; e < s.border.size(); ++e) bout[e] = s.perm[s.border[e]];
   // gather lists of the forward carries: row (voff[p] + rel[i]) of the parent receives row (voff[c] + ns_c + i) of
   // child c; children in ascending front order.  Rows with more than kGS contributors sum the surplus into an
   // extra row first (overflow_sum_kernel) that the last slot points to.
@@ -1091,7 +1229,8 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
 
   size_t free_b = 0, total_b = 0;
   EIGD_HIP(hipMemGetInfo(&free_b, &total_b));
-  const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + toff[nf] + 2 * v_rows * KBMAX) +
+  const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + toff[nf] + 2 * v_rows * KBMAX +
+                                        n_slabs * TW * KBMAX) +
                       16 * s.a_src.size() + 4 * gsrc.size() + (size_t(64) << 20);
   if (need > free_b) {
     set_error("factor needs %.2f GiB of device memory, %.2f GiB free", need / 1073741824.0, free_b / 1073741824.0);
@@ -1105,6 +1244,8 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   f->ov_lvl_ptr = ov_lvl_ptr;
   f->t_doubles = toff[nf];
   f->v_rows = v_rows;
+  f->n_slabs = n_slabs;
+  f->n_tickets = std::max(1, n_tickets);
   f->n_tri = tri_pref[nf];
   f->n_m21 = m_pref[nf];
   int rc = EIGD_OK;
@@ -1124,6 +1265,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   UP(d_pref_tiles, s.pref_tiles)
   UP(d_fwd_wg, fwd_wg)
   UP(d_bwd_wg, bwd_wg)
+  UP(d_bout, bout)
   UP(d_tri_pref, tri_pref)
   UP(d_m_pref, m_pref)
   UP(d_toff, toff)
@@ -1155,6 +1297,16 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   rc = dmalloc(&f->d_Inv, s.inv_doubles);
   rc = dmalloc(&f->d_T, static_cast<size_t>(f->t_doubles));
   rc = dmalloc(&f->d_aux, 2);
+  rc = dmalloc(&f->d_P, static_cast<size_t>(n_slabs) * TW * KBMAX);
+  if (rc == EIGD_OK) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_tickets), sizeof(int) * f->n_tickets);
+    if (e != hipSuccess) {
+      set_error("hipMalloc failed: %s", hipGetErrorString(e));
+      rc = EIGD_E_HIP;
+    } else {
+      e = hipMemset(f->d_tickets, 0, sizeof(int) * f->n_tickets);
+    }
+  }
   rc = dmalloc(&f->d_V, static_cast<size_t>(v_rows) * KBMAX);
   rc = dmalloc(&f->d_Y, static_cast<size_t>(s.sumd) * KBMAX);
   rc = dmalloc(&f->d_sgn, static_cast<size_t>(s.n));
@@ -1203,21 +1355,21 @@ int eigd_factor_solve(eigd_factor* f, double* dX, int ldx, int k, double alpha) 
   return eigd_factor_solve_to(f, dX, ldx, dX, ldx, k, alpha);
 }
 
-static int solve_blocks(eigd_factor* f, hipStream_t st, double* wV, double* wY, const double* dIn, int ldin,
-                        double* dOut, int ldout, int k, double alpha) {
+static int solve_blocks(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, int* wT, const double* dIn,
+                        int ldin, double* dOut, int ldout, int k, double alpha) {
   EIGD_REQUIRE(f && dIn && dOut, "null argument");
   EIGD_REQUIRE(k >= 1 && ldin >= k && ldout >= k, "bad block shape k=%d ldin=%d ldout=%d", k, ldin, ldout);
   for (int c0 = 0; c0 < k; c0 += KBMAX) {
     const int kb = std::min(KBMAX, k - c0);
     int rc;
     if (kb <= 4)
-      rc = sweep<1>(f, st, wV, wY, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
+      rc = sweep<1>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else if (kb <= 8)
-      rc = sweep<2>(f, st, wV, wY, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
+      rc = sweep<2>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else if (kb <= 16)
-      rc = sweep<4>(f, st, wV, wY, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
+      rc = sweep<4>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else
-      rc = sweep<8>(f, st, wV, wY, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
+      rc = sweep<8>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     if (rc != EIGD_OK) return rc;
   }
   return EIGD_OK;
@@ -1225,7 +1377,7 @@ static int solve_blocks(eigd_factor* f, hipStream_t st, double* wV, double* wY, 
 
 int eigd_factor_solve_to(eigd_factor* f, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha) {
   EIGD_REQUIRE(f, "null argument");
-  return solve_blocks(f, f->ctx->stream, f->d_V, f->d_Y, dIn, ldin, dOut, ldout, k, alpha);
+  return solve_blocks(f, f->ctx->stream, f->d_V, f->d_Y, f->d_P, f->d_tickets, dIn, ldin, dOut, ldout, k, alpha);
 }
 
 // A lane = a second set of sweep workspaces bound to another context (stream) of the same device: sweeps of
@@ -1233,7 +1385,8 @@ int eigd_factor_solve_to(eigd_factor* f, const double* dIn, int ldin, double* dO
 struct eigd_lane {
   eigd_factor* f = nullptr;
   eigd_ctx* ctx = nullptr;
-  double *V = nullptr, *Y = nullptr;
+  double *V = nullptr, *Y = nullptr, *P = nullptr;
+  int* tickets = nullptr;
 };
 
 int eigd_factor_lane_create(eigd_factor* f, eigd_ctx* ctx, eigd_lane** out) {
@@ -1248,7 +1401,10 @@ int eigd_factor_lane_create(eigd_factor* f, eigd_ctx* ctx, eigd_lane** out) {
   const size_t yb = sizeof(double) * std::max<size_t>(static_cast<size_t>(s.sumd) * KBMAX, 1);
   hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&l->V), vb);
   hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&l->Y), yb);
-  if (e1 != hipSuccess || e2 != hipSuccess) {
+  hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&l->P), sizeof(double) * static_cast<size_t>(f->n_slabs) * TW * KBMAX);
+  hipError_t e4 = hipMalloc(reinterpret_cast<void**>(&l->tickets), sizeof(int) * f->n_tickets);
+  if (e4 == hipSuccess) e4 = hipMemset(l->tickets, 0, sizeof(int) * f->n_tickets);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
     eigd_factor_lane_free(l);
     set_error("hipMalloc failed for a sweep lane");
     return EIGD_E_HIP;
@@ -1262,13 +1418,15 @@ int eigd_factor_lane_free(eigd_lane* l) {
   if (l->ctx && l->ctx->stream) (void)hipStreamSynchronize(l->ctx->stream);
   if (l->V) (void)hipFree(l->V);
   if (l->Y) (void)hipFree(l->Y);
+  if (l->P) (void)hipFree(l->P);
+  if (l->tickets) (void)hipFree(l->tickets);
   delete l;
   return EIGD_OK;
 }
 
 int eigd_factor_lane_solve_to(eigd_lane* l, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha) {
   EIGD_REQUIRE(l, "null argument");
-  return solve_blocks(l->f, l->ctx->stream, l->V, l->Y, dIn, ldin, dOut, ldout, k, alpha);
+  return solve_blocks(l->f, l->ctx->stream, l->V, l->Y, l->P, l->tickets, dIn, ldin, dOut, ldout, k, alpha);
 }
 
 int eigd_factor_stats(eigd_factor* f, double* out, int nout) {
