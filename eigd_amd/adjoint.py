@@ -428,14 +428,29 @@ def solve_shifted_lstsq(alpha, H, r):
     return y, np.linalg.norm(H0 @ y - r)
 
 
+_REORTH_TOL = 1e-13
+
+
 def _cgs2(Wst, T, ns, c0=0):
-    """T <- (I - W W^T) T twice over the first ns slabs (columns c0.. of the stack); returns the summed coefficients"""
+    """
+    T <- (I - W W^T) T over the first ns slabs (columns c0.. of the stack); returns the coefficients.
+
+    Classical Gram-Schmidt with a measured second pass: the first projection h1 = W^T T is subtracted and what
+    is left along W, h2 = W^T (T - W h1), is measured in the same pass over the stack.  h2 / h1 is the loss of
+    orthogonality that one-pass Gram-Schmidt would leave behind; it is subtracted (third pass) only when it
+    exceeds 1e-13 for some column -- the reference's modified Gram-Schmidt (eigenvector_derivatives.py:1254-1256)
+    leaves O(eps * cond) there, orders of magnitude more.
+    """
     h1 = Wst.dot(T, ns=ns, c0=c0)
     if ns <= 32:  # fused: subtract the first projection and measure what is left in one pass over W
         h2 = Wst.axpy_dot_into(T, h1, alpha=-1.0, c0=c0)
     else:
         Wst.axpy_into(T, h1, alpha=-1.0, c0=c0)
         h2 = Wst.dot(T, ns=ns, c0=c0)
+    n1 = np.sqrt(np.sum(h1 * h1, axis=0))
+    n2 = np.sqrt(np.sum(h2 * h2, axis=0))
+    if not np.any(n2 > _REORTH_TOL * n1):
+        return h1
     Wst.axpy_into(T, h2, alpha=-1.0, c0=c0)
     return h1 + h2
 

@@ -20,6 +20,7 @@
 // Per solve the kernels stream nnz(L) doubles twice (forward + backward) plus
 // O(sum of front dimensions) x k vector traffic: HBM bound for k <= 32.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -506,6 +507,9 @@ struct Tile {
 struct WgRec {
   int f, tile, s0, s1;
   int slab, cnt, G, flags;  // flags: bit 0 = mode 1, bit 1 = the front has children (carries to gather), bits 8.. = group
+  // the front's own numbers ride along: one scalar load instead of a second dependent round of them
+  int ns, bs, c0, parent;
+  int64_t voff, foff, toff, bptr;
 };
 
 struct LevelArgs {
@@ -530,31 +534,37 @@ __global__ void overflow_sum_kernel(int nrows, const int* __restrict__ ov_ptr, c
 }
 
 // Joins the G partial blocks of a split tile.  Returns false for all but the last group to arrive; for that one
-// acc holds the sum of the slabs 0..G-1 (fixed order) on return.
+// acc holds the sum of the slabs 0..G-1 (fixed order) on return.  Cross-workgroup hand-off inside a launch on
+// gfx950 (per-XCD L2s are not coherent): the slab is stored write-through (agent-scope relaxed atomic stores =
+// sc1), every wave drains its stores, ONE lane draws the ticket (relaxed, agent scope); the last arriver does ONE
+// agent-scope acquire before the workgroup reads the slabs with plain loads.
 template <int KPT>
-__device__ __forceinline__ bool fold_groups(const WgRec& w, const LevelArgs& la, double (&acc)[Tile<KPT>::NOUT]) {
+__device__ __forceinline__ bool fold_groups(const WgRec& w, const LevelArgs& la, double (&acc)[Tile<KPT>::NOUT],
+                                            int* sflag) {
   using T = Tile<KPT>;
-  __shared__ int last;
+  typedef unsigned long long u64;
   double* Pp = la.P + static_cast<int64_t>(w.slab) * (TW * KBMAX);
+  u64* mine = reinterpret_cast<u64*>(Pp + static_cast<int64_t>(w.flags >> 8) * (TW * KBMAX));
 #pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) {
-    int o, c;
-    T::coords(t, o, c);
-    Pp[static_cast<int64_t>(w.flags >> 8) * (TW * KBMAX) + o * KBMAX + c] = acc[t];
+  for (int t = 0; t < T::NOUT; ++t)  // lane-major slab layout: element t of lane l at t*256 + l
+    __hip_atomic_store(mine + t * kThreads + threadIdx.x, static_cast<u64>(__double_as_longlong(acc[t])),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    *sflag = (__hip_atomic_fetch_add(la.tickets + w.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == w.G - 1) ? 1 : 0;
+  __syncthreads();
+  if (*sflag == 0) return false;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(la.tickets + w.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next sweep
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) last = (atomicAdd(la.tickets + w.cnt, 1) == w.G - 1) ? 1 : 0;
-  __syncthreads();
-  if (!last) return false;
-  __threadfence();
-  if (threadIdx.x == 0) la.tickets[w.cnt] = 0;  // ready for the next sweep
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) {
-    int o, c;
-    T::coords(t, o, c);
     double s = 0.0;
-    for (int gg = 0; gg < w.G; ++gg) s += Pp[static_cast<int64_t>(gg) * (TW * KBMAX) + o * KBMAX + c];
+    for (int gg = 0; gg < w.G; ++gg) s += Pp[static_cast<int64_t>(gg) * (TW * KBMAX) + t * kThreads + threadIdx.x];
     acc[t] = s;
   }
   return true;
@@ -576,15 +586,14 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
   __shared__ double As[TW * TLD];
   __shared__ double Bs[TW * T::BLD];
   const WgRec w = la.wg[blockIdx.x];
-  const int f = w.f;
   const int kb = la.kb;
-  const int ns = fa.ns[f];
-  const int d = ns + fa.bs[f];
+  const int ns = w.ns;
+  const int d = ns + w.bs;
   const int nst = (ns + TW - 1) / TW;
   const bool single = (w.flags & 1) != 0, kids = (w.flags & 2) != 0;
-  const int64_t vbase = fa.voff[f];
-  const double* Tf = Tb + fa.toff[f];
-  const double* Ff = F + fa.foff[f];
+  const int64_t vbase = w.voff;
+  const double* Tf = Tb + w.toff;
+  const double* Ff = F + w.foff;
   const int ar = threadIdx.x & (TW - 1), ajb = threadIdx.x >> 6;  // lane -> (row, first column) of a matrix tile
 
   int gi[IT][kGS], xi[IT];
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
     }
   };
   // tile (row tile rt, column tile ct) of [T; M21]: element (r, j) at base + j*ld + r
-  auto fetch_a = [&](int rt, int ct) {
+  auto fetch_a = [&](int rt, int ct, double (&av)[TILE_IT]) {
     const bool own = rt < nst;
     const int row0 = own ? rt * TW : ns + (rt - nst) * TW;
     const int rows = min(TW, (own ? ns : d) - row0);
@@ -627,7 +636,7 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
       av[it] = *((j < wd && ar < rows) ? Ap + static_cast<int64_t>(j) * ld : fa.zero);
     }
   };
-  auto commit_a = [&]() {
+  auto commit_a = [&](const double (&av)[TILE_IT]) {
 #pragma unroll
     for (int it = 0; it < TILE_IT; ++it) As[(ajb + it * (kThreads / TW)) * TLD + ar] = av[it];  // As[k][o] = R(row0 + o, ct*64 + k)
   };
@@ -662,7 +671,7 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
     const int row0 = own ? rt * TW : ns + (rt - nst) * TW;
     const int rows = min(TW, (own ? ns : d) - row0);
     if (own) {
-      const double* sgp = fa.sgn + fa.c0[f] + row0;
+      const double* sgp = fa.sgn + w.c0 + row0;
       double* Yf = Y + (vbase + row0) * kb;
 #pragma unroll
       for (int t = 0; t < T::NOUT; ++t) {
@@ -685,21 +694,33 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) acc[t] = cg[t] = 0.0;
 
+  constexpr bool kDeep = false;  // a second matrix tile in flight costs occupancy (130..172 VGPRs): measured slower
   if (single) {  // one column tile: v1 is loaded once, the row tiles [s0, s1) are walked with it
-    fetch_idx(0);
-    fetch_b();
-    fetch_a(w.s0, 0);
-    commit_b();
-    for (int rt = w.s0; rt < w.s1; ++rt) {
-      commit_a();
+    auto step = [&](int rt, double (&cur)[TILE_IT], int nxt) {
+      commit_a(cur);
       __syncthreads();
-      if (rt + 1 < w.s1) fetch_a(rt + 1, 0);
+      if (nxt < w.s1) fetch_a(nxt, 0, cur);
       if (rt >= nst) fetch_carry(rt, cg);
 #pragma unroll
       for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
       T::mac(As, Bs, ns, acc);
       store_tile(rt, acc, cg);
       __syncthreads();
+    };
+    fetch_idx(0);
+    fetch_b();
+    fetch_a(w.s0, 0, av);
+    if constexpr (kDeep) {
+      double av2[TILE_IT];
+      if (w.s0 + 1 < w.s1) fetch_a(w.s0 + 1, 0, av2);
+      commit_b();
+      for (int rt = w.s0; rt < w.s1; rt += 2) {
+        step(rt, av, rt + 2);
+        if (rt + 1 < w.s1) step(rt + 1, av2, rt + 3);
+      }
+    } else {
+      commit_b();
+      for (int rt = w.s0; rt < w.s1; ++rt) step(rt, av, rt + 1);
     }
     return;
   }
@@ -707,22 +728,23 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
   const int rt = w.tile;
   fetch_idx(w.s0);
   fetch_b();
-  fetch_a(rt, w.s0);
+  fetch_a(rt, w.s0, av);
   if (w.s0 + 1 < w.s1) fetch_idx(w.s0 + 1);
+  if (kDeep && rt >= nst) fetch_carry(rt, cg);  // lands while the chain runs
   for (int ct = w.s0; ct < w.s1; ++ct) {
-    commit_a();
+    commit_a(av);
     commit_b();
     __syncthreads();
     if (ct + 1 < w.s1) {
       fetch_b();
-      fetch_a(rt, ct + 1);
+      fetch_a(rt, ct + 1, av);
       if (ct + 2 < w.s1) fetch_idx(ct + 2);
     }
     T::mac(As, Bs, min(TW, ns - ct * TW), acc);
     __syncthreads();
   }
-  if (w.G > 1 && !fold_groups<KPT>(w, la, acc)) return;
-  if (rt >= nst) fetch_carry(rt, cg);
+  if (w.G > 1 && !fold_groups<KPT>(w, la, acc, reinterpret_cast<int*>(As))) return;
+  if (!kDeep && rt >= nst) fetch_carry(rt, cg);
   store_tile(rt, acc, cg);
 }
 
@@ -739,18 +761,18 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
   __shared__ double As[TW * TLD];
   __shared__ double Bs[TW * T::BLD];
   const WgRec w = la.wg[blockIdx.x];
-  const int f = w.f, ct = w.tile;
+  const int ct = w.tile;
   const int kb = la.kb;
-  const int ns = fa.ns[f], bs = fa.bs[f];
+  const int ns = w.ns, bs = w.bs;
   const int d = ns + bs;
   const int nst = (ns + TW - 1) / TW;
   const int c0t = ct * TW;
   const int wc = min(TW, ns - c0t);
   const int nown = nst - ct;
-  const int64_t vbase = fa.voff[f];
-  const double* Tp = Tb + fa.toff[f] + static_cast<int64_t>(c0t) * ns;   // T(r, c0t + o) at o*ns + r
-  const double* Mp = F + fa.foff[f] + static_cast<int64_t>(c0t) * d;     // M21(r, c0t + o) at o*d + r
-  const int* __restrict__ bout = fa.bout + fa.bptr[f];
+  const int64_t vbase = w.voff;
+  const double* Tp = Tb + w.toff + static_cast<int64_t>(c0t) * ns;   // T(r, c0t + o) at o*ns + r
+  const double* Mp = F + w.foff + static_cast<int64_t>(c0t) * d;     // M21(r, c0t + o) at o*d + r
+  const int* __restrict__ bout = fa.bout + w.bptr;
   const int ar = threadIdx.x & (TW - 1), ajb = threadIdx.x >> 6;
 
   int ri[IT];
@@ -822,7 +844,7 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
     T::mac(As, Bs, kdim, acc);
     __syncthreads();
   }
-  if (w.G > 1 && !fold_groups<KPT>(w, la, acc)) return;
+  if (w.G > 1 && !fold_groups<KPT>(w, la, acc, reinterpret_cast<int*>(As))) return;
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) {
     int o, c;
@@ -1133,11 +1155,29 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   std::vector<int> h_fwd_ptr(static_cast<size_t>(s.nlevels) + 1, 0), h_bwd_ptr(static_cast<size_t>(s.nlevels) + 1, 0);
   int64_t fwd_slabs = 0, bwd_slabs = 0;
   int n_tickets = 0;
+  auto env_int = [](const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+  };
+  // chains longer than split_min tiles are cut into groups of about split_len tiles (at most split_maxg groups)
+  const int split_min = env_int("EIGD_SPLIT_MIN", 4), split_len = std::max(1, env_int("EIGD_SPLIT_LEN", 4));
+  const int split_maxg = std::max(1, env_int("EIGD_SPLIT_MAXG", 12)), split_nfl = env_int("EIGD_SPLIT_NFL", 128);
+  auto front_numbers = [&](WgRec& w, int fr) {
+    w.f = fr;
+    w.ns = s.f_ns[fr];
+    w.bs = s.f_bs[fr];
+    w.c0 = s.f_c0[fr];
+    w.parent = s.f_parent[fr];
+    w.voff = s.f_voff[fr];
+    w.foff = s.f_foff[fr];
+    w.toff = toff[fr];
+    w.bptr = s.f_bptr[fr];
+  };
   auto push_chain = [&](std::vector<WgRec>& out, int64_t& slabs, int fr, int tile, int L, bool split, int flags) {
-    const int G = (split && L > 8) ? std::min(8, (L + 5) / 6) : 1;
+    const int G = (split && L > split_min) ? std::min(split_maxg, (L + split_len - 1) / split_len) : 1;
     for (int g = 0; g < G; ++g) {
       WgRec w;
-      w.f = fr;
+      front_numbers(w, fr);
       w.tile = tile;
       w.s0 = static_cast<int>(static_cast<int64_t>(L) * g / G);
       w.s1 = static_cast<int>(static_cast<int64_t>(L) * (g + 1) / G);
@@ -1155,7 +1195,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   for (int l = 0; l < s.nlevels; ++l) {
     const int nfl = s.lvl_ptr[l + 1] - s.lvl_ptr[l];
     const bool sparse_level = nfl < 256;  // few fronts: parallelism has to come from inside the fronts
-    const bool split_level = nfl <= 8;    // the join of split chains costs a device-scope fence: only near the root
+    const bool split_level = nfl <= split_nfl;   // the join of split chains costs an agent-scope acquire: only where chains are long
     for (int q = s.lvl_ptr[l]; q < s.lvl_ptr[l + 1]; ++q) {
       const int fr = s.lvl_fronts[q];
       const int nst = (s.f_ns[fr] + TW - 1) / TW, nbt = (s.f_bs[fr] + TW - 1) / TW;
@@ -1164,7 +1204,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
         const int per = sparse_level ? 1 : nst + nbt;
         for (int t = 0; t < nst + nbt; t += per) {
           WgRec w;
-          w.f = fr;
+          front_numbers(w, fr);
           w.tile = 0;
           w.s0 = t;
           w.s1 = std::min(nst + nbt, t + per);

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""wall time of k-column sweeps on the C3 factor (development aid); split policy from the EIGD_SPLIT_* environment"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eigd_amd.device import Factor, default_context  # noqa: E402
+from eigd_amd.problems import BucklingColumn  # noqa: E402
+
+ctx = default_context()
+col = BucklingColumn(706, 706, seed=0)
+K = col.stiffness()
+F = Factor(ctx, K, coords=col.dof_coords())
+rng = np.random.default_rng(0)
+out = []
+for k in (1, 4, 8, 16, 32):
+    B = ctx.from_host(rng.normal(size=(K.shape[0], k)))
+    X = ctx.empty(K.shape[0], k)
+    for _ in range(3):
+        F.solve_to(B, X)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        F.solve_to(B, X)
+    ctx.sync()
+    out.append(f"k={k}: {1e3 * (time.perf_counter() - t0) / 20:.3f} ms")
+x = X.get()
+r = np.linalg.norm(K @ x - B.get()) / np.linalg.norm(B.get())
+print({k: os.environ[k] for k in os.environ if k.startswith("EIGD_SPLIT")}, " ".join(out), f"resid {r:.1e}")
