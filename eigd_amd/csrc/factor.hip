@@ -47,7 +47,8 @@ struct FrontArrays {
   const int64_t* bptr;
   const int* rel;
   const int64_t* toff;  // offset of the front's inverted triangle T = inv(L11) (ns x ns, column-major)
-  const int* gsrc;      // kGS rows of V per row of V: the children's carries that add into it (forward sweep), -1 = none
+  int nslot;            // carry planes a parent reads (forward sweep): V is nslot (+1 scratch) planes of vrows rows
+  int64_t vrows;
   const int* v_src;     // per row of V: the row of the caller's block it holds (own rows), -1 for border rows
   const int* bout;      // per border entry (bptr): its row in the caller's block
   double* sgn;          // +-1 per (permuted) column: A = L S L^T with S = diag(sgn); all +1 for a positive definite matrix
@@ -56,7 +57,8 @@ struct FrontArrays {
   int W;                // instead of branching around the load, which would serialise the loads of a tile
 };
 
-constexpr int kGS = 3;  // gather slots per row of V
+constexpr int kPlaneCols = 4 + 8 + 16 + 32;  // one set of carry planes per sweep width
+constexpr int kMaxS = 3;  // children per front with a carry plane of their own; further children share an extra plane
 
 __device__ __forceinline__ int find_slot(const int* __restrict__ pref, int na, int idx) {
   int lo = 0, hi = na;
@@ -508,8 +510,10 @@ struct WgRec {
   int f, tile, s0, s1;
   int slab, cnt, G, flags;  // flags: bit 0 = mode 1, bit 1 = the front has children (carries to gather), bits 8.. = group
   // the front's own numbers ride along: one scalar load instead of a second dependent round of them
-  int ns, bs, c0, parent;
+  int ns, bs, c0, slot;  // slot: the carry plane this front writes into (its index among its parent's children)
   int64_t voff, foff, toff, bptr;
+  int64_t pvoff;         // the parent's first row in V, -1 for a root
+  int64_t scratch;       // 1: surplus child (slot >= kMaxS): its carry goes to the scratch plane, at its own border rows
 };
 
 struct LevelArgs {
@@ -521,16 +525,17 @@ struct LevelArgs {
 
 constexpr int TILE_IT = TW * TW / kThreads;  // 16 matrix elements per lane and tile
 
-// rows of the forward carry with more than kGS contributors: the surplus children are summed into an
-// extra row first (fixed order), which the last gather slot of the destination row then points to
-__global__ void overflow_sum_kernel(int nrows, const int* __restrict__ ov_ptr, const int* __restrict__ ov_src,
-                                    int64_t first_row, int kb, double* V) {
+// fronts with more than kMaxS children: the carries of the surplus children (written to the scratch plane) are
+// summed, in fixed order, into the extra plane their parent reads
+__global__ void overflow_sum_kernel(int nrows, const int* __restrict__ ov_dst, const int* __restrict__ ov_ptr,
+                                    const int* __restrict__ ov_src, int kb, int ld, double* __restrict__ extra,
+                                    const double* __restrict__ scratch) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nrows * kb) return;
   const int x = idx / kb, c = idx - x * kb;
-  double s = 0.0;
-  for (int e = ov_ptr[x]; e < ov_ptr[x + 1]; ++e) s += V[static_cast<int64_t>(ov_src[e]) * kb + c];
-  V[(first_row + x) * kb + c] = s;
+  double sum = 0.0;
+  for (int e = ov_ptr[x]; e < ov_ptr[x + 1]; ++e) sum += scratch[static_cast<int64_t>(ov_src[e]) * ld + c];
+  extra[static_cast<int64_t>(ov_dst[x]) * ld + c] = sum;
 }
 
 // Joins the G partial blocks of a split tile.  Returns false for all but the last group to arrive; for that one
@@ -570,14 +575,17 @@ __device__ __forceinline__ bool fold_groups(const WgRec& w, const LevelArgs& la,
   return true;
 }
 
-// Forward sweep, one level.  For front f with v1 = alpha * X[own rows] + the children's carries on the own rows
-// (gathered on the fly through gsrc: kGS source rows per row of V, -1 = none; fixed summation order):
+// Forward sweep, one level.  The carries travel through V: nslot planes of (rows of all fronts) x KBMAX; child
+// number s of a front writes its carry into plane s AT THE PARENT'S ROWS (scatter through rel, no two writers per
+// plane and row), so the parent reads its rows of every plane with plain contiguous loads and adds them in plane
+// order -- no index hop, no atomics.  Entries no child ever writes stay zero from the allocation on.
+// For front f with v1 = alpha * X[own rows] + carries on the own rows:
 //   own row tile rt    : z(rt)  =  sum_{ct <= rt} T(rt, ct) v1(ct)                    -> Y = S z
-//   border row tile rt : carry  =  children's carries - sum_ct M21(rt, ct) v1(ct)     -> border rows of the front's V slice
+//   border row tile rt : carry  =  carries on those rows - sum_ct M21(rt, ct) v1(ct)  -> the parent's rows of plane w.slot
 // Matrix tiles and vector blocks are register staged one step ahead (the gather indices two), so the loads of
 // step t+1 are in flight while step t multiplies.  Masked lanes load from a zero word (address select): a branch
 // around the load would serialise the loads of a tile.
-template <int KPT>
+template <int KPT, bool SINGLE, bool DEEP>
 __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
                                                             const double* __restrict__ Tb, const double* X, int ldx,
                                                             double alpha, double* V, double* __restrict__ Y) {
@@ -590,14 +598,17 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
   const int ns = w.ns;
   const int d = ns + w.bs;
   const int nst = (ns + TW - 1) / TW;
-  const bool single = (w.flags & 1) != 0, kids = (w.flags & 2) != 0;
+  const bool kids = (w.flags & 2) != 0;
   const int64_t vbase = w.voff;
   const double* Tf = Tb + w.toff;
   const double* Ff = F + w.foff;
   const int ar = threadIdx.x & (TW - 1), ajb = threadIdx.x >> 6;  // lane -> (row, first column) of a matrix tile
 
-  int gi[IT][kGS], xi[IT];
+  int xi[IT];
   double bv[IT], av[TILE_IT];
+  const int nslot = kids ? fa.nslot : 0;
+  const int64_t vslot = fa.vrows * T::KB;  // plane size: rows of all fronts x KB (the planes of this sweep width)
+  double* Vout = V + static_cast<int64_t>(w.slot) * vslot;
 
   auto fetch_idx = [&](int ct) {
     const int wd = min(TW, ns - ct * TW);
@@ -607,18 +618,18 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
       const int64_t vrow = vbase + ct * TW + r;
       const bool ok = r < wd;
       xi[e] = *(ok ? fa.v_src + vrow : fa.neg1);
-#pragma unroll
-      for (int s = 0; s < kGS; ++s) gi[e][s] = *((ok && kids) ? fa.gsrc + vrow * kGS + s : fa.neg1);
     }
   };
-  auto fetch_b = [&]() {
+  auto fetch_b = [&](int ct) {
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
-      const int c = (threadIdx.x + e * kThreads) & (T::KB - 1);
-      const bool cok = c < kb;
-      double v = alpha * *((cok && xi[e] >= 0) ? X + static_cast<int64_t>(xi[e]) * ldx + c : fa.zero);
+      const int idx = threadIdx.x + e * kThreads;
+      const int c = idx & (T::KB - 1);
+      const bool ok = c < kb && xi[e] >= 0;
+      double v = alpha * *(ok ? X + static_cast<int64_t>(xi[e]) * ldx + c : fa.zero);
+      const double* cp = V + (vbase + ct * TW + idx / T::KB) * T::KB + c;
 #pragma unroll
-      for (int s = 0; s < kGS; ++s) v += *((cok && gi[e][s] >= 0) ? V + static_cast<int64_t>(gi[e][s]) * kb + c : fa.zero);
+      for (int s = 0; s <= kMaxS; ++s) v += *((ok && s < nslot) ? cp + s * vslot : fa.zero);
       bv[e] = v;
     }
   };
@@ -647,26 +658,24 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
       Bs[(idx / T::KB) * T::BLD + (idx & (T::KB - 1))] = bv[e];
     }
   };
-  // children's carries on the rows of output tile rt (border tiles), in the lane's output layout
-  auto fetch_carry = [&](int rt, double (&cg)[T::NOUT]) {
+  // carries on the rows of border tile rt and where its results go (rows of the parent), in the lane's output layout
+  auto fetch_carry = [&](int rt, double (&cg)[T::NOUT], int (&di)[T::NOUT]) {
     const int row0 = ns + (rt - nst) * TW;
     const int rows = min(TW, d - row0);
 #pragma unroll
     for (int t = 0; t < T::NOUT; ++t) {
       int o, c;
       T::coords(t, o, c);
-      const bool ok = kids && o < rows && c < kb;
-      const int64_t vrow = vbase + row0 + o;
+      const bool ok = o < rows && c < kb;
+      di[t] = *(ok ? fa.rel + w.bptr + (row0 - ns) + o : fa.neg1);
+      const double* cp = V + (vbase + row0 + o) * T::KB + c;
       double v = 0.0;
 #pragma unroll
-      for (int s = 0; s < kGS; ++s) {
-        const int g = *(ok ? fa.gsrc + vrow * kGS + s : fa.neg1);
-        v += *((g >= 0) ? V + static_cast<int64_t>(g) * kb + c : fa.zero);
-      }
+      for (int s = 0; s <= kMaxS; ++s) v += *((ok && s < nslot) ? cp + s * vslot : fa.zero);
       cg[t] = v;
     }
   };
-  auto store_tile = [&](int rt, const double (&acc)[T::NOUT], const double (&cg)[T::NOUT]) {
+  auto store_tile = [&](int rt, const double (&acc)[T::NOUT], const double (&cg)[T::NOUT], const int (&di)[T::NOUT]) {
     const bool own = rt < nst;
     const int row0 = own ? rt * TW : ns + (rt - nst) * TW;
     const int rows = min(TW, (own ? ns : d) - row0);
@@ -680,37 +689,40 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
         if (o < rows && c < kb) Yf[static_cast<int64_t>(o) * kb + c] = sgp[o] * acc[t];
       }
     } else {
-      double* Vf = V + (vbase + row0) * kb;
 #pragma unroll
       for (int t = 0; t < T::NOUT; ++t) {
         int o, c;
         T::coords(t, o, c);
-        if (o < rows && c < kb) Vf[static_cast<int64_t>(o) * kb + c] = cg[t] - acc[t];
+        const int64_t drow = (w.scratch != 0) ? vbase + row0 + o : w.pvoff + di[t];
+        if (di[t] >= 0) Vout[drow * T::KB + c] = cg[t] - acc[t];
       }
     }
   };
 
   double acc[T::NOUT], cg[T::NOUT];
+  int di[T::NOUT];
 #pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) acc[t] = cg[t] = 0.0;
+  for (int t = 0; t < T::NOUT; ++t) {
+    acc[t] = cg[t] = 0.0;
+    di[t] = -1;
+  }
 
-  constexpr bool kDeep = false;  // a second matrix tile in flight costs occupancy (130..172 VGPRs): measured slower
-  if (single) {  // one column tile: v1 is loaded once, the row tiles [s0, s1) are walked with it
+  if constexpr (SINGLE) {  // one column tile: v1 is loaded once, the row tiles [s0, s1) are walked with it
     auto step = [&](int rt, double (&cur)[TILE_IT], int nxt) {
       commit_a(cur);
       __syncthreads();
       if (nxt < w.s1) fetch_a(nxt, 0, cur);
-      if (rt >= nst) fetch_carry(rt, cg);
+      if (rt >= nst) fetch_carry(rt, cg, di);
 #pragma unroll
       for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
       T::mac(As, Bs, ns, acc);
-      store_tile(rt, acc, cg);
+      store_tile(rt, acc, cg, di);
       __syncthreads();
     };
     fetch_idx(0);
-    fetch_b();
+    fetch_b(0);
     fetch_a(w.s0, 0, av);
-    if constexpr (kDeep) {
+    if constexpr (DEEP) {  // two matrix tiles in flight
       double av2[TILE_IT];
       if (w.s0 + 1 < w.s1) fetch_a(w.s0 + 1, 0, av2);
       commit_b();
@@ -722,21 +734,18 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
       commit_b();
       for (int rt = w.s0; rt < w.s1; ++rt) step(rt, av, rt + 1);
     }
-    return;
-  }
-
+  } else {
   const int rt = w.tile;
   fetch_idx(w.s0);
-  fetch_b();
+  fetch_b(w.s0);
   fetch_a(rt, w.s0, av);
   if (w.s0 + 1 < w.s1) fetch_idx(w.s0 + 1);
-  if (kDeep && rt >= nst) fetch_carry(rt, cg);  // lands while the chain runs
   for (int ct = w.s0; ct < w.s1; ++ct) {
     commit_a(av);
     commit_b();
     __syncthreads();
     if (ct + 1 < w.s1) {
-      fetch_b();
+      fetch_b(ct + 1);
       fetch_a(rt, ct + 1, av);
       if (ct + 2 < w.s1) fetch_idx(ct + 2);
     }
@@ -744,8 +753,9 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
     __syncthreads();
   }
   if (w.G > 1 && !fold_groups<KPT>(w, la, acc, reinterpret_cast<int*>(As))) return;
-  if (!kDeep && rt >= nst) fetch_carry(rt, cg);
-  store_tile(rt, acc, cg);
+  if (rt >= nst) fetch_carry(rt, cg, di);
+  store_tile(rt, acc, cg, di);
+  }
 }
 
 // Backward sweep, one level: workgroup (front f, column tile ct) forms
@@ -871,10 +881,12 @@ struct eigd_factor {
   double* d_P = nullptr;
   int64_t n_slabs = 0;
   int n_tickets = 0;
-  int *d_gsrc = nullptr, *d_ov_ptr = nullptr, *d_ov_src = nullptr;
+  int *d_ov_dst = nullptr, *d_ov_ptr = nullptr, *d_ov_src = nullptr;
+  int nslot = 0, nplanes = 0;        // planes the parents read; planes allocated (+ scratch when there are surplus children)
   int64_t* d_toff = nullptr;
   double *d_T = nullptr, *d_aux = nullptr;  // aux: {0.0, (int) -1}
   std::vector<int> h_fwd_ptr, h_bwd_ptr;  // per level: first workgroup record
+  std::vector<int> h_fwd_nsingle;         // per level: leading records of single-column-tile fronts (own kernel)
   std::vector<int> ov_lvl_ptr;       // per level: range of overflow rows (extra rows of V after the sumd front rows)
   int64_t t_doubles = 0, v_rows = 0;
   int n_tri = 0, n_m21 = 0;
@@ -899,7 +911,8 @@ struct eigd_factor {
     a.bptr = d_bptr;
     a.rel = d_rel;
     a.toff = d_toff;
-    a.gsrc = d_gsrc;
+    a.nslot = nslot;
+    a.vrows = v_rows;
     a.v_src = d_v_src;
     a.bout = d_bout;
     a.sgn = d_sgn;
@@ -985,11 +998,19 @@ int numeric(eigd_factor* f, const double* hdata) {
   return EIGD_OK;
 }
 
+// second matrix tile in flight in the single-column-tile forward kernel: where the registers are free anyway
+template <int KPT>
+constexpr bool kDeepSingle = true;
+
 template <int KPT>
 int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, int* wT, const double* dIn, int ldin,
           double* dX, int ldx, int kb, double alpha) {
   const Symbolic& s = *f->sym;
   const FrontArrays fa = f->fa();
+  // every sweep width (KB = 4, 8, 16, 32 columns) has its own set of carry planes: rows are KB wide and the
+  // entries no child writes stay zero for good
+  constexpr int KB = 4 * KPT;
+  wV += static_cast<int64_t>(f->nplanes) * f->v_rows * (KB - 4);  // 4 + 8 + ... below KB = KB - 4
   auto level_args = [&](const WgRec* wg) {
     LevelArgs la;
     la.wg = wg;
@@ -1003,15 +1024,22 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     const int nov = f->ov_lvl_ptr[l + 1] - f->ov_lvl_ptr[l];
     if (nov > 0) {
       const int first = f->ov_lvl_ptr[l];
-      hipLaunchKernelGGL(overflow_sum_kernel, dim3((nov * kb + 255) / 256), dim3(256), 0, st, nov, f->d_ov_ptr + first,
-                         f->d_ov_src, s.sumd + first, kb, wV);
+      const int64_t plane = f->v_rows * KB;
+      hipLaunchKernelGGL(overflow_sum_kernel, dim3((nov * kb + 255) / 256), dim3(256), 0, st, nov, f->d_ov_dst + first,
+                         f->d_ov_ptr + first, f->d_ov_src, kb, KB, wV + (f->nslot - 1) * plane, wV + f->nslot * plane);
       EIGD_LAUNCH_CHECK();
     }
-    const int nwg = f->h_fwd_ptr[l + 1] - f->h_fwd_ptr[l];
-    if (nwg == 0) continue;
-    hipLaunchKernelGGL(fwd_level_kernel<KPT>, dim3(nwg), dim3(kThreads), 0, st, fa,
-                       level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
-    EIGD_LAUNCH_CHECK();
+    const int nwg = f->h_fwd_ptr[l + 1] - f->h_fwd_ptr[l], nsingle = f->h_fwd_nsingle[l];
+    if (nsingle > 0) {
+      hipLaunchKernelGGL((fwd_level_kernel<KPT, true, kDeepSingle<KPT>>), dim3(nsingle), dim3(kThreads), 0, st, fa,
+                         level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
+      EIGD_LAUNCH_CHECK();
+    }
+    if (nwg > nsingle) {
+      hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false>), dim3(nwg - nsingle), dim3(kThreads), 0, st, fa,
+                         level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
+      EIGD_LAUNCH_CHECK();
+    }
   }
   // ---- backward: root -> leaves, straight into the caller's block.
   for (int l = s.nlevels - 1; l >= 0; --l) {
@@ -1123,7 +1151,7 @@ int eigd_factor_free(eigd_factor* f) {
                   f->d_voff,      f->d_ioff,        f->d_bptr,       f->d_lvl_fronts, f->d_pref_chunks,
                   f->d_pref_tiles, f->d_cs_child,   f->d_a_src,      f->d_a_dst,    f->d_v_src, f->d_data,
                   f->d_F,         f->d_Inv,         f->d_V,          f->d_Y,        f->d_flag,  f->d_fwd_wg,
-                  f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_gsrc,     f->d_ov_ptr, f->d_ov_src,
+                  f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_ov_dst,   f->d_ov_ptr, f->d_ov_src,
                   f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux,      f->d_bout,  f->d_tickets,
                   f->d_P};
   for (void* p : ptrs)
@@ -1147,6 +1175,56 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     tri_pref[q + 1] = tri_pref[q] + static_cast<int>((ns + s.W - 1) / s.W);
     m_pref[q + 1] = m_pref[q] + (s.f_bs[q] + TW - 1) / TW;
   }
+  // carry planes: child number q of a front (ascending front order) writes plane q; children beyond kMaxS write
+  // the scratch plane and are summed into the extra plane (overflow_sum_kernel) before their parent's level runs
+  std::vector<int> child_no(static_cast<size_t>(nf), 0), nchild(static_cast<size_t>(nf), 0);
+  int maxchild = 0;
+  for (int c = 0; c < nf; ++c) {
+    const int p = s.f_parent[c];
+    if (p < 0 || s.f_bs[c] == 0) continue;
+    child_no[c] = nchild[p]++;
+    maxchild = std::max(maxchild, nchild[p]);
+  }
+  const bool surplus = maxchild > kMaxS;
+  const int ndirect = std::min(maxchild, kMaxS);
+  const int nslot = ndirect + (surplus ? 1 : 0);
+  const int nplanes = std::max(1, nslot + (surplus ? 1 : 0));
+  struct Extra { int level; int dst; std::vector<int> src; };
+  std::vector<Extra> extras;
+  if (surplus) {
+    std::vector<int64_t> extra_of(static_cast<size_t>(s.sumd), -1);
+    for (int c = 0; c < nf; ++c) {
+      const int p = s.f_parent[c];
+      if (p < 0 || child_no[c] < kMaxS) continue;
+      const int64_t b0 = s.f_bptr[c];
+      for (int i = 0; i < s.f_bs[c]; ++i) {
+        const int64_t dst = s.f_voff[p] + s.rel[b0 + i];
+        if (extra_of[dst] < 0) {
+          extra_of[dst] = static_cast<int64_t>(extras.size());
+          extras.push_back(Extra{s.f_level[p], static_cast<int>(dst), {}});
+        }
+        extras[extra_of[dst]].src.push_back(static_cast<int>(s.f_voff[c] + s.f_ns[c] + i));
+      }
+    }
+    std::stable_sort(extras.begin(), extras.end(), [](const Extra& a, const Extra& b) { return a.level < b.level; });
+  }
+  std::vector<int> ov_dst, ov_ptr, ov_src, ov_lvl_ptr(static_cast<size_t>(s.nlevels) + 1, 0);
+  {
+    // per level the ov_ptr entries are [count + 1] long so that a level's slice starts at its own offset
+    std::vector<int> lvl_cnt(static_cast<size_t>(s.nlevels), 0);
+    for (const Extra& e : extras) lvl_cnt[e.level] += 1;
+    // layout: ov_dst[x], ov_ptr[x] / ov_ptr[x + 1] with one shared trailing entry (offsets are absolute)
+    for (const Extra& e : extras) {
+      ov_dst.push_back(e.dst);
+      ov_ptr.push_back(static_cast<int>(ov_src.size()));
+      for (int q : e.src) ov_src.push_back(q);
+    }
+    ov_ptr.push_back(static_cast<int>(ov_src.size()));
+    for (int l = 0; l < s.nlevels; ++l) ov_lvl_ptr[l + 1] = ov_lvl_ptr[l] + lvl_cnt[l];
+  }
+  const int64_t v_rows = s.sumd;
+  EIGD_REQUIRE(v_rows < (int64_t(1) << 31), "vector workspace has too many rows");
+
   // workgroup records per level (see WgRec).  Levels with few fronts cut their long chains into groups.
   std::vector<char> has_kids(static_cast<size_t>(nf), 0);
   for (int c = 0; c < nf; ++c)
@@ -1167,11 +1245,14 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     w.ns = s.f_ns[fr];
     w.bs = s.f_bs[fr];
     w.c0 = s.f_c0[fr];
-    w.parent = s.f_parent[fr];
     w.voff = s.f_voff[fr];
     w.foff = s.f_foff[fr];
     w.toff = toff[fr];
     w.bptr = s.f_bptr[fr];
+    const int par = s.f_parent[fr];
+    w.pvoff = (par >= 0) ? s.f_voff[par] : -1;
+    w.scratch = (child_no[fr] >= kMaxS) ? 1 : 0;
+    w.slot = w.scratch ? nslot : child_no[fr];
   };
   auto push_chain = [&](std::vector<WgRec>& out, int64_t& slabs, int fr, int tile, int L, bool split, int flags) {
     const int G = (split && L > split_min) ? std::min(split_maxg, (L + split_len - 1) / split_len) : 1;
@@ -1192,7 +1273,9 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
       ++n_tickets;
     }
   };
+  std::vector<int> h_fwd_nsingle(static_cast<size_t>(s.nlevels), 0);
   for (int l = 0; l < s.nlevels; ++l) {
+    std::vector<WgRec> multi;
     const int nfl = s.lvl_ptr[l + 1] - s.lvl_ptr[l];
     const bool sparse_level = nfl < 256;  // few fronts: parallelism has to come from inside the fronts
     const bool split_level = nfl <= split_nfl;   // the join of split chains costs an agent-scope acquire: only where chains are long
@@ -1215,11 +1298,13 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
         }
       } else {
         for (int t = nst + nbt - 1; t >= 0; --t)  // border tiles (nst products) first, then the own tiles, longest first
-          push_chain(fwd_wg, fwd_slabs, fr, t, t < nst ? t + 1 : nst, split_level, kids);
+          push_chain(multi, fwd_slabs, fr, t, t < nst ? t + 1 : nst, split_level, kids);
       }
       const int nbt_b = (s.f_parent[fr] >= 0) ? nbt : 0;
       for (int t = 0; t < nst; ++t) push_chain(bwd_wg, bwd_slabs, fr, t, nst - t + nbt_b, split_level, 0);
     }
+    h_fwd_nsingle[l] = static_cast<int>(fwd_wg.size()) - h_fwd_ptr[l];
+    fwd_wg.insert(fwd_wg.end(), multi.begin(), multi.end());
     h_fwd_ptr[l + 1] = static_cast<int>(fwd_wg.size());
     h_bwd_ptr[l + 1] = static_cast<int>(bwd_wg.size());
   }
@@ -1227,51 +1312,11 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   // rows of the caller's block behind every border entry (backward sweep gathers x there)
   std::vector<int> bout(s.border.size());
   for (size_t e = 0; e < s.border.size(); ++e) bout[e] = s.perm[s.border[e]];
-  // gather lists of the forward carries: row (voff[p] + rel[i]) of the parent receives row (voff[c] + ns_c + i) of
-  // child c; children in ascending front order.  Rows with more than kGS contributors sum the surplus into an
-  // extra row first (overflow_sum_kernel) that the last slot points to.
-  std::vector<int> gsrc(static_cast<size_t>(s.sumd) * kGS, -1), gcnt(static_cast<size_t>(s.sumd), 0);
-  struct Surplus { int level; int64_t dst; std::vector<int> src; };
-  std::vector<Surplus> surplus;
-  std::vector<int64_t> surplus_of;  // dst row -> index into surplus (sparse: linear map only when needed)
-  for (int c = 0; c < nf; ++c) {
-    const int p = s.f_parent[c];
-    if (p < 0) continue;
-    const int64_t b0 = s.f_bptr[c];
-    for (int i = 0; i < s.f_bs[c]; ++i) {
-      const int64_t dst = s.f_voff[p] + s.rel[b0 + i];
-      const int src = static_cast<int>(s.f_voff[c] + s.f_ns[c] + i);
-      int& cnt = gcnt[dst];
-      if (cnt < kGS) {
-        gsrc[dst * kGS + cnt] = src;
-      } else {
-        if (surplus_of.empty()) surplus_of.assign(static_cast<size_t>(s.sumd), -1);
-        if (surplus_of[dst] < 0) {
-          surplus_of[dst] = static_cast<int64_t>(surplus.size());
-          surplus.push_back(Surplus{s.f_level[p], dst, {gsrc[dst * kGS + kGS - 1]}});
-        }
-        surplus[surplus_of[dst]].src.push_back(src);
-      }
-      ++cnt;
-    }
-  }
-  std::stable_sort(surplus.begin(), surplus.end(), [](const Surplus& a, const Surplus& b) { return a.level < b.level; });
-  std::vector<int> ov_ptr(1, 0), ov_src, ov_lvl_ptr(static_cast<size_t>(s.nlevels) + 1, 0);
-  for (size_t x = 0; x < surplus.size(); ++x) {
-    for (int e : surplus[x].src) ov_src.push_back(e);
-    ov_ptr.push_back(static_cast<int>(ov_src.size()));
-    gsrc[surplus[x].dst * kGS + kGS - 1] = static_cast<int>(s.sumd + static_cast<int64_t>(x));
-    ov_lvl_ptr[surplus[x].level + 1] += 1;
-  }
-  for (int l = 0; l < s.nlevels; ++l) ov_lvl_ptr[l + 1] += ov_lvl_ptr[l];
-  const int64_t v_rows = s.sumd + static_cast<int64_t>(surplus.size());
-  EIGD_REQUIRE(v_rows < (int64_t(1) << 31), "vector workspace has too many rows");
-
   size_t free_b = 0, total_b = 0;
   EIGD_HIP(hipMemGetInfo(&free_b, &total_b));
-  const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + toff[nf] + 2 * v_rows * KBMAX +
-                                        n_slabs * TW * KBMAX) +
-                      16 * s.a_src.size() + 4 * gsrc.size() + (size_t(64) << 20);
+  const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + toff[nf] +
+                                        (2 * nplanes + 1) * v_rows * KBMAX + n_slabs * TW * KBMAX) +
+                      16 * s.a_src.size() + (size_t(64) << 20);
   if (need > free_b) {
     set_error("factor needs %.2f GiB of device memory, %.2f GiB free", need / 1073741824.0, free_b / 1073741824.0);
     return EIGD_E_HIP;
@@ -1280,10 +1325,13 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   f->ctx = ctx;
   f->sym = &h->s;
   f->h_fwd_ptr = h_fwd_ptr;
+  f->h_fwd_nsingle = h_fwd_nsingle;
   f->h_bwd_ptr = h_bwd_ptr;
   f->ov_lvl_ptr = ov_lvl_ptr;
   f->t_doubles = toff[nf];
   f->v_rows = v_rows;
+  f->nslot = nslot;
+  f->nplanes = nplanes;
   f->n_slabs = n_slabs;
   f->n_tickets = std::max(1, n_tickets);
   f->n_tri = tri_pref[nf];
@@ -1309,7 +1357,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   UP(d_tri_pref, tri_pref)
   UP(d_m_pref, m_pref)
   UP(d_toff, toff)
-  UP(d_gsrc, gsrc)
+  UP(d_ov_dst, ov_dst)
   UP(d_ov_ptr, ov_ptr)
   UP(d_ov_src, ov_src)
   UP(d_cs_child, s.cs_child)
@@ -1347,7 +1395,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
       e = hipMemset(f->d_tickets, 0, sizeof(int) * f->n_tickets);
     }
   }
-  rc = dmalloc(&f->d_V, static_cast<size_t>(v_rows) * KBMAX);
+  rc = dmalloc(&f->d_V, static_cast<size_t>(nplanes) * v_rows * kPlaneCols);
   rc = dmalloc(&f->d_Y, static_cast<size_t>(s.sumd) * KBMAX);
   rc = dmalloc(&f->d_sgn, static_cast<size_t>(s.n));
   if (rc == EIGD_OK) {
@@ -1371,6 +1419,9 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   }
   EIGD_HIP(hipMemsetAsync(f->d_Inv, 0, sizeof(double) * std::max<int64_t>(s.inv_doubles, 1), ctx->stream));
   EIGD_HIP(hipMemsetAsync(f->d_T, 0, sizeof(double) * std::max<int64_t>(f->t_doubles, 1), ctx->stream));  // upper triangles stay zero
+  // carry planes: entries no child writes must read as zero, in every sweep
+  EIGD_HIP(hipMemsetAsync(f->d_V, 0, sizeof(double) * std::max<int64_t>(static_cast<int64_t>(nplanes) * v_rows * kPlaneCols, 1),
+                          ctx->stream));
   {
     double aux[2] = {0.0, 0.0};
     const int m1 = -1;
@@ -1437,13 +1488,14 @@ int eigd_factor_lane_create(eigd_factor* f, eigd_ctx* ctx, eigd_lane** out) {
   eigd_lane* l = new eigd_lane();
   l->f = f;
   l->ctx = ctx;
-  const size_t vb = sizeof(double) * std::max<size_t>(static_cast<size_t>(f->v_rows) * KBMAX, 1);
+  const size_t vb = sizeof(double) * std::max<size_t>(static_cast<size_t>(f->nplanes) * f->v_rows * kPlaneCols, 1);
   const size_t yb = sizeof(double) * std::max<size_t>(static_cast<size_t>(s.sumd) * KBMAX, 1);
   hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&l->V), vb);
   hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&l->Y), yb);
   hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&l->P), sizeof(double) * static_cast<size_t>(f->n_slabs) * TW * KBMAX);
   hipError_t e4 = hipMalloc(reinterpret_cast<void**>(&l->tickets), sizeof(int) * f->n_tickets);
   if (e4 == hipSuccess) e4 = hipMemset(l->tickets, 0, sizeof(int) * f->n_tickets);
+  if (e1 == hipSuccess) e1 = hipMemset(l->V, 0, vb);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
     eigd_factor_lane_free(l);
     set_error("hipMalloc failed for a sweep lane");

@@ -222,6 +222,41 @@ def test_indefinite_shift_ldlt_and_singular_matrix(ctx):
         Factor(ctx, sparse.kron(sparse.identity(20), np.ones((2, 2))).tocsr())  # exactly singular: zero pivot
 
 
+def star_matrix(nb, g=6, hub=4, seed=0):
+    """nb grid blocks that only talk to each other through a small hub: assembly-tree nodes with many children"""
+    rng = np.random.default_rng(seed)
+    blocks = [grid_matrix(g, g, 1, seed=i) for i in range(nb)]
+    A = sparse.block_diag(blocks + [sparse.identity(hub) * 50.0]).tolil()
+    n0, ntot = g * g, nb * g * g + hub
+    for b in range(nb):
+        for h in range(hub):
+            i = b * n0 + rng.integers(n0)
+            A[i, ntot - hub + h] = A[ntot - hub + h, i] = 0.3
+    A = A.tocsr()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("nb,k", [(5, 3), (9, 1), (9, 20)])
+def test_fronts_with_many_children_use_the_surplus_plane(ctx, nb, k):
+    """more than three children per front: the surplus carries are summed through the scratch / extra planes"""
+    from eigd_amd.device import Factor, Symbolic
+
+    A = star_matrix(nb)
+    sym = Symbolic(A, leaf_size=16, panel_width=8)
+    parent = sym.array("f_parent")
+    assert np.bincount(parent[parent >= 0]).max() > 3
+    F = Factor(ctx, A, symbolic=sym)
+    rng = np.random.default_rng(2)
+    B = rng.normal(size=(A.shape[0], k))
+    ref = splu(A.tocsc()).solve(B)
+    for _ in range(2):  # twice: the planes' never-written entries must still read zero
+        X = F.solve_inplace(ctx.from_host(B)).get()
+        assert relerr(X, ref) < 1e-12
+    X1 = F.solve_inplace(ctx.from_host(B[:, :1])).get()  # another width on the same planes
+    assert relerr(X1, ref[:, :1]) < 1e-12
+
+
 def test_fem_like_ill_conditioned_factor(ctx):
     """Q4 plate-like stencil with a 1e6 stiffness contrast (SIMP void/solid), solved to SuperLU accuracy"""
     from eigd_amd.device import Factor
