@@ -487,7 +487,8 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     if done.all():
         return dpsi, converged, info
     W = ctx.workspace_stack("krylov_W", maxiter + 1, prob.n, k)
-    Z = ctx.workspace_stack("krylov_Z", maxiter, prob.n, k).zero()  # finished columns keep zero (never NaN) entries
+    Z = ctx.workspace_stack("krylov_Z", maxiter, prob.n, k)  # columns of finished modes are never written: their
+    # coefficients in the final psi += Z y are exact zeros, which eigd_stack_axpy skips without touching the entry
     W0 = W[0]
     W0.copy_from(R0)
     prob.project_r(W0)                                   # ref 1232

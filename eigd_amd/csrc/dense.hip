@@ -7,6 +7,9 @@
 // depend on scheduling (run-to-run bitwise reproducible for a given block shape).
 #include <algorithm>
 
+#include <cstdint>
+#include <type_traits>
+
 #include "common.h"
 
 namespace eigd {
@@ -112,9 +115,15 @@ __global__ __launch_bounds__(kThreads) void stack_axpy_kernel(int n, int k, int 
 #pragma unroll
       for (int q = 0; q < 8; ++q) sv[q] = sp[(j + q) * slab];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s += sv[q] * Hs[(j + q) * k + c];
+      for (int q = 0; q < 8; ++q) {  // a zero coefficient skips its slab entry, whatever bits it holds (never-written columns)
+        const double h = Hs[(j + q) * k + c];
+        s += (h != 0.0) ? sv[q] * h : 0.0;
+      }
     }
-    for (; j < ns; ++j) s += sp[j * slab] * Hs[j * k + c];
+    for (; j < ns; ++j) {
+      const double h = Hs[j * k + c];
+      s += (h != 0.0) ? sp[j * slab] * h : 0.0;
+    }
     T[r * ldt + c] += alpha * s;
   }
 }
@@ -201,6 +210,10 @@ __global__ __launch_bounds__(kThreads) void lincomb_kernel(int n, int k, double*
 // ---------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// rows per workgroup step of gemm_tn: few loads per wave and step keep the kernel light (many waves per CU)
+constexpr int kTnRows = 16;
+
+template <int TPW>  // tiles per wave: 1 (at most four 16 x 16 tiles in all) or 4
 __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(int n, int ku, int kx, const double* __restrict__ U,
                                                           int64_t rsu, int64_t csu, const double* __restrict__ X,
                                                           int ldx, double* __restrict__ partial) {
@@ -208,32 +221,77 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(int n, int ku, int kx
   const int li = lane & 15, lk = lane >> 4;
   const int nta = (ku + 15) >> 4, ntb = (kx + 15) >> 4;
   const int ntiles = nta * ntb;  // <= 16
-  double4_t acc[4];
+  // fewer than four tiles (narrow X): the waves that would idle take a share of the rows of a tile instead
+  // (rsplit waves per tile, quad q of the row block goes to share q % rsplit); shares are added through LDS
+  const int rsplit = (TPW == 1 && ntiles == 1) ? 4 : (TPW == 1 && ntiles == 2) ? 2 : 1;
+  const int share = (rsplit > 1) ? wave / ntiles : 0;
+  double4_t acc[TPW];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kRB; base < n; base += static_cast<int64_t>(gridDim.x) * kRB) {
+  for (int t = 0; t < TPW; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+  auto rows_of_share = [&](auto RS, int64_t base, int tile, double4_t& c) {
+    constexpr int rs = decltype(RS)::value;
+    const int ta = tile / ntb, tb = tile - ta * ntb;
+    const int a = ta * 16 + li, b = tb * 16 + li;
+    const bool oka = a < ku, okb = b < kx;
+    const double* up = U + a * csu;
+    const double* xp = X + b;
+    double av[kTnRows / 4 / rs], bv[kTnRows / 4 / rs];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int tile = wave + 4 * t;
-      if (tile >= ntiles) break;
-      const int ta = tile / ntb, tb = tile - ta * ntb;
-      const int a = ta * 16 + li, b = tb * 16 + li;
-      const bool oka = a < ku, okb = b < kx;
-      double av[kRB / 4], bv[kRB / 4];
+    for (int q = 0; q < kTnRows / 4 / rs; ++q) {
+      const int64_t r = base + (q * rs + share) * 4 + lk;
+      const bool okr = r < n;
+      av[q] = (okr && oka) ? up[r * rsu] : 0.0;
+      bv[q] = (okr && okb) ? xp[r * ldx] : 0.0;
+    }
 #pragma unroll
-      for (int q = 0; q < kRB / 4; ++q) {
-        const int64_t r = base + q * 4 + lk;
-        const bool okr = r < n;
-        av[q] = (okr && oka) ? U[r * rsu + a * csu] : 0.0;
-        bv[q] = (okr && okb) ? X[r * ldx + b] : 0.0;
+    for (int q = 0; q < kTnRows / 4 / rs; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], c, 0, 0, 0);
+  };
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kTnRows; base < n; base += static_cast<int64_t>(gridDim.x) * kTnRows) {
+    if constexpr (TPW == 1) {
+      if (rsplit == 4)
+        rows_of_share(std::integral_constant<int, 4>{}, base, 0, acc[0]);
+      else if (rsplit == 2)
+        rows_of_share(std::integral_constant<int, 2>{}, base, wave % 2, acc[0]);
+      else if (wave < ntiles)
+        rows_of_share(std::integral_constant<int, 1>{}, base, wave, acc[0]);
+    } else {
+#pragma unroll 1
+      for (int t = 0; t < 4; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile >= ntiles) break;
+        double4_t c = (t == 0) ? acc[0] : (t == 1) ? acc[1 % TPW] : (t == 2) ? acc[2 % TPW] : acc[3 % TPW];
+        rows_of_share(std::integral_constant<int, 1>{}, base, tile, c);
+        if (t == 0)
+          acc[0] = c;
+        else if (t == 1)
+          acc[1 % TPW] = c;
+        else if (t == 2)
+          acc[2 % TPW] = c;
+        else
+          acc[3 % TPW] = c;
       }
-#pragma unroll
-      for (int q = 0; q < kRB / 4; ++q) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc[t], 0, 0, 0);
     }
   }
   double* p = partial + static_cast<int64_t>(blockIdx.x) * ku * kx;
+  if (rsplit > 1) {
+    __shared__ double red[4][4][64];  // [wave][reg][lane]
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+    for (int reg = 0; reg < 4; ++reg) red[wave][reg][lane] = acc[0][reg];
+    __syncthreads();
+    if (share != 0) return;
+    const int tile = wave;  // waves 0 .. ntiles-1 hold share 0
+    const int ta = tile / ntb, tb = tile - ta * ntb;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      double sum = 0.0;
+      for (int sh = 0; sh < rsplit; ++sh) sum += red[tile + sh * ntiles][reg][lane];
+      const int a = ta * 16 + lk + 4 * reg, b = tb * 16 + li;
+      if (a < ku && b < kx) p[a * kx + b] = sum;
+    }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
     const int tile = wave + 4 * t;
     if (tile >= ntiles) break;
     const int ta = tile / ntb, tb = tile - ta * ntb;
@@ -254,64 +312,81 @@ __device__ __forceinline__ int cs_stride(int kx) { return (kx % 32 == 0) ? kx + 
 __global__ __launch_bounds__(kThreads) void gemm_nn_kernel(int n, int ku, int kx, const double* __restrict__ U,
                                                           int64_t rsu, int64_t csu, const double* __restrict__ C,
                                                           double* __restrict__ X, int ldx, double alpha, double beta) {
-  __shared__ double Us[kRB][kMaxK + 1];
-  extern __shared__ double Cs[];  // ku x cs_stride(kx)
+  extern __shared__ double Cs[];  // ku x cs_stride(kx), then the staged rows of U: kRB x (ku + 1)
   const int tid = threadIdx.x;
   const int cld = cs_stride(kx);
+  const int uld = ku + 1;
+  double* Us = Cs + ku * cld;
   for (int q = tid; q < ku * kx; q += kThreads) Cs[(q / kx) * cld + q % kx] = C[q];
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
-  const int ntb = (kx + 15) >> 4;
+  const int ntb = (kx + 15) >> 4;  // <= 4
   const int ku4 = (ku + 3) & ~3;
-  for (int64_t base = static_cast<int64_t>(blockIdx.x) * kRB; base < n; base += static_cast<int64_t>(gridDim.x) * kRB) {
+  constexpr int IT = kRB * kMaxK / kThreads;  // 16 staged elements per lane
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kRB;
+  // where the lane's staged elements live, relative to the row block: computed once (the divisions are by runtime ku)
+  int64_t goff[IT];
+  int soff[IT], srow[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int qq = tid + it * kThreads;
+    int rr, a;
+    if (rsu == 1) {
+      rr = qq % kRB;
+      a = qq / kRB;
+    } else {
+      a = qq % ku;
+      rr = qq / ku;
+    }
+    const bool ok = qq < kRB * ku;
+    goff[it] = rr * rsu + a * csu;
+    soff[it] = rr * uld + a;
+    srow[it] = ok ? rr : kRB;  // kRB: never below `rows`
+  }
+  double tmp[IT];
+  // the next row block of U is fetched into registers while the current one multiplies
+  auto fetch = [&](int64_t base) {
+    const int rows = static_cast<int>((n - base) < kRB ? (n - base) : kRB);
+    const double* ub = U + base * rsu;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) tmp[it] = (srow[it] < rows) ? ub[goff[it]] : 0.0;
+  };
+  int64_t base = static_cast<int64_t>(blockIdx.x) * kRB;
+  if (base < n) fetch(base);
+  for (; base < n; base += stride) {
     const int rows = static_cast<int>((n - base) < kRB ? (n - base) : kRB);
     __syncthreads();
-    {
-      constexpr int IT = kRB * kMaxK / kThreads;  // 16 staged elements per lane
-      double tmp[IT];
 #pragma unroll
-      for (int it = 0; it < IT; ++it) {
-        const int qq = tid + it * kThreads;
-        int rr, a;
-        if (rsu == 1) {
-          rr = qq % kRB;
-          a = qq / kRB;
-        } else {
-          a = qq % ku;
-          rr = qq / ku;
-        }
-        tmp[it] = (qq < kRB * ku && rr < rows) ? U[(base + rr) * rsu + a * csu] : 0.0;
-      }
-#pragma unroll
-      for (int it = 0; it < IT; ++it) {
-        const int qq = tid + it * kThreads;
-        if (qq < kRB * ku) {
-          if (rsu == 1)
-            Us[qq % kRB][qq / kRB] = tmp[it];
-          else
-            Us[qq / ku][qq % ku] = tmp[it];
-        }
-      }
-    }
+    for (int it = 0; it < IT; ++it)
+      if (srow[it] < kRB) Us[soff[it]] = tmp[it];
     __syncthreads();
+    if (base + stride < n) fetch(base + stride);
     if (16 * wave >= rows) continue;  // wave-uniform
-    for (int tb = 0; tb < ntb; ++tb) {
+    // the block of X this wave updates: loaded before the products, so its latency hides behind them
+    double xv[4][4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = 16 * wave + lk + 4 * reg, b = tb * 16 + li;
+        xv[tb][reg] = (beta != 0.0 && tb < ntb && r < rows && b < kx) ? X[(base + r) * ldx + b] : 0.0;
+      }
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      if (tb >= ntb) break;
       const int b = tb * 16 + li;
       const bool okb = b < kx;
       double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
       for (int k0 = 0; k0 < ku4; k0 += 4) {
         const int k = k0 + lk;
-        const double av = (k < ku) ? Us[16 * wave + li][k] : 0.0;
+        const double av = (k < ku) ? Us[(16 * wave + li) * uld + k] : 0.0;
         const double bv = (k < ku && okb) ? Cs[k * cld + b] : 0.0;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
       }
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = 16 * wave + lk + 4 * reg;  // f64 MFMA result map: row = (l>>4) + 4*reg, col = l&15
-        if (r < rows && okb) {
-          double* xp = X + (base + r) * ldx + b;
-          *xp = (beta == 0.0) ? alpha * acc[reg] : beta * (*xp) + alpha * acc[reg];
-        }
+        if (r < rows && okb) X[(base + r) * ldx + b] = (beta == 0.0) ? alpha * acc[reg] : beta * xv[tb][reg] + alpha * acc[reg];
       }
     }
   }
@@ -373,8 +448,12 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
   if (rc) return rc;
   double* res = ctx->scratch;
   double* partial = ctx->scratch + nout;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, csu, dX, ldx,
-                     partial);
+  if (((ku + 15) / 16) * ((kx + 15) / 16) <= 4)
+    hipLaunchKernelGGL(gemm_tn_kernel<1>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, csu, dX, ldx,
+                       partial);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel<4>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, csu, dX, ldx,
+                       partial);
   EIGD_LAUNCH_CHECK();
   rc = reduce_to_host(ctx, partial, nb, nout, res, hC);
   if (rc) return rc;
@@ -385,7 +464,7 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
 static int gemm_nn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu,
                           const double* dC, double* dX, int ldx, double alpha, double beta) {
   const int nb = grid_for_rows(n, kRB);
-  const size_t cs_bytes = sizeof(double) * ku * ((kx % 32 == 0) ? kx + 16 : kx);
+  const size_t cs_bytes = sizeof(double) * (ku * ((kx % 32 == 0) ? kx + 16 : kx) + kRB * (ku + 1));
   hipLaunchKernelGGL(gemm_nn_kernel, dim3(nb), dim3(kThreads), cs_bytes, ctx->stream, n, ku, kx, dU, rsu, csu, dC, dX,
                      ldx, alpha, beta);
   EIGD_LAUNCH_CHECK();

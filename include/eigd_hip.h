@@ -146,7 +146,8 @@ int eigd_lincomb(eigd_ctx* ctx, int n, int k, double* dOut, int ldo, int nterms,
 /* batched Gram-Schmidt against a stack of ns slabs (each n x k, leading dimension lds, element stride `slab`;
  * a column range of a wider stack is addressed by offsetting dS and keeping lds):
  *   stack_dot : hH[j*k + c] = sum_r S_j[r,c] T[r,c]            (1229, 1255, 1013, 1530)
- *   stack_axpy: T[r,c] += alpha * sum_j S_j[r,c] hH[j*k + c]    (1230, 1256, 1014, 1531, 1277) */
+ *   stack_axpy: T[r,c] += alpha * sum_j S_j[r,c] hH[j*k + c]    (1230, 1256, 1014, 1531, 1277); an exactly zero
+ *               coefficient skips its slab entry (which may never have been written) */
 int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* dT,
                    int ldt, double* hH);
 int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* hH,

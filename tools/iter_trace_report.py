@@ -8,7 +8,10 @@ import sys
 from collections import defaultdict
 
 path = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
-which = [int(a) for a in sys.argv[2:]]
+which = [int(a) for a in sys.argv[2:] if not a.startswith("sum=")]
+sum_rng = [tuple(int(x) for x in a[4:].split(":")) for a in sys.argv[2:] if a.startswith("sum=")]
+totals = defaultdict(float)
+tot_gap = 0.0
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = []
@@ -26,7 +29,7 @@ for w in range(len(starts)):
     sweep = other = gaps = 0.0
     prev = t0
     by = defaultdict(float)
-    kpt = re.search(r"level_kernel<(\d+)>", seq[0]["Kernel_Name"]).group(1)
+    kpt = re.search(r"level_kernel<(\d+)", seq[0]["Kernel_Name"]).group(1)
     for r in seq:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         name = r["Kernel_Name"].split("(")[0].replace("void eigd::", "").replace("eigd::", "")
@@ -37,6 +40,11 @@ for w in range(len(starts)):
             gaps += max(0, s - prev) / 1e3
             by[re.sub(r"<.*", "", name)] += (e - s) / 1e3
         prev = e
+    if any(a <= w < b for a, b in sum_rng):
+        totals["(sweep level kernels)"] += sweep
+        for kname, v in by.items():
+            totals[kname] += v
+        tot_gap += gaps
     top = ", ".join(f"{k} {v:.0f}" for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:6])
     print(f"sweep {w:3d} KPT {kpt}: sweep {sweep:7.1f}  other {other:7.1f}  gaps {gaps:6.1f} us | {top}")
     if w in which or (w - len(starts)) in which:
@@ -46,3 +54,10 @@ for w in range(len(starts)):
             name = r["Kernel_Name"].split("(")[0].replace("void eigd::", "")
             print(f"      gap {(s - prev) / 1e3:7.1f}  dur {(e - s) / 1e3:8.1f} us  wg {int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])):6d}  {name}")
             prev = e
+
+if sum_rng:
+    print("--- totals over", sum_rng, "(us)")
+    for kname, v in sorted(totals.items(), key=lambda kv: -kv[1]):
+        print(f"  {v:10.1f}  {kname}")
+    print(f"  {tot_gap:10.1f}  (host gaps)")
+    print(f"  {sum(totals.values()) + tot_gap:10.1f}  total")
