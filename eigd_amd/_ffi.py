@@ -75,6 +75,10 @@ _SIGNATURES = {
     "eigd_stack_dot": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_int, c_vp],
     "eigd_stack_axpy": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_dbl],
     "eigd_stack_axpy_dot": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_dbl, c_vp],
+    "eigd_stack_cgs2": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_int, c_dbl, c_vp, c_vp],
+    "eigd_colnorm2_dev": [c_vp, c_int, c_int, c_vp, c_int, c_vp],
+    "eigd_colnorm2_fetch": [c_vp, c_vp, c_int],
+    "eigd_scale_inv_norm": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp],
     "eigd_copy_block": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_gather_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
     "eigd_scatter_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],

@@ -441,18 +441,17 @@ def _cgs2(Wst, T, ns, c0=0):
     exceeds 1e-13 for some column -- the reference's modified Gram-Schmidt (eigenvector_derivatives.py:1254-1256)
     leaves O(eps * cond) there, orders of magnitude more.
     """
-    h1 = Wst.dot(T, ns=ns, c0=c0)
-    if ns <= 32:  # fused: subtract the first projection and measure what is left in one pass over W
-        h2 = Wst.axpy_dot_into(T, h1, alpha=-1.0, c0=c0)
-    else:
+    if T.k * ns * 8 > 60 * 1024:  # deeper than one coefficient block: pass by pass
+        h1 = Wst.dot(T, ns=ns, c0=c0)
         Wst.axpy_into(T, h1, alpha=-1.0, c0=c0)
         h2 = Wst.dot(T, ns=ns, c0=c0)
-    n1 = np.sqrt(np.sum(h1 * h1, axis=0))
-    n2 = np.sqrt(np.sum(h2 * h2, axis=0))
-    if not np.any(n2 > _REORTH_TOL * n1):
-        return h1
-    Wst.axpy_into(T, h2, alpha=-1.0, c0=c0)
-    return h1 + h2
+        n1 = np.sqrt(np.sum(h1 * h1, axis=0))
+        n2 = np.sqrt(np.sum(h2 * h2, axis=0))
+        if not np.any(n2 > _REORTH_TOL * n1):
+            return h1
+        Wst.axpy_into(T, h2, alpha=-1.0, c0=c0)
+        return h1 + h2
+    return Wst.cgs2(T, ns, c0=c0, tol=_REORTH_TOL)[0]  # one call, one host synchronisation
 
 
 def _active_range(done):
@@ -536,15 +535,14 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     for j in range(1, maxiter + 1):
         h = _cgs2(W, Ta, j, c0=lo)                       # ref 1254-1256 (Gram-Schmidt vs all previous W)
         prob.project_r(Ta)                               # ref 1257
-        hn = Ta.colnorms()                               # ref 1259
+        hn2 = Ta.colnorm2_dev()                          # ref 1259: the norms stay on the device ...
         jlast = j
         cur = (lo, hi)
         nxt = None
         if j < maxiter:
-            dn = done[lo:hi]
-            scale = np.where(dn | (hn == 0.0), 0.0, 1.0 / np.where(hn == 0.0, 1.0, hn))
-            W[j].cols(lo, hi).assign_lincomb([(scale, Ta)])  # ref 1260
-            nxt = enqueue_operator(j, lo, hi, 0)
+            W[j].cols(lo, hi).assign_scaled_inverse(Ta, hn2, done[lo:hi])  # ref 1260 ... where the next basis vector
+            nxt = enqueue_operator(j, lo, hi, 0)         # is formed; the host reads them behind the sweep in flight
+        hn = np.sqrt(ctx.fetch_colnorm2(cur[1] - cur[0]))
         small_solves(j, cur[0], cur[1], h, hn)
         if done.all():
             break

@@ -58,6 +58,14 @@ struct eigd_ctx {
   double* coef = nullptr;
   size_t coef_bytes = 0;
   int n_cu = 256;
+  // pinned host staging for small results whose D2H copy is issued in stream order and collected later
+  // (eigd_colnorm2_dev / eigd_colnorm2_fetch): the copy completes behind the kernel that made the numbers,
+  // not behind whatever the host enqueues afterwards
+  double* pinned = nullptr;   // 2 * kMaxK doubles
+  hipEvent_t ev_pinned = nullptr;
+  int pinned_count = 0;
+  double* pinned_h = nullptr;  // pinned staging of coefficient blocks (eigd_stack_cgs2)
+  size_t pinned_h_bytes = 0;
 
   int ensure_scratch(size_t bytes);
   int ensure_coef(size_t bytes);

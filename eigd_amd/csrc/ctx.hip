@@ -89,6 +89,9 @@ int eigd_ctx_destroy(eigd_ctx* ctx) {
   if (ctx->coef) (void)hipFree(ctx->coef);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev_pinned) (void)hipEventDestroy(ctx->ev_pinned);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->pinned_h) (void)hipHostFree(ctx->pinned_h);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return EIGD_OK;

@@ -7,7 +7,10 @@
 // depend on scheduling (run-to-run bitwise reproducible for a given block shape).
 #include <algorithm>
 
+#include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <vector>
 #include <type_traits>
 
 #include "common.h"
@@ -199,6 +202,25 @@ __global__ __launch_bounds__(kThreads) void lincomb_kernel(int n, int k, double*
     for (int t = 0; t < nterms; ++t) s += cf[t] * a.x[t][r * a.ld[t] + c];
     out[r * ldo + c] = s;
   }
+}
+
+struct SkipMask {
+  unsigned char skip[kMaxK];
+};
+
+// out[r][c] = x[r][c] / sqrt(norm2[c]); columns with skip[c] != 0 or norm2[c] == 0 become zero.  norm2 lives on the
+// device (the column norms never visit the host on this path).
+template <int KP>
+__global__ __launch_bounds__(kThreads) void scale_inv_norm_kernel(int n, int k, const double* __restrict__ x, int ldx,
+                                                                 double* __restrict__ out, int ldo,
+                                                                 const double* __restrict__ norm2, SkipMask m) {
+  constexpr int RP = kThreads / KP;
+  const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
+  if (c >= k) return;
+  const double n2 = norm2[c];
+  const double sc = (m.skip[c] != 0 || n2 == 0.0) ? 0.0 : 1.0 / sqrt(n2);
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP)
+    out[r * ldo + c] = sc * x[r * ldx + c];
 }
 
 // ---------------------------------------------------------------------------
@@ -575,6 +597,189 @@ int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_
   }
   EIGD_HIP(hipMemcpyAsync(hH, res, sizeof(double) * ns * k, hipMemcpyDeviceToHost, ctx->stream));
   EIGD_HIP(hipStreamSynchronize(ctx->stream));
+  return EIGD_OK;
+}
+
+static int stack_dot_device(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* dT,
+                            int ldt, double** dres) {
+  constexpr int JB = 16;
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 8);
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) * JB * k + static_cast<size_t>(ns) * k));
+  if (rc) return rc;
+  double* res = ctx->scratch;                                    // ns * k results
+  double* partial = ctx->scratch + static_cast<size_t>(ns) * k;  // nb * JB * k
+  for (int j0 = 0; j0 < ns; j0 += JB) {
+    const int nj = std::min(JB, ns - j0);
+    rc = dispatch_kp(k, [&](auto KP) {
+      hipLaunchKernelGGL((stack_dot_kernel<decltype(KP)::value, JB>), dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, nj,
+                         dS + j0 * slab, slab, lds, dT, ldt, partial);
+    });
+    if (rc) return rc;
+    EIGD_LAUNCH_CHECK();
+    rc = reduce_to_host(ctx, partial, nb, nj * k, res + static_cast<size_t>(j0) * k, nullptr);
+    if (rc) return rc;
+  }
+  *dres = res;
+  return EIGD_OK;
+}
+
+static int stack_axpy_device(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* dH,
+                             double* dT, int ldt, double alpha) {
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 8);
+  int rc = dispatch_kp(k, [&](auto KP) {
+    hipLaunchKernelGGL(stack_axpy_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), sizeof(double) * ns * k,
+                       ctx->stream, n, k, ns, dS, slab, lds, dH, dT, ldt, alpha);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  return EIGD_OK;
+}
+
+static int stack_axpy_dot_device(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds,
+                                 const double* dH1, double* dT, int ldt, double alpha, double** dres) {
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 8);
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) + 1) * ns * k);
+  if (rc) return rc;
+  double* res = ctx->scratch;
+  double* partial = ctx->scratch + static_cast<size_t>(ns) * k;
+  const size_t shm = sizeof(double) * ns * k;
+  rc = dispatch_kp(k, [&](auto KP) {
+    constexpr int kpv = decltype(KP)::value;
+    if (ns <= 8)
+      hipLaunchKernelGGL((stack_axpy_dot_kernel<kpv, 8>), dim3(nb), dim3(kThreads), shm, ctx->stream, n, k, ns, dS, slab,
+                         lds, dH1, dT, ldt, alpha, partial);
+    else if (ns <= 16)
+      hipLaunchKernelGGL((stack_axpy_dot_kernel<kpv, 16>), dim3(nb), dim3(kThreads), shm, ctx->stream, n, k, ns, dS, slab,
+                         lds, dH1, dT, ldt, alpha, partial);
+    else
+      hipLaunchKernelGGL((stack_axpy_dot_kernel<kpv, 32>), dim3(nb), dim3(kThreads), shm, ctx->stream, n, k, ns, dS, slab,
+                         lds, dH1, dT, ldt, alpha, partial);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  rc = reduce_to_host(ctx, partial, nb, ns * k, res, nullptr);
+  if (rc) return rc;
+  *dres = res;
+  return EIGD_OK;
+}
+
+int eigd_stack_cgs2(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, double* dT, int ldt,
+                    double tol, double* hH, int* hpasses) {
+  EIGD_REQUIRE(ctx && dS && dT && hH, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && lds >= k &&
+                   slab >= static_cast<int64_t>(n - 1) * lds + k,
+               "bad shape n=%d k=%d ns=%d", n, k, ns);
+  EIGD_REQUIRE(static_cast<size_t>(ns) * k * sizeof(double) <= 60 * 1024, "stack too deep for one pass: ns*k=%d", ns * k);
+  const size_t nh = static_cast<size_t>(ns) * k;
+  int rc = ctx->ensure_coef(sizeof(double) * 2 * nh);  // [h1][h2]: device copies of the coefficients
+  if (rc) return rc;
+  double* res = nullptr;
+  // pass 1: h1 = S^T T.  It stays on the device for pass 2; the host sees it together with h2.
+  rc = stack_dot_device(ctx, n, k, ns, dS, slab, lds, dT, ldt, &res);
+  if (rc) return rc;
+  EIGD_HIP(hipMemcpyAsync(ctx->coef, res, sizeof(double) * nh, hipMemcpyDeviceToDevice, ctx->stream));
+  int passes = 2;
+  if (ns <= 32) {  // pass 2, fused: T -= S h1 and h2 = S^T T in one pass over the stack
+    rc = stack_axpy_dot_device(ctx, n, k, ns, dS, slab, lds, ctx->coef, dT, ldt, -1.0, &res);
+    if (rc) return rc;
+  } else {
+    rc = stack_axpy_device(ctx, n, k, ns, dS, slab, lds, ctx->coef, dT, ldt, -1.0);
+    if (rc) return rc;
+    rc = stack_dot_device(ctx, n, k, ns, dS, slab, lds, dT, ldt, &res);
+    if (rc) return rc;
+    passes = 3;
+  }
+  if (ctx->pinned_h_bytes < sizeof(double) * 2 * nh) {
+    if (ctx->pinned_h) {
+      EIGD_HIP(hipStreamSynchronize(ctx->stream));
+      EIGD_HIP(hipHostFree(ctx->pinned_h));
+      ctx->pinned_h = nullptr;
+      ctx->pinned_h_bytes = 0;
+    }
+    const size_t want = sizeof(double) * 2 * nh + (size_t(1) << 16);
+    EIGD_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned_h), want, hipHostMallocDefault));
+    ctx->pinned_h_bytes = want;
+  }
+  double* h1 = ctx->pinned_h;
+  double* h2 = ctx->pinned_h + nh;
+  EIGD_HIP(hipMemcpyAsync(h1, ctx->coef, sizeof(double) * nh, hipMemcpyDeviceToHost, ctx->stream));
+  EIGD_HIP(hipMemcpyAsync(h2, res, sizeof(double) * nh, hipMemcpyDeviceToHost, ctx->stream));
+  EIGD_HIP(hipMemcpyAsync(ctx->coef + nh, res, sizeof(double) * nh, hipMemcpyDeviceToDevice, ctx->stream));
+  EIGD_HIP(hipStreamSynchronize(ctx->stream));
+  // what one-pass Gram-Schmidt left along S, column by column: subtract it only where it matters
+  bool again = false;
+  for (int c = 0; c < k && !again; ++c) {
+    double n1 = 0.0, n2 = 0.0;
+    for (int j = 0; j < ns; ++j) {
+      n1 += h1[static_cast<size_t>(j) * k + c] * h1[static_cast<size_t>(j) * k + c];
+      n2 += h2[static_cast<size_t>(j) * k + c] * h2[static_cast<size_t>(j) * k + c];
+    }
+    if (std::sqrt(n2) > tol * std::sqrt(n1)) again = true;
+  }
+  if (again) {
+    rc = stack_axpy_device(ctx, n, k, ns, dS, slab, lds, ctx->coef + nh, dT, ldt, -1.0);
+    if (rc) return rc;
+    for (size_t q = 0; q < nh; ++q) h1[q] += h2[q];
+    passes += 1;
+  }
+  std::memcpy(hH, h1, sizeof(double) * nh);
+  if (hpasses) *hpasses = passes;
+  return EIGD_OK;
+}
+
+int eigd_colnorm2_dev(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, double* dOut) {
+  EIGD_REQUIRE(ctx && dX && dOut, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldx >= k, "bad shape n=%d k=%d", n, k);
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 8);
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) + 1) * k);
+  if (rc) return rc;
+  double* partial = ctx->scratch + k;
+  rc = dispatch_kp(k, [&](auto KP) {
+    hipLaunchKernelGGL(coldot_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dX, ldx, dX,
+                       ldx, partial);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  rc = reduce_to_host(ctx, partial, nb, k, dOut, nullptr);
+  if (rc) return rc;
+  // copy for the host, in stream order right behind the reduction; eigd_colnorm2_fetch collects it
+  if (!ctx->pinned) {
+    EIGD_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), sizeof(double) * 2 * kMaxK, hipHostMallocDefault));
+    EIGD_HIP(hipEventCreateWithFlags(&ctx->ev_pinned, hipEventDisableTiming));
+  }
+  EIGD_HIP(hipMemcpyAsync(ctx->pinned, dOut, sizeof(double) * k, hipMemcpyDeviceToHost, ctx->stream));
+  EIGD_HIP(hipEventRecord(ctx->ev_pinned, ctx->stream));
+  ctx->pinned_count = k;
+  return EIGD_OK;
+}
+
+int eigd_colnorm2_fetch(eigd_ctx* ctx, double* hout, int k) {
+  EIGD_REQUIRE(ctx && hout, "null argument");
+  EIGD_REQUIRE(ctx->pinned && k == ctx->pinned_count, "no pending column norms of width %d", k);
+  EIGD_HIP(hipEventSynchronize(ctx->ev_pinned));
+  std::memcpy(hout, ctx->pinned, sizeof(double) * k);
+  ctx->pinned_count = 0;
+  return EIGD_OK;
+}
+
+int eigd_scale_inv_norm(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, double* dOut, int ldo,
+                        const double* dNorm2, const unsigned char* hskip) {
+  EIGD_REQUIRE(ctx && dX && dOut && dNorm2, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldx >= k && ldo >= k, "bad shape n=%d k=%d", n, k);
+  SkipMask m;
+  for (int c = 0; c < kMaxK; ++c) m.skip[c] = (hskip && c < k) ? hskip[c] : 0;
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 4);
+  int rc = dispatch_kp(k, [&](auto KP) {
+    hipLaunchKernelGGL(scale_inv_norm_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dX, ldx,
+                       dOut, ldo, dNorm2, m);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
   return EIGD_OK;
 }
 

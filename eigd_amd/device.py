@@ -79,6 +79,12 @@ class Context:
     def stack(self, ns, n, k=1):
         return DeviceStack(self, ns, n, k)
 
+    def fetch_colnorm2(self, k):
+        """host copy of the last colnorm2_dev result: waits for that copy only, not for work enqueued since"""
+        out = np.empty(k)
+        call("eigd_colnorm2_fetch", self.h, hptr(out), int(k))
+        return out
+
     def workspace_stack(self, tag, ns, n, k=1):
         """
         A stack that is kept alive between calls and handed out again for the same (tag, shape): the Krylov
@@ -221,6 +227,20 @@ class DeviceBlock:
     def colnorms(self):
         return np.sqrt(self.coldot(self))
 
+    def colnorm2_dev(self):
+        """squared column norms, left on the device (no host synchronisation); ctx.fetch_colnorm2(k) collects the copy"""
+        assert self.k <= 64
+        out = self.ctx.empty(1, self.k)
+        call("eigd_colnorm2_dev", self.ctx.h, self.n, self.k, self.ptr, self.ld, out.ptr)
+        return out
+
+    def assign_scaled_inverse(self, src, norm2_dev, skip):
+        """self[:, c] = src[:, c] / sqrt(norm2[c]) with norm2 on the device; zero where skip[c] or the norm is zero"""
+        assert self.k == src.k and self.k <= 64
+        mask = np.ascontiguousarray(np.asarray(skip, dtype=bool)[: self.k], dtype=np.uint8)
+        call("eigd_scale_inv_norm", self.ctx.h, self.n, self.k, src.ptr, src.ld, self.ptr, self.ld, norm2_dev.ptr, hptr(mask))
+        return self
+
     def tdot(self, X):
         """self^T X  -> host (self.k x X.k)"""
         out = np.empty((self.k, X.k))
@@ -319,6 +339,14 @@ class DeviceStack:
             call("eigd_stack_axpy", self.ctx.h, self.n, T.k, b - a, c_vp(self.buf.ptr + 8 * ((j0 + a) * self.slab + c0)),
                  self.slab, self.k, hptr(np.ascontiguousarray(H[a:b])), T.ptr, T.ld, float(alpha))
         return T
+
+    def cgs2(self, T, ns, c0=0, tol=1e-13):
+        """one Gram-Schmidt step of T against slabs [0, ns) (columns c0..): returns (coefficients, passes over the stack)"""
+        H = np.empty((ns, T.k))
+        passes = C.c_int(0)
+        call("eigd_stack_cgs2", self.ctx.h, self.n, T.k, ns, c_vp(self.buf.ptr + 8 * c0), self.slab, self.k, T.ptr, T.ld,
+             float(tol), hptr(H), C.byref(passes))
+        return H, passes.value
 
     def axpy_dot_into(self, T, H1, alpha=1.0, j0=0, c0=0):
         """T += alpha * sum_j S_j H1[j]; returns H2[j, c] = S_j[:, c] . T[:, c] on the updated T (ns <= 32)"""

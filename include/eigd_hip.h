@@ -155,6 +155,20 @@ int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
 /* fused middle of the twice-applied Gram-Schmidt: T += alpha * sum_j S_j hH1[j]; then hH2[j] = S_j . T (ns <= 32) */
 int eigd_stack_axpy_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* hH1,
                         double* dT, int ldt, double alpha, double* hH2);
+/* one Gram-Schmidt step of the lock-step Krylov solvers in a single call (1254-1256, 1012-1014): T -= S (S^T T),
+ * then the part of T still along S is measured (second pass over the stack) and subtracted only if it exceeds
+ * tol * |S^T T| for some column.  hH (ns x k) receives the coefficients applied; *hpasses the passes over the stack.
+ * One host synchronisation instead of one per pass. */
+int eigd_stack_cgs2(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, double* dT, int ldt,
+                    double tol, double* hH, int* hpasses);
+/* squared column norms into device memory (no host synchronisation) and the normalisation that consumes them:
+ * Out[:, c] = X[:, c] / sqrt(dNorm2[c]), zero where hskip[c] != 0 or the norm is zero (1259-1260, 1233-1234) */
+int eigd_colnorm2_dev(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, double* dOut);
+/* the same numbers on the host: their copy was issued in stream order behind eigd_colnorm2_dev, this call waits for
+ * that copy only (not for kernels enqueued since) */
+int eigd_colnorm2_fetch(eigd_ctx* ctx, double* hout, int k);
+int eigd_scale_inv_norm(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, double* dOut, int ldo,
+                        const double* dNorm2, const unsigned char* hskip);
 /* copy an n x k block between buffers with different leading dimensions / column offsets */
 int eigd_copy_block(eigd_ctx* ctx, int n, int k, const double* dSrc, int lds, double* dDst, int ldd);
 /* gather columns: Dst[r, j] = Src[r, cols[j]] (compaction of the active modes) */

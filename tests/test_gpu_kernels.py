@@ -287,3 +287,34 @@ def test_factor_with_geometric_ordering(ctx):
         B = rng.normal(size=(A.shape[0], k))
         X = F.solve_inplace(ctx.from_host(B)).get()
         assert np.linalg.norm(A @ X - B) / np.linalg.norm(B) < 1e-12
+
+
+@pytest.mark.parametrize("ns,k,c0", [(5, 7, 0), (20, 32, 0), (40, 12, 9)])
+def test_fused_gram_schmidt_step_and_device_norms(ctx, ns, k, c0):
+    """eigd_stack_cgs2 / eigd_colnorm2_dev / eigd_scale_inv_norm against numpy"""
+    rng = np.random.default_rng(ns)
+    n, kw = 20011, k + c0
+    Wh = np.linalg.qr(rng.normal(size=(n, ns)))[0]             # the same orthonormal basis in every column
+    st = ctx.stack(ns, n, kw)
+    for j in range(ns):
+        st[j].copy_from(ctx.from_host(np.repeat(Wh[:, j:j + 1], kw, axis=1)))
+    T0 = rng.normal(size=(n, k)) + Wh @ rng.normal(size=(ns, k)) * 1e3   # large components along W: second pass needed
+    T = ctx.from_host(T0)
+    H, passes = st.cgs2(T, ns, c0=c0, tol=1e-13)
+    href = Wh.T @ T0
+    assert relerr(H, href) < 1e-12
+    Tn = T.get()
+    assert np.abs(Wh.T @ Tn).max() < 1e-10 * np.abs(T0).max()
+    assert relerr(Tn, T0 - Wh @ href) < 1e-9
+    assert passes in (2, 3, 4)
+    H2, passes2 = st.cgs2(T, ns, c0=c0, tol=1e-13)             # already orthogonal: nothing left to subtract
+    assert passes2 <= 4 and np.abs(H2).max() < 1e-9 * np.abs(T0).max()
+    n2 = T.colnorm2_dev()
+    assert relerr(n2.get()[0], np.sum(Tn * Tn, axis=0)) < 1e-13
+    assert np.array_equal(ctx.fetch_colnorm2(k), n2.get()[0])
+    skip = np.zeros(k, dtype=bool)
+    skip[0] = True
+    out = ctx.empty(n, k).assign_scaled_inverse(T, n2, skip).get()
+    ref = Tn / np.sqrt(np.sum(Tn * Tn, axis=0))
+    ref[:, 0] = 0.0
+    assert relerr(out, ref) < 1e-14
