@@ -277,9 +277,32 @@ def main():
         log(rank, f"df/dx check: adjoint {ans:.10e}  central difference {fd:.10e}  rel-err {accuracy['dfdx_fd_rel_err']:.2e} "
                   f"({time.perf_counter() - t0:.1f}s)")
 
-    # ------------------------------------------------------------------ roofline of the SpMV kernel (HIP events)
-    # K and G (same sparsity, 235 MB of traffic each) are applied alternately so that consecutive launches
-    # cannot be served from the 256 MiB Infinity Cache: this is the HBM-streaming rate of the kernel.
+    # ------------------------------------------------------------------ roofline of the dominant kernels (HIP events)
+    # The k-column triangular sweep (fwd_level_kernel + bwd_level_kernel, one launch per tree level and direction) is
+    # where a step spends most of its time.  One "launch" below = one sweep of N columns through the factor.
+    # Algorithmic bytes: every entry of L once per direction (2 * 8 * nnz(L)) plus the block
+    # read and written once (16 n N).  HBM traffic: FETCH_SIZE (doubled, the guide's gfx950 correction, calibrated on
+    # a stream of known size in the same run) + WRITE_SIZE from the PMC passes under profiles/; C3 default only.
+    Xs = ctx.from_host(rng.normal(size=(n, N)))
+    Xo = ctx.empty(n, N)
+    for _ in range(3):
+        factor.solve_device_to(Xs, Xo)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(10):
+        factor.solve_device_to(Xs, Xo)
+    sweep_ms = ctx.timer_stop_ms() / 10
+    sweep_bytes = factor.factor.solve_bytes(N)
+    default_c3 = (args.nx, args.ny, N, args.ordering) == (706, 706, 32, "geometric")
+    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+    roofline = {"kernel": "fwd_level_kernel + bwd_level_kernel (one sweep of the factor, all tree levels)",
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": 6579000000 if default_c3 else None,
+                "traffic_source": "profiles/r01_pmc_fetch_sweep_coldot.csv + r01_pmc_write_sweep_coldot.csv",
+                "bytes_per_launch": sweep_bytes, "us_per_launch": round(sweep_ms * 1e3, 1), "columns": N,
+                "nnzL": fstats["nnzL"]}
+    # SpMV, the bit-exact CSR-stream kernel: K and G (same sparsity, 235 MB of traffic each) are applied alternately
+    # so that consecutive launches cannot be served from the 256 MiB Infinity Cache
     x = ctx.from_host(rng.normal(size=n))
     y = ctx.empty(n, 1)
     y2 = ctx.empty(n, 1)
@@ -293,27 +316,12 @@ def main():
         dG.apply(x, y2)
     spmv_ms = ctx.timer_stop_ms() / (2 * (args.spmv_reps // 2))
     spmv_bytes = dK.spmv_bytes(1)
-    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled as the guide
-    # prescribes for gfx950 -- calibrated there on an 8-byte-per-lane stream of known size -- plus WRITE_SIZE);
-    # only valid for the default C3 matrix
-    traffic = 237996096 if (args.nx, args.ny) == (706, 706) else None
-    roofline = {"kernel": "spmv_stream_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_fetch_spmv_coldot.csv + r01_pmc_write_spmv_coldot.csv",
-                "bytes_per_launch": spmv_bytes, "us_per_launch": round(spmv_ms * 1e3, 2)}
-    # the k-column triangular sweep (the dominant cost of a step), same accounting
-    Xs = ctx.from_host(rng.normal(size=(n, N)))
-    factor.solve_device(Xs)
-    ctx.sync()
-    ctx.timer_start()
-    for _ in range(5):
-        factor.solve_device(Xs)
-    sweep_ms = ctx.timer_stop_ms() / 5
-    sweep_bytes = factor.factor.solve_bytes(N)
-    sweep = {"ms": round(sweep_ms, 3), "algorithmic_GBs": round(sweep_bytes / sweep_ms / 1e6, 1),
-             "frac_of_peak": round(sweep_bytes / sweep_ms / 1e6 / HBM_PEAK_GBS, 4), "columns": N,
-             "nnzL": fstats["nnzL"]}
+    spmv_rate = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+    spmv = {"kernel": "spmv_stream_kernel", "bound": "hbm", "achieved": round(spmv_rate, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(spmv_rate / HBM_PEAK_GBS, 4),
+            "traffic": 237996096 if (args.nx, args.ny) == (706, 706) else None,
+            "traffic_source": "profiles/r01_pmc_fetch_spmv_coldot.csv + r01_pmc_write_spmv_coldot.csv",
+            "bytes_per_launch": spmv_bytes, "us_per_launch": round(spmv_ms * 1e3, 2)}
 
     # ------------------------------------------------------------------ CPU baseline (oracle = port of the reference)
     cpu = None
@@ -339,7 +347,7 @@ def main():
                    "ordering": args.ordering,
                    "parallelism": f"modes sharded over {world} GPU(s), one df/dx all-reduce"},
         "roofline": roofline,
-        "sweep": sweep,
+        "spmv": spmv,
         "cpu_baseline": cpu,
         "accuracy": accuracy,
         "preamble_s": {k: round(v, 3) for k, v in timing.items()},
