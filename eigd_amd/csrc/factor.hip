@@ -2,8 +2,9 @@
 //
 // Replaces SuperLU behind eigd's SpLuOperator (eigd/eigenvector_derivatives.py:11-23).
 // The shifted matrix K - sigma M (or K + sigma G below the first buckling load) is
-// symmetric positive definite in every example of the reference, so the factor is
-// LL^T on a nested-dissection ordering:
+// symmetric positive definite in every example of the reference; the factor is
+// L S L^T (S = diag(+-1), all +1 then: plain Cholesky; negative entries = inertia of an
+// interior shift, no pivoting) on a nested-dissection ordering:
 //
 //   numeric : multifrontal.  Every front is a dense d x d square (d = own columns +
 //             border) in one big HBM buffer; levels of the assembly tree are processed
@@ -11,14 +12,17 @@
 //             step of W columns: potrf (+ explicit inverse of the W x W diagonal block),
 //             trsm as a product with that inverse, trailing update tile by tile.
 //   inverses: T = inv(L11) and M21 = L21 inv(L11) per front (two launches over all fronts).
-//   solve   : ONE launch per level of the assembly tree and direction.  Each front owns a d x k
-//             slice of a vector workspace; the forward sweep multiplies by [T; M21] and passes
-//             border carries child -> parent (gathered by the parent, fixed order), the
-//             backward sweep multiplies by the transpose and pulls x parent -> child.
-//             No atomics anywhere: the sweeps are bitwise reproducible.
+//   solve   : ONE launch per level of the assembly tree and direction.  The forward sweep
+//             multiplies the fronts' right-hand sides by [T; M21]; the carry of child number s
+//             of a front is written into carry plane s at the parent's rows, so the parent adds
+//             its rows of the planes in plane order (no index hop, no two writers per entry).
+//             The backward sweep multiplies by the transpose and gathers x of the border rows
+//             straight from the caller's block.  Long chains of big fronts are cut over several
+//             workgroups that hand partial blocks over in-launch (write-through stores + ticket).
+//             No floating-point atomics anywhere: the sweeps are bitwise reproducible.
 //
 // Per solve the kernels stream nnz(L) doubles twice (forward + backward) plus
-// O(sum of front dimensions) x k vector traffic: HBM bound for k <= 32.
+// O(sum of front dimensions) x k vector traffic.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
