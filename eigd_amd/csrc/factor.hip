@@ -589,8 +589,9 @@ __device__ __forceinline__ bool fold_groups(const WgRec& w, const LevelArgs& la,
 // Matrix tiles and vector blocks are register staged one step ahead (the gather indices two), so the loads of
 // step t+1 are in flight while step t multiplies.  Masked lanes load from a zero word (address select): a branch
 // around the load would serialise the loads of a tile.
-template <int KPT, bool SINGLE, bool DEEP>
-__global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
+template <int KPT, bool SINGLE, bool DEEP, int NSL>  // NSL: carry planes compiled in (2: binary trees, else kMaxS + 1)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((SINGLE && KPT == 4) ? 3 : 1)))
+void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
                                                             const double* __restrict__ Tb, const double* X, int ldx,
                                                             double alpha, double* V, double* __restrict__ Y) {
   using T = Tile<KPT>;
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
       double v = alpha * *(ok ? X + static_cast<int64_t>(xi[e]) * ldx + c : fa.zero);
       const double* cp = V + (vbase + ct * TW + idx / T::KB) * T::KB + c;
 #pragma unroll
-      for (int s = 0; s <= kMaxS; ++s) v += *((ok && s < nslot) ? cp + s * vslot : fa.zero);
+      for (int s = 0; s < NSL; ++s) v += *((ok && s < nslot) ? cp + s * vslot : fa.zero);
       bv[e] = v;
     }
   };
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
       const double* cp = V + (vbase + row0 + o) * T::KB + c;
       double v = 0.0;
 #pragma unroll
-      for (int s = 0; s <= kMaxS; ++s) v += *((ok && s < nslot) ? cp + s * vslot : fa.zero);
+      for (int s = 0; s < NSL; ++s) v += *((ok && s < nslot) ? cp + s * vslot : fa.zero);
       cg[t] = v;
     }
   };
@@ -711,7 +712,78 @@ __global__ __launch_bounds__(kThreads) void fwd_level_kernel(FrontArrays fa, Lev
     di[t] = -1;
   }
 
-  if constexpr (SINGLE) {  // one column tile: v1 is loaded once, the row tiles [s0, s1) are walked with it
+  if constexpr (SINGLE && KPT == 4) {  // (at KPT = 8 fragments + carries exceed the register budget of 3 waves per SIMD)
+    // One column tile, MFMA path: v1 goes to LDS once; after that barrier the four waves run on their own.  A wave
+    // owns output rows 16w..16w+15 of every row tile and loads exactly the matrix fragments its MFMAs consume,
+    // straight from global memory into the operand layout (lane (i, k) holds R(row0 + 16w + i, 4*kk + k)): no matrix
+    // tile in LDS, no barrier per tile, a third of the LDS footprint -- more workgroups per CU on the levels that
+    // hold most of the factor.  The next tile's fragments are requested as soon as the MFMAs of this one are issued.
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int orow = 16 * wave + li;
+    auto fetch_frag = [&](int rt, double (&a)[16]) {
+      const bool own = rt < nst;
+      const int row0 = own ? rt * TW : ns + (rt - nst) * TW;
+      const int rows = min(TW, (own ? ns : d) - row0);
+      const int ld = own ? ns : d;
+      const double* Ab = (own ? Tf : Ff) + row0;  // uniform base, 32-bit lane offsets (a tile spans < 2^31 doubles)
+      const ptrdiff_t zoff = fa.zero - Ab;        // masked lanes read the zero word
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int k = 4 * kk + lk;
+        a[kk] = (k < ns && orow < rows) ? Ab[static_cast<unsigned>(k * ld + orow)] : Ab[zoff];
+      }
+    };
+    auto stepd = [&](int rt, double (&cur)[16], int nxt) {
+      // 32 columns: the carries are requested after the products (registers: 3 waves per SIMD without spills)
+      if (KPT < 8 && rt >= nst) fetch_carry(rt, cg, di);
+      double4_t c[T::NT];
+#pragma unroll
+      for (int n = 0; n < T::NT; ++n) c[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int k = 4 * kk + lk;
+#pragma unroll
+        for (int n = 0; n < T::NT; ++n)
+          c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[kk], Bs[k * T::BLD + 16 * n + li], c[n], 0, 0, 0);
+      }
+      if (nxt < w.s1) fetch_frag(nxt, cur);
+#pragma unroll
+      for (int n = 0; n < T::NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[4 * n + r] = c[n][r];
+      if (KPT >= 8 && rt >= nst) fetch_carry(rt, cg, di);
+      store_tile(rt, acc, cg, di);
+    };
+    double a0[16];
+    fetch_idx(0);
+    fetch_frag(w.s0, a0);
+    // v1 -> LDS in two halves (register budget): X row + carries of half the lane's elements at a time
+    constexpr int HB = (IT > 4) ? IT / 2 : IT;
+#pragma unroll
+    for (int h = 0; h < IT; h += HB) {
+      double vh[HB];
+#pragma unroll
+      for (int e = h; e < h + HB; ++e) {
+        const int idx = threadIdx.x + e * kThreads;
+        const int c = idx & (T::KB - 1);
+        const bool ok = c < kb && xi[e] >= 0;
+        double v = alpha * *(ok ? X + static_cast<int64_t>(xi[e]) * ldx + c : fa.zero);
+        const double* cp = V + (vbase + idx / T::KB) * T::KB + c;
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) v += *((ok && s < nslot) ? cp + s * vslot : fa.zero);
+        vh[e - h] = v;
+      }
+#pragma unroll
+      for (int e = h; e < h + HB; ++e) {
+        const int idx = threadIdx.x + e * kThreads;
+        Bs[(idx / T::KB) * T::BLD + (idx & (T::KB - 1))] = vh[e - h];
+      }
+      asm volatile("" ::: "memory");  // keep the halves apart: the second half's loads are not hoisted above these stores
+    }
+    __syncthreads();
+    for (int rt = w.s0; rt < w.s1; ++rt) stepd(rt, a0, rt + 1);
+  } else if constexpr (SINGLE) {  // one column tile: v1 is loaded once, the row tiles [s0, s1) are walked with it
     auto step = [&](int rt, double (&cur)[TILE_IT], int nxt) {
       commit_a(cur);
       __syncthreads();
@@ -1034,14 +1106,24 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
       EIGD_LAUNCH_CHECK();
     }
     const int nwg = f->h_fwd_ptr[l + 1] - f->h_fwd_ptr[l], nsingle = f->h_fwd_nsingle[l];
+    const bool two = f->nslot <= 2;
     if (nsingle > 0) {
-      hipLaunchKernelGGL((fwd_level_kernel<KPT, true, kDeepSingle<KPT>>), dim3(nsingle), dim3(kThreads), 0, st, fa,
-                         level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
+      if (two)
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, kDeepSingle<KPT>, 2>), dim3(nsingle), dim3(kThreads), 0, st, fa,
+                           level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
+      else
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, kDeepSingle<KPT>, kMaxS + 1>), dim3(nsingle), dim3(kThreads), 0,
+                           st, fa, level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
       EIGD_LAUNCH_CHECK();
     }
     if (nwg > nsingle) {
-      hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false>), dim3(nwg - nsingle), dim3(kThreads), 0, st, fa,
-                         level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
+      if (two)
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, 2>), dim3(nwg - nsingle), dim3(kThreads), 0, st, fa,
+                           level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
+      else
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, kMaxS + 1>), dim3(nwg - nsingle), dim3(kThreads), 0, st,
+                           fa, level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), f->d_F, f->d_T, dIn, ldin, alpha, wV,
+                           wY);
       EIGD_LAUNCH_CHECK();
     }
   }
