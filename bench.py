@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--ordering", choices=("geometric", "algebraic"), default="geometric",
                     help="nested dissection with the mesh coordinates as a hint, or purely from the matrix graph")
     ap.add_argument("--pyprofile", default=None, help="write a cProfile summary of one extra step to this file")
+    ap.add_argument("--emulate-rank", default=None, help="r/P: time the mode share of rank r of P on this GPU (development aid)")
     ap.add_argument("--trace", default=None, help="write the per-iteration host timeline of one extra step to this file")
     ap.add_argument("--no-fd-check", action="store_true", help="skip the directional finite-difference check of df/dx")
     args = ap.parse_args()
@@ -92,6 +93,23 @@ def main():
         comm = TorchDistComm(device=torch.device("cuda", local_rank))
     if args.gpus != world:
         log(rank, f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if args.emulate_rank and world == 1:
+        # development aid: time the share of ONE rank of a P-rank job on this GPU (no collective; results are partial)
+        class _OneOfMany:
+            def __init__(self, r, p):
+                self.rank, self.size = r, p
+
+            def allreduce_sum(self, a):
+                return a
+
+            def allreduce_max(self, x):
+                return x
+
+            def barrier(self):
+                pass
+
+        r_, p_ = (int(x) for x in args.emulate_rank.split("/"))
+        comm = _OneOfMany(r_, p_)
 
     import eigd_amd as eg
     from eigd_amd.device import CSRMatrix, ElementBilinear, default_context
@@ -163,7 +181,7 @@ def main():
 
     def fence():
         ctx.sync()
-        if comm is not None:
+        if comm is not None and world > 1:
             import torch
 
             torch.cuda.synchronize()

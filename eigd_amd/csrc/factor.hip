@@ -1539,9 +1539,13 @@ static int solve_blocks(eigd_factor* f, hipStream_t st, double* wV, double* wY, 
   for (int c0 = 0; c0 < k; c0 += KBMAX) {
     const int kb = std::min(KBMAX, k - c0);
     int rc;
-    if (kb <= 4)
+    static const int min_kpt = [] {  // EIGD_SWEEP_MIN_KPT: development knob (route narrow sweeps through a wider kernel)
+      const char* v = std::getenv("EIGD_SWEEP_MIN_KPT");
+      return (v && *v) ? std::atoi(v) : 1;
+    }();
+    if (kb <= 4 && min_kpt <= 1)
       rc = sweep<1>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
-    else if (kb <= 8)
+    else if (kb <= 8 && min_kpt <= 2)
       rc = sweep<2>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else if (kb <= 16)
       rc = sweep<4>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
