@@ -518,6 +518,7 @@ struct WgRec {
   int64_t voff, foff, toff, bptr;
   int64_t pvoff;         // the parent's first row in V, -1 for a root
   int64_t scratch;       // 1: surplus child (slot >= kMaxS): its carry goes to the scratch plane, at its own border rows
+  int64_t ftoff;         // the front's block in the transposed copy Ft
 };
 
 struct LevelArgs {
@@ -939,6 +940,191 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
   }
 }
 
+// ------------------------------------------------------------------ narrow sweeps (k <= 8) of single-tile fronts
+// The bottom levels of the tree hold most of the factor in fronts with at most 64 own columns.  For a handful of
+// right-hand sides the tile kernels above are bound by LDS traffic and barriers, so these fronts get a leaner form:
+// ONE WAVE per 64-row tile, no LDS, no barrier.  Lane r of the wave owns output row r; it reads its matrix row
+// element by element (the wave reads whole 512-byte column segments), the right-hand side block lives one row per
+// lane in registers and is broadcast with v_readlane.  The backward sweep runs the same scheme on a transposed copy
+// of [T; M21] (Ft, row-major d x ns per front, made once after the factorisation).
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+template <int KB, int NSL>
+__global__ __launch_bounds__(128) void fwd_wave_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
+                                                       const double* __restrict__ F, const double* __restrict__ Tb,
+                                                       const double* X, int ldx, double alpha, double* V,
+                                                       double* __restrict__ Y, int kb) {
+  const WgRec w = recs[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ns = w.ns, d = ns + w.bs;
+  const bool kids = (w.flags & 2) != 0;
+  const int nslot = kids ? fa.nslot : 0;
+  const int64_t vslot = fa.vrows * KB, vbase = w.voff;
+  // v1, one row per lane: alpha * X[own row] + the carries on that row
+  double b[KB];
+  {
+    const bool ok = lane < ns;
+    const int xi = *(ok ? fa.v_src + vbase + lane : fa.neg1);
+    const double* cp = V + (vbase + lane) * KB;
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      const bool okc = ok && c < kb;
+      double v = alpha * *(okc ? X + static_cast<int64_t>(xi) * ldx + c : fa.zero);
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) v += *((okc && s < nslot) ? cp + s * vslot + c : fa.zero);
+      b[c] = v;
+    }
+  }
+  double* Vout = V + static_cast<int64_t>(w.slot) * vslot;
+  for (int rt = w.s0 + wave; rt < w.s1; rt += 2) {
+    const bool own = rt < 1;
+    const int row0 = own ? 0 : ns + (rt - 1) * TW;
+    const int rows = min(TW, (own ? ns : d) - row0);
+    const int ld = own ? ns : d;
+    const double* Ab = (own ? Tb + w.toff : F + w.foff) + row0;
+    const bool rok = lane < rows;
+    // carries on the tile's rows and where the results go (border tiles)
+    double cg[KB];
+    int di = -1;
+    if (!own) {
+      di = *(rok ? fa.rel + w.bptr + (row0 - ns) + lane : fa.neg1);
+      const double* cp = V + (vbase + row0 + lane) * KB;
+#pragma unroll
+      for (int c = 0; c < KB; ++c) {
+        double v = 0.0;
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) v += *((rok && c < kb && s < nslot) ? cp + s * vslot + c : fa.zero);
+        cg[c] = v;
+      }
+    }
+    double acc[KB];
+#pragma unroll
+    for (int c = 0; c < KB; ++c) acc[c] = 0.0;
+#pragma unroll
+    for (int k0 = 0; k0 < TW; k0 += 16) {
+      if (k0 < ns) {  // uniform
+        double a[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const int k = k0 + kk;
+          a[kk] = *((rok && k < ns) ? Ab + static_cast<int64_t>(k) * ld + lane : fa.zero);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+          for (int c = 0; c < KB; ++c) acc[c] += a[kk] * readlane_f64(b[c], k0 + kk);
+      }
+    }
+    if (own) {
+      const double sg = *(rok ? fa.sgn + w.c0 + lane : fa.zero);
+      double* yp = Y + (vbase + lane) * kb;
+#pragma unroll
+      for (int c = 0; c < KB; ++c)
+        if (rok && c < kb) yp[c] = sg * acc[c];
+    } else {
+      const int64_t drow = (w.scratch != 0) ? vbase + row0 + lane : w.pvoff + di;
+#pragma unroll
+      for (int c = 0; c < KB; ++c)
+        if (di >= 0 && c < kb) Vout[drow * KB + c] = cg[c] - acc[c];
+    }
+  }
+}
+
+// one wave per front (single column tile): x1 = T^T y - M21^T x_border with the transposed copy Ft
+template <int KB>
+__global__ __launch_bounds__(64) void bwd_wave_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
+                                                      const double* __restrict__ Ft, const double* __restrict__ Y,
+                                                      double* Out, int ldo, int kb) {
+  const WgRec w = recs[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int ns = w.ns, bs = w.bs, d = ns + bs;
+  const int64_t vbase = w.voff;
+  const int ntile = w.s1;  // 1 + border tiles (0 for a root)
+  const int* __restrict__ bout = fa.bout + w.bptr;
+  const double* Fp = Ft + w.ftoff;  // row r of [T; M21] at r * ns
+  const bool ook = lane < ns;
+  auto load_b = [&](int t, int ri, double (&b)[KB]) {
+    if (t == 0) {
+      const double* yp = Y + (vbase + lane) * kb;
+#pragma unroll
+      for (int c = 0; c < KB; ++c) b[c] = *((lane < ns && c < kb) ? yp + c : fa.zero);
+    } else {
+#pragma unroll
+      for (int c = 0; c < KB; ++c) b[c] = -*((ri >= 0 && c < kb) ? Out + static_cast<int64_t>(ri) * ldo + c : fa.zero);
+    }
+  };
+  auto load_idx = [&](int t) {  // border tile t >= 1: rows of the caller's block
+    const int r = (t - 1) * TW + lane;
+    return *((t >= 1 && t < ntile && r < bs) ? bout + r : fa.neg1);
+  };
+  double acc[KB], bc[KB], bn[KB];
+#pragma unroll
+  for (int c = 0; c < KB; ++c) acc[c] = bn[c] = 0.0;
+  load_b(0, -1, bc);
+  int ri = load_idx(1);
+  for (int t = 0; t < ntile; ++t) {
+    if (t + 1 < ntile) load_b(t + 1, ri, bn);
+    ri = load_idx(t + 2);
+    const int rbase = (t == 0) ? 0 : ns + (t - 1) * TW;
+    const int rows = min(TW, ((t == 0) ? ns : d) - rbase);
+    const double* Ap = Fp + static_cast<int64_t>(rbase) * ns + lane;
+#pragma unroll
+    for (int k0 = 0; k0 < TW; k0 += 16) {
+      if (k0 < rows) {  // uniform
+        double a[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const int k = k0 + kk;
+          a[kk] = *((ook && k < rows) ? Ap + static_cast<int64_t>(k) * ns : fa.zero);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+          for (int c = 0; c < KB; ++c) acc[c] += a[kk] * readlane_f64(bc[c], k0 + kk);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < KB; ++c) bc[c] = bn[c];
+  }
+  if (ook) {
+    double* op = Out + static_cast<int64_t>(fa.v_src[vbase + lane]) * ldo;
+#pragma unroll
+    for (int c = 0; c < KB; ++c)
+      if (c < kb) op[c] = acc[c];
+  }
+}
+
+// Ft(r, o) = [T; M21](r, o), row-major d x ns per front: 64 x 64 tiles through LDS
+__global__ __launch_bounds__(kThreads) void transpose_front_kernel(FrontArrays fa, const int* __restrict__ tr_pref,
+                                                                  int nfronts, const int64_t* __restrict__ ftoff,
+                                                                  const double* __restrict__ F,
+                                                                  const double* __restrict__ Tb, double* __restrict__ Ft) {
+  __shared__ double tile[TW][TW + 1];
+  const int f = find_slot(tr_pref, nfronts, blockIdx.x);
+  const int ns = fa.ns[f], d = ns + fa.bs[f];
+  const int nct = (ns + TW - 1) / TW;
+  const int local = blockIdx.x - tr_pref[f];
+  const int rt = local / nct, ct = local - rt * nct;
+  const int r0 = rt * TW, o0 = ct * TW;
+  const int r = threadIdx.x & (TW - 1), q = threadIdx.x >> 6;
+  for (int oo = q; oo < TW; oo += kThreads / TW) {  // coalesced along r
+    const int gr = r0 + r, go = o0 + oo;
+    double v = 0.0;
+    if (gr < d && go < ns)
+      v = (gr < ns) ? Tb[fa.toff[f] + static_cast<int64_t>(go) * ns + gr] : F[fa.foff[f] + static_cast<int64_t>(go) * d + gr];
+    tile[r][oo] = v;
+  }
+  __syncthreads();
+  for (int rr = q; rr < TW; rr += kThreads / TW) {  // coalesced along o
+    const int gr = r0 + rr, go = o0 + r;
+    if (gr < d && go < ns) Ft[ftoff[f] + static_cast<int64_t>(gr) * ns + go] = tile[rr][r];
+  }
+}
+
 }  // namespace eigd
 
 using namespace eigd;
@@ -963,6 +1149,15 @@ struct eigd_factor {
   double *d_T = nullptr, *d_aux = nullptr;  // aux: {0.0, (int) -1}
   std::vector<int> h_fwd_ptr, h_bwd_ptr;  // per level: first workgroup record
   std::vector<int> h_fwd_nsingle;         // per level: leading records of single-column-tile fronts (own kernel)
+  std::vector<int> h_bwd_nsingle;         // per level: leading backward records of single-column-tile fronts
+  // narrow sweeps (k <= 8): one record per single-tile front and level, the transposed copy of [T; M21]
+  WgRec* d_wave_wg = nullptr;
+  std::vector<int> h_wave_ptr;
+  int64_t* d_ftoff = nullptr;
+  int* d_tr_pref = nullptr;
+  double* d_Ft = nullptr;
+  int64_t ft_doubles = 0;
+  int n_tr = 0;
   std::vector<int> ov_lvl_ptr;       // per level: range of overflow rows (extra rows of V after the sumd front rows)
   int64_t t_doubles = 0, v_rows = 0;
   int n_tri = 0, n_m21 = 0;
@@ -1061,6 +1256,11 @@ int numeric(eigd_factor* f, const double* hdata) {
     hipLaunchKernelGGL(m21_kernel, dim3(f->n_m21), dim3(kThreads), 0, st, fa, f->d_m_pref, s.nfronts, f->d_F, f->d_T);
     EIGD_LAUNCH_CHECK();
   }
+  if (f->n_tr > 0) {
+    hipLaunchKernelGGL(transpose_front_kernel, dim3(f->n_tr), dim3(kThreads), 0, st, fa, f->d_tr_pref, s.nfronts, f->d_ftoff,
+                       f->d_F, f->d_T, f->d_Ft);
+    EIGD_LAUNCH_CHECK();
+  }
   int flag[2] = {0, 0};
   EIGD_HIP(hipMemcpyAsync(flag, f->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   EIGD_HIP(hipStreamSynchronize(st));
@@ -1107,7 +1307,21 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     }
     const int nwg = f->h_fwd_ptr[l + 1] - f->h_fwd_ptr[l], nsingle = f->h_fwd_nsingle[l];
     const bool two = f->nslot <= 2;
-    if (nsingle > 0) {
+    const int nwave = f->h_wave_ptr[l + 1] - f->h_wave_ptr[l];
+    bool narrow = false;
+    if constexpr (KPT <= 2) {
+      if (nwave > 0) {  // narrow sweep: one wave per tile of the single-tile fronts
+        if (two)
+          hipLaunchKernelGGL((fwd_wave_kernel<KB, 2>), dim3(nwave), dim3(128), 0, st, fa, f->d_wave_wg + f->h_wave_ptr[l],
+                             f->d_F, f->d_T, dIn, ldin, alpha, wV, wY, kb);
+        else
+          hipLaunchKernelGGL((fwd_wave_kernel<KB, kMaxS + 1>), dim3(nwave), dim3(128), 0, st, fa,
+                             f->d_wave_wg + f->h_wave_ptr[l], f->d_F, f->d_T, dIn, ldin, alpha, wV, wY, kb);
+        EIGD_LAUNCH_CHECK();
+        narrow = true;
+      }
+    }
+    if (!narrow && nsingle > 0) {
       if (two)
         hipLaunchKernelGGL((fwd_level_kernel<KPT, true, kDeepSingle<KPT>, 2>), dim3(nsingle), dim3(kThreads), 0, st, fa,
                            level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
@@ -1131,6 +1345,21 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
   for (int l = s.nlevels - 1; l >= 0; --l) {
     const int nwg = f->h_bwd_ptr[l + 1] - f->h_bwd_ptr[l];
     if (nwg == 0) continue;
+    const int nwave = f->h_wave_ptr[l + 1] - f->h_wave_ptr[l];
+    if constexpr (KPT <= 2) {
+      if (nwave > 0) {  // narrow sweep: the single-tile fronts go wave by wave, the others as always
+        const int nsb = f->h_bwd_nsingle[l];
+        if (nwg > nsb) {
+          hipLaunchKernelGGL(bwd_level_kernel<KPT>, dim3(nwg - nsb), dim3(kThreads), 0, st, fa,
+                             level_args(f->d_bwd_wg + f->h_bwd_ptr[l] + nsb), f->d_F, f->d_T, wY, dX, ldx);
+          EIGD_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(bwd_wave_kernel<KB>, dim3(nwave), dim3(64), 0, st, fa, f->d_wave_wg + f->h_wave_ptr[l],
+                           f->d_Ft, wY, dX, ldx, kb);
+        EIGD_LAUNCH_CHECK();
+        continue;
+      }
+    }
     hipLaunchKernelGGL(bwd_level_kernel<KPT>, dim3(nwg), dim3(kThreads), 0, st, fa,
                        level_args(f->d_bwd_wg + f->h_bwd_ptr[l]), f->d_F, f->d_T, wY, dX, ldx);
     EIGD_LAUNCH_CHECK();
@@ -1239,7 +1468,7 @@ int eigd_factor_free(eigd_factor* f) {
                   f->d_F,         f->d_Inv,         f->d_V,          f->d_Y,        f->d_flag,  f->d_fwd_wg,
                   f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_ov_dst,   f->d_ov_ptr, f->d_ov_src,
                   f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux,      f->d_bout,  f->d_tickets,
-                  f->d_P};
+                  f->d_P,         f->d_wave_wg,     f->d_ftoff,      f->d_tr_pref,  f->d_Ft};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;
@@ -1253,10 +1482,14 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   EIGD_HIP(hipSetDevice(ctx->device));
   // ---- host tables of the sweeps
   const int nf = s.nfronts;
-  std::vector<int64_t> toff(static_cast<size_t>(nf) + 1, 0);
+  std::vector<int64_t> toff(static_cast<size_t>(nf) + 1, 0), ftoff(static_cast<size_t>(nf) + 1, 0);
   std::vector<int> tri_pref(static_cast<size_t>(nf) + 1, 0), m_pref(static_cast<size_t>(nf) + 1, 0);
+  std::vector<int> tr_pref(static_cast<size_t>(nf) + 1, 0);
   for (int q = 0; q < nf; ++q) {
     const int64_t ns = s.f_ns[q];
+    const int64_t dq = ns + s.f_bs[q];
+    ftoff[q + 1] = ftoff[q] + dq * ns;
+    tr_pref[q + 1] = tr_pref[q] + static_cast<int>(((dq + TW - 1) / TW) * ((ns + TW - 1) / TW));
     toff[q + 1] = toff[q] + ns * ns;
     tri_pref[q + 1] = tri_pref[q] + static_cast<int>((ns + s.W - 1) / s.W);
     m_pref[q + 1] = m_pref[q] + (s.f_bs[q] + TW - 1) / TW;
@@ -1335,6 +1568,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     w.foff = s.f_foff[fr];
     w.toff = toff[fr];
     w.bptr = s.f_bptr[fr];
+    w.ftoff = ftoff[fr];
     const int par = s.f_parent[fr];
     w.pvoff = (par >= 0) ? s.f_voff[par] : -1;
     w.scratch = (child_no[fr] >= kMaxS) ? 1 : 0;
@@ -1359,9 +1593,11 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
       ++n_tickets;
     }
   };
-  std::vector<int> h_fwd_nsingle(static_cast<size_t>(s.nlevels), 0);
+  std::vector<int> h_fwd_nsingle(static_cast<size_t>(s.nlevels), 0), h_bwd_nsingle(static_cast<size_t>(s.nlevels), 0);
+  std::vector<WgRec> wave_wg;
+  std::vector<int> h_wave_ptr(static_cast<size_t>(s.nlevels) + 1, 0);
   for (int l = 0; l < s.nlevels; ++l) {
-    std::vector<WgRec> multi;
+    std::vector<WgRec> multi, bmulti;
     const int nfl = s.lvl_ptr[l + 1] - s.lvl_ptr[l];
     const bool sparse_level = nfl < 256;  // few fronts: parallelism has to come from inside the fronts
     const bool split_level = nfl <= split_nfl;   // the join of split chains costs an agent-scope acquire: only where chains are long
@@ -1370,6 +1606,17 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
       const int nst = (s.f_ns[fr] + TW - 1) / TW, nbt = (s.f_bs[fr] + TW - 1) / TW;
       const int kids = has_kids[fr] ? 2 : 0;
       if (nst == 1) {  // single column tile: the right-hand side block is loaded once per workgroup
+        {
+          WgRec w;  // narrow sweeps: one record per front, waves take the row tiles
+          front_numbers(w, fr);
+          w.tile = 0;
+          w.s0 = 0;
+          w.s1 = nst + nbt;
+          w.slab = w.cnt = 0;
+          w.G = 1;
+          w.flags = 1 | kids;
+          wave_wg.push_back(w);
+        }
         const int per = sparse_level ? 1 : nst + nbt;
         for (int t = 0; t < nst + nbt; t += per) {
           WgRec w;
@@ -1387,9 +1634,13 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
           push_chain(multi, fwd_slabs, fr, t, t < nst ? t + 1 : nst, split_level, kids);
       }
       const int nbt_b = (s.f_parent[fr] >= 0) ? nbt : 0;
-      for (int t = 0; t < nst; ++t) push_chain(bwd_wg, bwd_slabs, fr, t, nst - t + nbt_b, split_level, 0);
+      for (int t = 0; t < nst; ++t)
+        push_chain(nst == 1 ? bwd_wg : bmulti, bwd_slabs, fr, t, nst - t + nbt_b, split_level, 0);
     }
     h_fwd_nsingle[l] = static_cast<int>(fwd_wg.size()) - h_fwd_ptr[l];
+    h_bwd_nsingle[l] = static_cast<int>(bwd_wg.size()) - h_bwd_ptr[l];
+    bwd_wg.insert(bwd_wg.end(), bmulti.begin(), bmulti.end());
+    h_wave_ptr[l + 1] = static_cast<int>(wave_wg.size());
     fwd_wg.insert(fwd_wg.end(), multi.begin(), multi.end());
     h_fwd_ptr[l + 1] = static_cast<int>(fwd_wg.size());
     h_bwd_ptr[l + 1] = static_cast<int>(bwd_wg.size());
@@ -1401,7 +1652,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   size_t free_b = 0, total_b = 0;
   EIGD_HIP(hipMemGetInfo(&free_b, &total_b));
   const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + toff[nf] +
-                                        (2 * nplanes + 1) * v_rows * KBMAX + n_slabs * TW * KBMAX) +
+                                        ftoff[nf] + (2 * nplanes + 1) * v_rows * KBMAX + n_slabs * TW * KBMAX) +
                       16 * s.a_src.size() + (size_t(64) << 20);
   if (need > free_b) {
     set_error("factor needs %.2f GiB of device memory, %.2f GiB free", need / 1073741824.0, free_b / 1073741824.0);
@@ -1412,6 +1663,10 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   f->sym = &h->s;
   f->h_fwd_ptr = h_fwd_ptr;
   f->h_fwd_nsingle = h_fwd_nsingle;
+  f->h_bwd_nsingle = h_bwd_nsingle;
+  f->h_wave_ptr = h_wave_ptr;
+  f->ft_doubles = ftoff[nf];
+  f->n_tr = tr_pref[nf];
   f->h_bwd_ptr = h_bwd_ptr;
   f->ov_lvl_ptr = ov_lvl_ptr;
   f->t_doubles = toff[nf];
@@ -1439,6 +1694,9 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   UP(d_pref_tiles, s.pref_tiles)
   UP(d_fwd_wg, fwd_wg)
   UP(d_bwd_wg, bwd_wg)
+  UP(d_wave_wg, wave_wg)
+  UP(d_ftoff, ftoff)
+  UP(d_tr_pref, tr_pref)
   UP(d_bout, bout)
   UP(d_tri_pref, tri_pref)
   UP(d_m_pref, m_pref)
@@ -1471,6 +1729,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   rc = dmalloc(&f->d_Inv, s.inv_doubles);
   rc = dmalloc(&f->d_T, static_cast<size_t>(f->t_doubles));
   rc = dmalloc(&f->d_aux, 2);
+  rc = dmalloc(&f->d_Ft, static_cast<size_t>(f->ft_doubles));
   rc = dmalloc(&f->d_P, static_cast<size_t>(n_slabs) * TW * KBMAX);
   if (rc == EIGD_OK) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_tickets), sizeof(int) * f->n_tickets);
