@@ -1287,6 +1287,10 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
   // entries no child writes stay zero for good
   constexpr int KB = 4 * KPT;
   wV += static_cast<int64_t>(f->nplanes) * f->v_rows * (KB - 4);  // 4 + 8 + ... below KB = KB - 4
+  static const int wave_max_kpt = [] {  // widest sweep that uses the wave-per-tile kernels for single-tile fronts
+    const char* v = std::getenv("EIGD_WAVE_MAX_KPT");
+    return (v && *v) ? std::atoi(v) : 2;
+  }();
   auto level_args = [&](const WgRec* wg) {
     LevelArgs la;
     la.wg = wg;
@@ -1309,7 +1313,7 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     const bool two = f->nslot <= 2;
     const int nwave = f->h_wave_ptr[l + 1] - f->h_wave_ptr[l];
     bool narrow = false;
-    if constexpr (KPT <= 2) {
+    if (KPT <= wave_max_kpt) {
       if (nwave > 0) {  // narrow sweep: one wave per tile of the single-tile fronts
         if (two)
           hipLaunchKernelGGL((fwd_wave_kernel<KB, 2>), dim3(nwave), dim3(128), 0, st, fa, f->d_wave_wg + f->h_wave_ptr[l],
@@ -1346,7 +1350,7 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     const int nwg = f->h_bwd_ptr[l + 1] - f->h_bwd_ptr[l];
     if (nwg == 0) continue;
     const int nwave = f->h_wave_ptr[l + 1] - f->h_wave_ptr[l];
-    if constexpr (KPT <= 2) {
+    if (KPT <= wave_max_kpt) {
       if (nwave > 0) {  // narrow sweep: the single-tile fronts go wave by wave, the others as always
         const int nsb = f->h_bwd_nsingle[l];
         if (nwg > nsb) {
