@@ -53,6 +53,7 @@ class Context:
 
     def close(self):
         if self.h is not None and self.h.value:
+            self.trim_pool()
             _ffi.lib().eigd_ctx_destroy(self.h)
             self.h = None
 
@@ -100,6 +101,17 @@ class Context:
 
     def release_workspaces(self):
         self.__dict__.pop("_ws", None)
+        self.trim_pool()
+
+    def trim_pool(self):
+        """give the pooled (released, reusable) device blocks back to the driver"""
+        pool = self.__dict__.pop("_pool", {})
+        self.__dict__["_pool_bytes"] = 0
+        if self.h is None:
+            return
+        for free in pool.values():
+            for ptr in free:
+                _ffi.lib().eigd_free(self.h, c_vp(ptr))
 
 
 def default_context():
@@ -115,20 +127,46 @@ def default_context():
     return _default_ctx
 
 
+_POOL_KEEP_PER_SIZE = 6           # blocks of one size kept for reuse
+_POOL_MAX_BYTES = 24 * 1024**3     # and in total (the Krylov workspaces have their own cache)
+
+
 class _Buffer:
-    """owning device allocation"""
+    """
+    Owning device allocation.  Released blocks go to a per-context pool keyed by size and are handed out again:
+    a step allocates the same n x k temporaries every time, and hipMalloc / hipFree of 256 MB blocks cost up to
+    milliseconds (hipFree also waits for the device).  Stream order makes the reuse safe: all work goes through the
+    context's one stream.
+    """
 
     def __init__(self, ctx, nbytes):
         self.ctx = ctx
-        p = c_vp()
-        call("eigd_malloc", ctx.h, int(nbytes), C.byref(p))
-        self.ptr = p.value
         self.nbytes = int(nbytes)
+        pool = ctx.__dict__.setdefault("_pool", {})
+        free = pool.get(self.nbytes)
+        if free:
+            self.ptr = free.pop()
+            ctx.__dict__["_pool_bytes"] = ctx.__dict__.get("_pool_bytes", 0) - self.nbytes
+            return
+        p = c_vp()
+        try:
+            call("eigd_malloc", ctx.h, self.nbytes, C.byref(p))
+        except _ffi.EigdHipError:
+            ctx.trim_pool()  # out of memory: give the pooled blocks back and try once more
+            call("eigd_malloc", ctx.h, self.nbytes, C.byref(p))
+        self.ptr = p.value
 
     def __del__(self):
         try:
             if getattr(self, "ptr", None) and self.ctx.h is not None:
-                _ffi.lib().eigd_free(self.ctx.h, c_vp(self.ptr))
+                pool = self.ctx.__dict__.setdefault("_pool", {})
+                free = pool.setdefault(self.nbytes, [])
+                held = self.ctx.__dict__.get("_pool_bytes", 0)
+                if len(free) < _POOL_KEEP_PER_SIZE and held + self.nbytes <= _POOL_MAX_BYTES:
+                    free.append(self.ptr)
+                    self.ctx.__dict__["_pool_bytes"] = held + self.nbytes
+                else:
+                    _ffi.lib().eigd_free(self.ctx.h, c_vp(self.ptr))
                 self.ptr = None
         except Exception:
             pass
