@@ -331,6 +331,11 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(int n, int ku, int kx
 // conflict-free row stride), so the LDS traffic per flop is an eighth of a scalar inner loop.
 __device__ __forceinline__ int cs_stride(int kx) { return (kx % 32 == 0) ? kx + 16 : kx; }
 
+// masked lanes load this word (address select) instead of branching around the load: loads in divergent branches
+// make the compiler wait for ALL outstanding memory operations (vmcnt(0)) at every later use -- including every
+// store, which then run one at a time
+__device__ const double g_zero_word = 0.0;
+
 __global__ __launch_bounds__(kThreads) void gemm_nn_kernel(int n, int ku, int kx, const double* __restrict__ U,
                                                           int64_t rsu, int64_t csu, const double* __restrict__ C,
                                                           double* __restrict__ X, int ldx, double alpha, double beta) {
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nn_kernel(int n, int ku, int kx
     const int rows = static_cast<int>((n - base) < kRB ? (n - base) : kRB);
     const double* ub = U + base * rsu;
 #pragma unroll
-    for (int it = 0; it < IT; ++it) tmp[it] = (srow[it] < rows) ? ub[goff[it]] : 0.0;
+    for (int it = 0; it < IT; ++it) tmp[it] = *((srow[it] < rows) ? ub + goff[it] : &g_zero_word);
   };
   int64_t base = static_cast<int64_t>(blockIdx.x) * kRB;
   if (base < n) fetch(base);
@@ -391,24 +396,40 @@ __global__ __launch_bounds__(kThreads) void gemm_nn_kernel(int n, int ku, int kx
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = 16 * wave + lk + 4 * reg, b = tb * 16 + li;
-        xv[tb][reg] = (beta != 0.0 && tb < ntb && r < rows && b < kx) ? X[(base + r) * ldx + b] : 0.0;
+        xv[tb][reg] = *((beta != 0.0 && tb < ntb && r < rows && b < kx) ? X + (base + r) * ldx + b : &g_zero_word);
       }
+    // products of all column tiles first ...
+    double4_t accs[4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      accs[tb] = double4_t{0.0, 0.0, 0.0, 0.0};
+      if (tb >= ntb) continue;
+      const int b = tb * 16 + li;
+      const bool okb = b < kx;
+      for (int k0 = 0; k0 < ku4; k0 += 4) {
+        const int k = k0 + lk;
+        const double av = (k < ku) ? Us[(16 * wave + li) * uld + k] : 0.0;
+        const double bv = (k < ku && okb) ? Cs[k * cld + b] : 0.0;
+        accs[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, accs[tb], 0, 0, 0);
+      }
+    }
+    // ... then ONE explicit wait for everything in flight (the block of X, the prefetched rows of U) ahead of the
+    // stores: otherwise every masked store block below gets its own vmcnt(0), which also waits for the store before it
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt / expcnt untouched
 #pragma unroll
     for (int tb = 0; tb < 4; ++tb) {
       if (tb >= ntb) break;
       const int b = tb * 16 + li;
       const bool okb = b < kx;
-      double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
-      for (int k0 = 0; k0 < ku4; k0 += 4) {
-        const int k = k0 + lk;
-        const double av = (k < ku) ? Us[(16 * wave + li) * uld + k] : 0.0;
-        const double bv = (k < ku && okb) ? Cs[k * cld + b] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
+      // values first, stores after: a store's data register must not be reused before the store has completed
+      double outv[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        outv[reg] = (beta == 0.0) ? alpha * accs[tb][reg] : beta * xv[tb][reg] + alpha * accs[tb][reg];
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = 16 * wave + lk + 4 * reg;  // f64 MFMA result map: row = (l>>4) + 4*reg, col = l&15
-        if (r < rows && okb) X[(base + r) * ldx + b] = (beta == 0.0) ? alpha * acc[reg] : beta * xv[tb][reg] + alpha * acc[reg];
+        if (r < rows && okb) X[(base + r) * ldx + b] = outv[reg];
       }
     }
   }
@@ -485,8 +506,13 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
 
 static int gemm_nn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu,
                           const double* dC, double* dX, int ldx, double alpha, double beta) {
-  const int nb = grid_for_rows(n, kRB);
   const size_t cs_bytes = sizeof(double) * (ku * ((kx % 32 == 0) ? kx + 16 : kx) + kRB * (ku + 1));
+  // a grid-stride kernel whose workgroups do not all fit the chip at once runs a second, thinly occupied round:
+  // launch exactly what is resident
+  int per_cu = 0;
+  EIGD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_nn_kernel, kThreads, cs_bytes));
+  const int resident = std::max(1, per_cu) * ctx->n_cu;
+  const int nb = std::min(grid_for_rows(n, kRB), resident);
   hipLaunchKernelGGL(gemm_nn_kernel, dim3(nb), dim3(kThreads), cs_bytes, ctx->stream, n, ku, kx, dU, rsu, csu, dC, dX,
                      ldx, alpha, beta);
   EIGD_LAUNCH_CHECK();

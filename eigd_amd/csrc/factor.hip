@@ -685,6 +685,9 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
     const bool own = rt < nst;
     const int row0 = own ? rt * TW : ns + (rt - nst) * TW;
     const int rows = min(TW, (own ? ns : d) - row0);
+    // values first, ONE explicit wait, then the stores (a load inside each masked store block would make every
+    // store wait for the one before it)
+    double ov[T::NOUT];
     if (own) {
       const double* sgp = fa.sgn + w.c0 + row0;
       double* Yf = Y + (vbase + row0) * kb;
@@ -692,15 +695,25 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
       for (int t = 0; t < T::NOUT; ++t) {
         int o, c;
         T::coords(t, o, c);
-        if (o < rows && c < kb) Yf[static_cast<int64_t>(o) * kb + c] = sgp[o] * acc[t];
+        ov[t] = *((o < rows && c < kb) ? sgp + o : fa.zero) * acc[t];
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+      for (int t = 0; t < T::NOUT; ++t) {
+        int o, c;
+        T::coords(t, o, c);
+        if (o < rows && c < kb) Yf[static_cast<int64_t>(o) * kb + c] = ov[t];
       }
     } else {
+#pragma unroll
+      for (int t = 0; t < T::NOUT; ++t) ov[t] = cg[t] - acc[t];
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll
       for (int t = 0; t < T::NOUT; ++t) {
         int o, c;
         T::coords(t, o, c);
         const int64_t drow = (w.scratch != 0) ? vbase + row0 + o : w.pvoff + di[t];
-        if (di[t] >= 0) Vout[drow * T::KB + c] = cg[t] - acc[t];
+        if (di[t] >= 0) Vout[drow * T::KB + c] = ov[t];
       }
     }
   };
@@ -932,11 +945,21 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
     __syncthreads();
   }
   if (w.G > 1 && !fold_groups<KPT>(w, la, acc, reinterpret_cast<int*>(As))) return;
+  // destination rows first, ONE explicit wait, then the stores: an index load inside each masked store block would
+  // make every store wait for the one before it (vmcnt(0) per block)
+  int oi[T::NOUT];
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) {
     int o, c;
     T::coords(t, o, c);
-    if (o < wc && c < kb) Out[static_cast<int64_t>(fa.v_src[vbase + c0t + o]) * ldo + c] = acc[t];
+    oi[t] = *((o < wc && c < kb) ? fa.v_src + vbase + c0t + o : fa.neg1);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+  for (int t = 0; t < T::NOUT; ++t) {
+    int o, c;
+    T::coords(t, o, c);
+    if (oi[t] >= 0) Out[static_cast<int64_t>(oi[t]) * ldo + c] = acc[t];
   }
 }
 
@@ -1022,11 +1045,13 @@ __global__ __launch_bounds__(128) void fwd_wave_kernel(FrontArrays fa, const WgR
     if (own) {
       const double sg = *(rok ? fa.sgn + w.c0 + lane : fa.zero);
       double* yp = Y + (vbase + lane) * kb;
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one wait, then the stores back to back
 #pragma unroll
       for (int c = 0; c < KB; ++c)
         if (rok && c < kb) yp[c] = sg * acc[c];
     } else {
       const int64_t drow = (w.scratch != 0) ? vbase + row0 + lane : w.pvoff + di;
+      __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
       for (int c = 0; c < KB; ++c)
         if (di >= 0 && c < kb) Vout[drow * KB + c] = cg[c] - acc[c];
@@ -1090,8 +1115,10 @@ __global__ __launch_bounds__(64) void bwd_wave_kernel(FrontArrays fa, const WgRe
 #pragma unroll
     for (int c = 0; c < KB; ++c) bc[c] = bn[c];
   }
-  if (ook) {
-    double* op = Out + static_cast<int64_t>(fa.v_src[vbase + lane]) * ldo;
+  const int oi = *(ook ? fa.v_src + vbase + lane : fa.neg1);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one wait, then the stores back to back
+  if (oi >= 0) {
+    double* op = Out + static_cast<int64_t>(oi) * ldo;
 #pragma unroll
     for (int c = 0; c < KB; ++c)
       if (c < kb) op[c] = acc[c];

@@ -12,7 +12,7 @@ phase = None
 acc = defaultdict(list)
 for r in rows:
     name = r["Kernel_Name"]
-    m = re.search(r"spmm_rows_kernel<(\d+)>", name)
+    m = re.search(r"spmm_(?:rows|tiled)_kernel<(\d+)>", name)
     if m:
         phase = int(m.group(1))
     if phase is None:
