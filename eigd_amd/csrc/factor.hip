@@ -572,10 +572,21 @@ __device__ __forceinline__ bool fold_groups(const WgRec& w, const LevelArgs& la,
   }
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < T::NOUT; ++t) {
-    double s = 0.0;
-    for (int gg = 0; gg < w.G; ++gg) s += Pp[static_cast<int64_t>(gg) * (TW * KBMAX) + t * kThreads + threadIdx.x];
-    acc[t] = s;
+  for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
+  for (int gg = 0; gg < w.G; gg += 2) {  // two slabs per trip, all their loads in flight; sums in slab order
+    const double* p0 = Pp + static_cast<int64_t>(gg) * (TW * KBMAX) + threadIdx.x;
+    const bool two = gg + 1 < w.G;
+    double a[T::NOUT], b[T::NOUT];
+#pragma unroll
+    for (int t = 0; t < T::NOUT; ++t) {
+      a[t] = p0[t * kThreads];
+      b[t] = two ? p0[TW * KBMAX + t * kThreads] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < T::NOUT; ++t) {
+      acc[t] += a[t];
+      if (two) acc[t] += b[t];
+    }
   }
   return true;
 }
