@@ -635,14 +635,12 @@ bool analyze(int n, const int32_t* ip, const int32_t* ix, int leaf_size, int pan
   s.ls_pref_ptr.assign(nls + 1, 0);
   s.pref_chunks.clear();
   s.pref_tiles.clear();
-  s.pref_work.clear();
   for (int l = 0; l < s.nlevels; ++l) {
     for (int st = 0; st < s.lvl_nsteps[l]; ++st) {
       const int rec = s.ls_ptr[l] + st;
       int na = 0;
       s.pref_chunks.push_back(0);
       s.pref_tiles.push_back(0);
-      s.pref_work.push_back(0);
       for (int q = s.lvl_ptr[l]; q < s.lvl_ptr[l + 1]; ++q) {
         int f = s.lvl_fronts[q];
         if (s.f_npanels[f] <= st) break;
@@ -656,7 +654,6 @@ bool analyze(int n, const int32_t* ip, const int32_t* ix, int leaf_size, int pan
           s.error = "level too large for 32-bit tile indices";
           return false;
         }
-        s.pref_work.push_back(s.pref_work.back() + std::max(1, nch));
         s.pref_chunks.push_back(static_cast<int>(pc));
         s.pref_tiles.push_back(static_cast<int>(pt));
       }
@@ -664,28 +661,6 @@ bool analyze(int n, const int32_t* ip, const int32_t* ix, int leaf_size, int pan
       s.ls_pref_ptr[rec + 1] = static_cast<int64_t>(s.pref_chunks.size());
     }
   }
-  s.lvl_pp_ptr.assign(s.nlevels + 1, 0);
-  s.pref_panels.clear();
-  s.pref_bwork.clear();
-  s.f_poff.assign(nn, -1);
-  s.nslabs = 0;
-  for (int l = 0; l < s.nlevels; ++l) {
-    s.lvl_pp_ptr[l] = static_cast<int64_t>(s.pref_panels.size());
-    s.pref_panels.push_back(0);
-    s.pref_bwork.push_back(0);
-    for (int q = s.lvl_ptr[l]; q < s.lvl_ptr[l + 1]; ++q) {
-      const int f = s.lvl_fronts[q];
-      const int ntiles = (s.f_bs[f] + s.CH - 1) / s.CH;
-      const int ngroups = std::max(1, (ntiles + s.BG - 1) / s.BG);
-      s.pref_panels.push_back(s.pref_panels.back() + s.f_npanels[f]);
-      s.pref_bwork.push_back(s.pref_bwork.back() + s.f_npanels[f] * ngroups);
-      if (ngroups > 1) {
-        s.f_poff[f] = static_cast<int>(s.nslabs);
-        s.nslabs += static_cast<int64_t>(s.f_npanels[f]) * ngroups;
-      }
-    }
-  }
-  s.lvl_pp_ptr[s.nlevels] = static_cast<int64_t>(s.pref_panels.size());
   // extend-add lists by (level of the parent, slot of the child)
   if (s.maxslots < 1) s.maxslots = 1;
   s.cs_ptr.assign(static_cast<size_t>(s.nlevels) * s.maxslots + 1, 0);

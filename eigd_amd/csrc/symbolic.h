@@ -37,15 +37,6 @@ struct Symbolic {
   std::vector<int64_t> ls_pref_ptr;       // per (level, step): offset into pref arrays (nactive + 1 entries each)
   std::vector<int> pref_chunks;           // prefix sums of row chunks below the panel
   std::vector<int> pref_tiles;            // prefix sums of chunks^2 (trailing update tiles)
-  std::vector<int> pref_work;             // prefix sums of max(1, chunks): workgroups of a fused forward step
-  std::vector<int64_t> lvl_pp_ptr;        // per level: offset into pref_panels (nfronts_in_level + 1 entries each)
-  std::vector<int> pref_panels;           // per level: prefix sums of the fronts' panel counts
-  // backward border products: a front's border tiles are split into groups of BG tiles; fronts with more
-  // than one group go through partial slabs (f_poff = first slab, -1 otherwise)
-  int BG = 4;
-  std::vector<int> pref_bwork;            // per level (same offsets as pref_panels): prefix of npanels * ngroups
-  std::vector<int> f_poff;                // per front
-  int64_t nslabs = 0;
   // extend-add lists: children of the fronts of a level, grouped by child slot
   int maxslots = 0;
   std::vector<int> cs_ptr;                // nlevels * maxslots + 1
