@@ -318,3 +318,25 @@ def test_fused_gram_schmidt_step_and_device_norms(ctx, ns, k, c0):
     ref = Tn / np.sqrt(np.sum(Tn * Tn, axis=0))
     ref[:, 0] = 0.0
     assert relerr(out, ref) < 1e-13
+
+
+def test_split_chain_hand_off_is_reproducible_over_many_sweeps(ctx):
+    """the in-launch hand-off of partial blocks (big fronts near the root) gives the same bits sweep after sweep"""
+    from eigd_amd.device import Factor
+
+    A = grid_matrix(220, 210, 2, seed=11)          # top separators of ~440 dofs: chains of 7 tiles, cut into groups
+    F = Factor(ctx, A)
+    rng = np.random.default_rng(5)
+    ref = {}
+    for k in (4, 32):
+        B = ctx.from_host(rng.normal(size=(A.shape[0], k)))
+        X = ctx.empty(A.shape[0], k)
+        F.solve_to(B, X)
+        ref[k] = (B, X.get())
+        assert np.linalg.norm(A @ ref[k][1] - B.get()) / np.linalg.norm(B.get()) < 1e-12
+    for it in range(150):
+        k = 4 if it % 3 else 32
+        B, x0 = ref[k]
+        X = ctx.empty(A.shape[0], k)
+        F.solve_to(B, X)
+        assert np.array_equal(X.get(), x0), (it, k)
