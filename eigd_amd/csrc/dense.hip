@@ -336,6 +336,71 @@ __device__ __forceinline__ int cs_stride(int kx) { return (kx % 32 == 0) ? kx + 
 // store, which then run one at a time
 __device__ const double g_zero_word = 0.0;
 
+// Row-major U (csu == 1): every wave works alone on 16-row groups and feeds its MFMAs with fragments of U loaded
+// straight from global memory (lane (i, k) holds U(base + i, 4 q + k): 32-byte pieces of the rows, every line is
+// used up by the eight loads of the group).  No LDS for U, no barrier after the one that publishes C, few registers:
+// many waves per CU keep the stream of U going.  NQ = ceil(ku / 4) compiled in (8 or 16).
+template <int NQ>
+__global__ __launch_bounds__(kThreads) void gemm_nn_direct_kernel(int n, int ku, int kx, const double* __restrict__ U,
+                                                                 int64_t rsu, const double* __restrict__ C,
+                                                                 double* __restrict__ X, int ldx, double alpha,
+                                                                 double beta) {
+  extern __shared__ double Cs[];  // ku x cs_stride(kx)
+  const int tid = threadIdx.x;
+  const int cld = cs_stride(kx);
+  for (int q = tid; q < ku * kx; q += kThreads) Cs[(q / kx) * cld + q % kx] = C[q];
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ntb = (kx + 15) >> 4;  // <= 4
+  const int64_t ngroups = (static_cast<int64_t>(n) + 15) / 16;
+  const int64_t gstride = static_cast<int64_t>(gridDim.x) * 4;
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave; g < ngroups; g += gstride) {
+    const int64_t base = g * 16;
+    const int rows = static_cast<int>((n - base) < 16 ? (n - base) : 16);
+    const double* up = U + (base + li) * rsu + lk;
+    double a[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = *((li < rows && 4 * q + lk < ku) ? up + 4 * q : &g_zero_word);
+    double xv[4][4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = lk + 4 * reg, b = tb * 16 + li;
+        xv[tb][reg] = *((beta != 0.0 && tb < ntb && r < rows && b < kx) ? X + (base + r) * ldx + b : &g_zero_word);
+      }
+    double4_t accs[4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      accs[tb] = double4_t{0.0, 0.0, 0.0, 0.0};
+      if (tb >= ntb) continue;
+      const int b = tb * 16 + li;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int k = 4 * q + lk;
+        const double bv = (k < ku && b < kx) ? Cs[k * cld + b] : 0.0;
+        accs[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bv, accs[tb], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one wait, then the stores back to back
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      if (tb >= ntb) break;
+      const int b = tb * 16 + li;
+      double outv[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        outv[reg] = (beta == 0.0) ? alpha * accs[tb][reg] : beta * xv[tb][reg] + alpha * accs[tb][reg];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = lk + 4 * reg;  // f64 MFMA result map: row = (l>>4) + 4*reg, col = l&15
+        if (r < rows && b < kx) X[(base + r) * ldx + b] = outv[reg];
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void gemm_nn_kernel(int n, int ku, int kx, const double* __restrict__ U,
                                                           int64_t rsu, int64_t csu, const double* __restrict__ C,
                                                           double* __restrict__ X, int ldx, double alpha, double beta) {
@@ -507,6 +572,18 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
 static int gemm_nn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu,
                           const double* dC, double* dX, int ldx, double alpha, double beta) {
   const size_t cs_bytes = sizeof(double) * (ku * ((kx % 32 == 0) ? kx + 16 : kx) + kRB * (ku + 1));
+  if (csu == 1 && ku <= 64) {  // row-major U: wave-private streaming without LDS staging
+    const size_t cbytes = sizeof(double) * ku * ((kx % 32 == 0) ? kx + 16 : kx);
+    const int nbd = grid_for_rows(n, 64);
+    if (ku <= 32)
+      hipLaunchKernelGGL(gemm_nn_direct_kernel<8>, dim3(nbd), dim3(kThreads), cbytes, ctx->stream, n, ku, kx, dU, rsu, dC,
+                         dX, ldx, alpha, beta);
+    else
+      hipLaunchKernelGGL(gemm_nn_direct_kernel<16>, dim3(nbd), dim3(kThreads), cbytes, ctx->stream, n, ku, kx, dU, rsu, dC,
+                         dX, ldx, alpha, beta);
+    EIGD_LAUNCH_CHECK();
+    return EIGD_OK;
+  }
   // a grid-stride kernel whose workgroups do not all fit the chip at once runs a second, thinly occupied round:
   // launch exactly what is resident
   int per_cu = 0;
