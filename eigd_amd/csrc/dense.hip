@@ -789,10 +789,20 @@ int eigd_stack_cgs2(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
     rc = stack_axpy_dot_device(ctx, n, k, ns, dS, slab, lds, ctx->coef, dT, ldt, -1.0, &res);
     if (rc) return rc;
   } else {
-    rc = stack_axpy_device(ctx, n, k, ns, dS, slab, lds, ctx->coef, dT, ldt, -1.0);
+    // more than 32 slabs: subtract the tail slabs' part first, then the fused pass over the first 32 (T is final
+    // there, so it measures h2 of those slabs), then one dot for the tail slabs: the tail is read twice, the
+    // first 32 slabs once
+    const int nb = ns - 32;
+    const size_t na_k = static_cast<size_t>(32) * k;
+    rc = stack_axpy_device(ctx, n, k, nb, dS + 32 * slab, slab, lds, ctx->coef + na_k, dT, ldt, -1.0);
     if (rc) return rc;
-    rc = stack_dot_device(ctx, n, k, ns, dS, slab, lds, dT, ldt, &res);
+    rc = stack_axpy_dot_device(ctx, n, k, 32, dS, slab, lds, ctx->coef, dT, ldt, -1.0, &res);
     if (rc) return rc;
+    EIGD_HIP(hipMemcpyAsync(ctx->coef + nh, res, sizeof(double) * na_k, hipMemcpyDeviceToDevice, ctx->stream));
+    rc = stack_dot_device(ctx, n, k, nb, dS + 32 * slab, slab, lds, dT, ldt, &res);
+    if (rc) return rc;
+    EIGD_HIP(hipMemcpyAsync(ctx->coef + nh + na_k, res, sizeof(double) * nb * k, hipMemcpyDeviceToDevice, ctx->stream));
+    res = ctx->coef + nh;  // h2 assembled in place
     passes = 3;
   }
   if (ctx->pinned_h_bytes < sizeof(double) * 2 * nh) {
@@ -810,7 +820,8 @@ int eigd_stack_cgs2(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
   double* h2 = ctx->pinned_h + nh;
   EIGD_HIP(hipMemcpyAsync(h1, ctx->coef, sizeof(double) * nh, hipMemcpyDeviceToHost, ctx->stream));
   EIGD_HIP(hipMemcpyAsync(h2, res, sizeof(double) * nh, hipMemcpyDeviceToHost, ctx->stream));
-  EIGD_HIP(hipMemcpyAsync(ctx->coef + nh, res, sizeof(double) * nh, hipMemcpyDeviceToDevice, ctx->stream));
+  if (res != ctx->coef + nh)
+    EIGD_HIP(hipMemcpyAsync(ctx->coef + nh, res, sizeof(double) * nh, hipMemcpyDeviceToDevice, ctx->stream));
   EIGD_HIP(hipStreamSynchronize(ctx->stream));
   // what one-pass Gram-Schmidt left along S, column by column: subtract it only where it matters
   bool again = false;
