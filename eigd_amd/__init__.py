@@ -4,7 +4,7 @@ hot path.  Drop-in names (reference eigd/__init__.py:1-3 star-exports its module
 
     SpLuOperator, IRAM, BasicLanczos,
     add_eig_total_derivative, eval_adjoint_residual_norm, are_eigenvalues_repeated,
-    generate_adjoint_correction, laa, dl, pcpg, pgmres, sibk
+    generate_adjoint_correction, laa, dl, pcpg, pgmres, sibk, eigsh_mod
 
 All arithmetic on n-vectors runs in hand-written HIP kernels (libeigd_hip.so, C ABI in
 include/eigd_hip.h).  There is no CPU fallback: without the library or a GPU the calls raise.
@@ -22,5 +22,5 @@ from .adjoint import (  # noqa: F401
     pgmres,
     sibk,
 )
-from .lanczos import IRAM, BasicLanczos  # noqa: F401
+from .lanczos import IRAM, BasicLanczos, eigsh_mod  # noqa: F401
 from .operators import SpLuOperator  # noqa: F401

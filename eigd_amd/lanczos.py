@@ -507,3 +507,30 @@ class IRAM(_AdjointAPI):
         self._nV = m
         self._V_host = None
         return self.lam, self.Phi
+
+
+def eigsh_mod(A, k=6, M=None, sigma=None, which="LM", v0=None, ncv=None, maxiter=None, tol=0, return_eigenvectors=True,
+              Minv=None, OPinv=None, mode="normal"):
+    """
+    The reference's extended ``eigsh`` (eigd/arpack.py:104-442, star-exported through eigd/__init__.py:3), for the one
+    way eigd calls it (eigenvector_derivatives.py:1944-1954): shift-invert with the factor as ``OPinv``, ``which="LM"``,
+    ``mode`` "normal" (``A x = lambda M x``) or "buckling".  Returns what the reference returns there:
+    ``d (k,), z (n, k), Tm (ncv, ncv), v (n, ncv)`` -- eigenvalues, eigenvectors, the projected matrix and the
+    M-orthonormal Lanczos basis with ``OP v = v Tm + f e_m^T`` (restarted Lanczos on the device, see ``IRAM``).
+    Other argument combinations belong to scipy's ``eigsh`` and are not part of this path.
+    """
+    if sigma is None or OPinv is None or M is None:
+        raise ValueError("eigsh_mod: only the shift-invert path of eigd is implemented (sigma, M and OPinv are required)")
+    if which != "LM" or Minv is not None:
+        raise ValueError("eigsh_mod: only which='LM' without Minv is implemented")
+    if mode not in ("normal", "buckling"):
+        raise ValueError(f"Unknown mode {mode!r}")
+    if v0 is not None:
+        warnings.warn("eigsh_mod: v0 is ignored (fixed start vector, as the IRAM class)")
+    solver = IRAM(N=k, m=ncv, tol=tol, mode=mode, maxiter=maxiter)
+    if ncv is not None:
+        solver.m = int(ncv)   # the function does not apply the class's max(20, 2N+1, m) rule (ref 1895-1898)
+    d, z = solver.solve(A, M, OPinv, sigma)
+    if not return_eigenvectors:
+        return d
+    return d, z, solver.T, solver.V

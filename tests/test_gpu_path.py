@@ -690,3 +690,25 @@ def test_interior_shift_finds_eigenvalues_on_both_sides():
     R = K @ Phi - (M @ Phi) * lam
     assert np.linalg.norm(R, axis=0).max() < 1e-8
     assert np.all(np.isin(np.round(lam, 8), np.round(lam_ref, 8)))
+
+
+def test_eigsh_mod_function_returns_the_lanczos_relation():
+    """the reference's eigsh_mod (arpack.py:104) as eigd calls it: d, z, Tm, v with OP v = v Tm + f e_m^T"""
+    import eigd_amd as eg
+
+    g = load_golden("g4_laplace900_basiclanczos")
+    K, M = csr_from(g, "K"), csr_from(g, "M")
+    sigma = -0.1
+    fac = eg.SpLuOperator((K - sigma * M).tocsc())
+    d, z, Tm, v = eg.eigsh_mod(K, k=6, M=M, sigma=sigma, which="LM", OPinv=fac, ncv=40, mode="normal")
+    assert d.shape == (6,) and z.shape == (K.shape[0], 6) and Tm.shape == (40, 40) and v.shape == (K.shape[0], 40)
+    assert np.allclose(d, g["normal_lam"][:6], rtol=1e-9)
+    R = K @ z - (M @ z) * d
+    assert np.linalg.norm(R, axis=0).max() < 1e-8
+    assert np.abs(v.T @ (M @ v) - np.eye(40)).max() < 1e-10            # M-orthonormal basis
+    OPv = np.column_stack([fac(M @ v[:, j]) for j in range(40)])
+    E = OPv - v @ Tm
+    assert np.abs(E[:, :-1]).max() < 1e-9 * np.abs(Tm).max()           # only the last column carries the residual f
+    assert eg.eigsh_mod(K, k=6, M=M, sigma=sigma, OPinv=fac, ncv=40, return_eigenvectors=False).shape == (6,)
+    with pytest.raises(ValueError):
+        eg.eigsh_mod(K, k=6, M=M)                                       # not the shift-invert path
