@@ -340,3 +340,27 @@ def test_split_chain_hand_off_is_reproducible_over_many_sweeps(ctx):
         X = ctx.empty(A.shape[0], k)
         F.solve_to(B, X)
         assert np.array_equal(X.get(), x0), (it, k)
+
+
+def test_tiny_and_disconnected_matrices(ctx):
+    """n = 1, 2, 5 and a block-diagonal matrix with isolated dofs: forests of tiny fronts, roots without borders"""
+    from eigd_amd.device import CSRMatrix, Factor
+
+    rng = np.random.default_rng(7)
+    cases = [sparse.csr_matrix(np.array([[2.5]])),
+             sparse.csr_matrix(np.array([[2.0, -1.0], [-1.0, 2.0]])),
+             sparse.csr_matrix(np.diag([1.0, 2.0, 3.0, 4.0, 5.0]) + 0.1 * np.ones((5, 5))),
+             sparse.block_diag([grid_matrix(6, 5, 2, seed=1), grid_matrix(4, 4, 1, seed=2), sparse.identity(3) * 2.0,
+                                grid_matrix(9, 3, 1, seed=3)]).tocsr()]
+    for A in cases:
+        A.sort_indices()
+        n = A.shape[0]
+        F = Factor(ctx, A, leaf_size=8, panel_width=8)
+        for k in (1, 3, 9, 33):
+            B = rng.normal(size=(n, k))
+            X = F.solve_inplace(ctx.from_host(B)).get()
+            assert np.linalg.norm(A @ X - B) <= 1e-12 * np.linalg.norm(B), (n, k)
+        x = rng.normal(size=n)
+        assert np.array_equal(CSRMatrix(ctx, A).apply(ctx.from_host(x)).get()[:, 0], A @ x)
+        Xm = rng.normal(size=(n, 5))
+        assert np.array_equal(CSRMatrix(ctx, A).apply(ctx.from_host(Xm)).get(), A @ Xm)
