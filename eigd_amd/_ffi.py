@@ -76,6 +76,14 @@ _SIGNATURES = {
     "eigd_stack_axpy": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_dbl],
     "eigd_stack_axpy_dot": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_dbl, c_vp],
     "eigd_stack_cgs2": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_int, c_dbl, c_vp, c_vp],
+    "eigd_csr_update_values_dev": [c_vp, c_vp],
+    "eigd_factor_refactor_dev": [c_vp, c_vp],
+    "eigd_assembler_create": [c_vp, c_int, c_int, c_int, c_vp, c_vp],
+    "eigd_assembler_free": [c_vp],
+    "eigd_assembler_nnz": [c_vp, c_vp],
+    "eigd_assembler_pattern": [c_vp, c_vp, c_vp],
+    "eigd_assemble": [c_vp, c_vp, c_int, c_vp, c_vp],
+    "eigd_elem_linear_matrices": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp],
     "eigd_colnorm2_dev": [c_vp, c_int, c_int, c_vp, c_int, c_vp],
     "eigd_colnorm2_fetch": [c_vp, c_vp, c_int],
     "eigd_scale_inv_norm": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp],

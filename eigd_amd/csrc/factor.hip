@@ -1243,10 +1243,11 @@ int upload(eigd_factor* f, T** dptr, const std::vector<T>& h) {
   return EIGD_OK;
 }
 
-int numeric(eigd_factor* f, const double* hdata) {
+int numeric(eigd_factor* f, const double* data, bool on_device = false) {
   const Symbolic& s = *f->sym;
   hipStream_t st = f->ctx->stream;
-  EIGD_HIP(hipMemcpyAsync(f->d_data, hdata, sizeof(double) * f->data_len, hipMemcpyHostToDevice, st));
+  EIGD_HIP(hipMemcpyAsync(f->d_data, data, sizeof(double) * f->data_len,
+                          on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   EIGD_HIP(hipMemsetAsync(f->d_F, 0, sizeof(double) * s.front_doubles, st));
   EIGD_HIP(hipMemsetAsync(f->d_flag, 0, 2 * sizeof(int), st));
   {
@@ -1827,6 +1828,11 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
 int eigd_factor_refactor(eigd_factor* f, const double* hdata) {
   EIGD_REQUIRE(f && hdata, "null argument");
   return numeric(f, hdata);
+}
+
+int eigd_factor_refactor_dev(eigd_factor* f, const double* dvals) {
+  EIGD_REQUIRE(f && dvals, "null argument");
+  return numeric(f, dvals, true);
 }
 
 int eigd_factor_solve(eigd_factor* f, double* dX, int ldx, int k, double alpha) {

@@ -9,6 +9,10 @@
 //
 // KP lanes share one element (one lane per mode column): row gathers are k*8-byte contiguous
 // segments, the per-element sum is a fixed shuffle tree (deterministic).
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
 #include "common.h"
 
 namespace eigd {
@@ -53,9 +57,169 @@ __global__ __launch_bounds__(kThreads) void elem_bilinear_kernel(int nelem, int 
   if (c == 0 && el < nelem) out[el] += alpha * (scale ? scale[el] : 1.0) * s;
 }
 
+// Assembly of element matrices into CSR values, gather form: the entry of every stored (row, column) pair sums its
+// contributions in a fixed order (ascending element, then position in the element matrix) -- no atomics, the same
+// bits on every run.  vals[z] = sum_s scale[e_s] * Me[(per_elem ? e_s : 0)][ab_s], src = e * nd^2 + ab.
+__global__ __launch_bounds__(kThreads) void assemble_gather_kernel(int64_t nnz, const int32_t* __restrict__ nz_ptr,
+                                                                  const int32_t* __restrict__ nz_src, int nd2,
+                                                                  const double* __restrict__ Me, int per_elem,
+                                                                  const double* __restrict__ scale,
+                                                                  double* __restrict__ vals) {
+  for (int64_t z = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; z < nnz;
+       z += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    double sum = 0.0;
+    for (int q = nz_ptr[z]; q < nz_ptr[z + 1]; ++q) {
+      const int src = nz_src[q];
+      const int e = src / nd2, ab = src - e * nd2;
+      const double m = Me[(per_elem ? static_cast<int64_t>(e) * nd2 : 0) + ab];
+      sum += (scale ? scale[e] : 1.0) * m;
+    }
+    vals[z] = sum;
+  }
+}
+
+// Element matrices that depend linearly on the element's own dof values (geometric / stress stiffness of a
+// linear pre-buckling state, examples/buckling.py:220-255): Me[e] = sum_m (L[m] . u_e) * Q[m], u_e gathered from the
+// FULL dof vector through edofs (no constraints here: prescribed dofs carry their values).  One thread per entry.
+__global__ __launch_bounds__(kThreads) void elem_linear_matrices_kernel(int nelem, int nd, const int32_t* __restrict__ edofs,
+                                                                       const double* __restrict__ u, int nterms,
+                                                                       const double* __restrict__ L,
+                                                                       const double* __restrict__ Q,
+                                                                       double* __restrict__ out) {
+  const int nd2 = nd * nd;
+  const int64_t total = static_cast<int64_t>(nelem) * nd2;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+       idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int e = static_cast<int>(idx / nd2), ab = static_cast<int>(idx - static_cast<int64_t>(e) * nd2);
+    double ue[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) ue[a] = (a < nd) ? u[edofs[static_cast<int64_t>(e) * nd + a]] : 0.0;
+    double sum = 0.0;
+    for (int m = 0; m < nterms; ++m) {
+      double c = 0.0;
+      for (int a = 0; a < nd; ++a) c += L[m * nd + a] * ue[a];
+      sum += c * Q[m * nd2 + ab];
+    }
+    out[idx] = sum;
+  }
+}
+
 }  // namespace eigd
 
 using namespace eigd;
+
+extern "C" int eigd_elem_linear_matrices(eigd_ctx* ctx, int nelem, int nd, const int32_t* d_edofs, const double* du,
+                                         int nterms, const double* dL, const double* dQ, double* dOut) {
+  EIGD_REQUIRE(ctx && d_edofs && du && dL && dQ && dOut, "null argument");
+  EIGD_REQUIRE(nelem > 0 && nd >= 1 && nd <= 8 && nterms >= 1, "bad shape nelem=%d nd=%d nterms=%d", nelem, nd, nterms);
+  const int64_t total = static_cast<int64_t>(nelem) * nd * nd;
+  const int nb = static_cast<int>(std::min<int64_t>((total + kThreads - 1) / kThreads, 65536));
+  hipLaunchKernelGGL(elem_linear_matrices_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, nelem, nd, d_edofs, du, nterms,
+                     dL, dQ, dOut);
+  EIGD_LAUNCH_CHECK();
+  return EIGD_OK;
+}
+
+struct eigd_assembler {
+  eigd_ctx* ctx = nullptr;
+  int n = 0, nelem = 0, nd = 0;
+  int64_t nnz = 0;
+  std::vector<int32_t> indptr, indices;  // host copy of the pattern (rows sorted)
+  int32_t *d_nz_ptr = nullptr, *d_nz_src = nullptr;
+};
+
+extern "C" int eigd_assembler_free(eigd_assembler* a) {
+  if (!a) return EIGD_OK;
+  if (a->ctx && a->ctx->stream) (void)hipStreamSynchronize(a->ctx->stream);
+  if (a->d_nz_ptr) (void)hipFree(a->d_nz_ptr);
+  if (a->d_nz_src) (void)hipFree(a->d_nz_src);
+  delete a;
+  return EIGD_OK;
+}
+
+extern "C" int eigd_assembler_create(eigd_ctx* ctx, int n, int nelem, int nd, const int32_t* elem_dofs,
+                                     eigd_assembler** out) {
+  EIGD_REQUIRE(ctx && elem_dofs && out, "null argument");
+  EIGD_REQUIRE(n > 0 && nelem > 0 && nd >= 1 && nd <= 8, "bad shape n=%d nelem=%d nd=%d", n, nelem, nd);
+  *out = nullptr;
+  const int nd2 = nd * nd;
+  EIGD_REQUIRE(static_cast<int64_t>(nelem) * nd2 < (int64_t(1) << 31), "too many element entries");
+  // (row, col, source) triples of the unconstrained element entries, sorted by (row, col, source)
+  struct Trip { int32_t r, c, src; };
+  std::vector<Trip> tr;
+  tr.reserve(static_cast<size_t>(nelem) * nd2);
+  for (int e = 0; e < nelem; ++e)
+    for (int a = 0; a < nd; ++a) {
+      const int32_t r = elem_dofs[static_cast<int64_t>(e) * nd + a];
+      if (r < 0) continue;
+      EIGD_REQUIRE(r < n, "element %d: dof %d out of range", e, r);
+      for (int b = 0; b < nd; ++b) {
+        const int32_t c = elem_dofs[static_cast<int64_t>(e) * nd + b];
+        if (c < 0) continue;
+        tr.push_back(Trip{r, c, static_cast<int32_t>(e * nd2 + a * nd + b)});
+      }
+    }
+  std::sort(tr.begin(), tr.end(), [](const Trip& x, const Trip& y) {
+    if (x.r != y.r) return x.r < y.r;
+    if (x.c != y.c) return x.c < y.c;
+    return x.src < y.src;
+  });
+  eigd_assembler* a = new eigd_assembler();
+  a->ctx = ctx;
+  a->n = n;
+  a->nelem = nelem;
+  a->nd = nd;
+  a->indptr.assign(static_cast<size_t>(n) + 1, 0);
+  std::vector<int32_t> nz_ptr, nz_src(tr.size());
+  nz_ptr.reserve(tr.size() / 2 + 2);
+  for (size_t q = 0; q < tr.size(); ++q) {
+    if (q == 0 || tr[q].r != tr[q - 1].r || tr[q].c != tr[q - 1].c) {
+      nz_ptr.push_back(static_cast<int32_t>(q));
+      a->indices.push_back(tr[q].c);
+      a->indptr[tr[q].r + 1] += 1;
+    }
+    nz_src[q] = tr[q].src;
+  }
+  nz_ptr.push_back(static_cast<int32_t>(tr.size()));
+  for (int i = 0; i < n; ++i) a->indptr[i + 1] += a->indptr[i];
+  a->nnz = static_cast<int64_t>(a->indices.size());
+  EIGD_HIP(hipSetDevice(ctx->device));
+  hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&a->d_nz_ptr), sizeof(int32_t) * nz_ptr.size());
+  hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&a->d_nz_src), sizeof(int32_t) * std::max<size_t>(nz_src.size(), 1));
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    eigd_assembler_free(a);
+    set_error("hipMalloc failed for the assembly lists");
+    return EIGD_E_HIP;
+  }
+  EIGD_HIP(hipMemcpy(a->d_nz_ptr, nz_ptr.data(), sizeof(int32_t) * nz_ptr.size(), hipMemcpyHostToDevice));
+  if (!nz_src.empty())
+    EIGD_HIP(hipMemcpy(a->d_nz_src, nz_src.data(), sizeof(int32_t) * nz_src.size(), hipMemcpyHostToDevice));
+  *out = a;
+  return EIGD_OK;
+}
+
+extern "C" int eigd_assembler_nnz(eigd_assembler* a, int64_t* nnz) {
+  EIGD_REQUIRE(a && nnz, "null argument");
+  *nnz = a->nnz;
+  return EIGD_OK;
+}
+
+extern "C" int eigd_assembler_pattern(eigd_assembler* a, int32_t* hindptr, int32_t* hindices) {
+  EIGD_REQUIRE(a && hindptr && hindices, "null argument");
+  std::copy(a->indptr.begin(), a->indptr.end(), hindptr);
+  std::copy(a->indices.begin(), a->indices.end(), hindices);
+  return EIGD_OK;
+}
+
+extern "C" int eigd_assemble(eigd_assembler* a, const double* dMe, int per_elem, const double* dscale, double* dvals) {
+  EIGD_REQUIRE(a && dMe && dvals, "null argument");
+  if (a->nnz == 0) return EIGD_OK;
+  const int nb = static_cast<int>(std::min<int64_t>((a->nnz + kThreads - 1) / kThreads, 65536));
+  hipLaunchKernelGGL(assemble_gather_kernel, dim3(nb), dim3(kThreads), 0, a->ctx->stream, a->nnz, a->d_nz_ptr, a->d_nz_src,
+                     a->nd * a->nd, dMe, per_elem, dscale, dvals);
+  EIGD_LAUNCH_CHECK();
+  return EIGD_OK;
+}
 
 extern "C" int eigd_elem_bilinear(eigd_ctx* ctx, int nelem, int nd, const int32_t* d_edofs, const double* dMe,
                                   int per_elem, const double* dscale, const double* dW, int ldw, const double* dV,

@@ -322,6 +322,13 @@ int eigd_csr_update_values(eigd_mat* A, const double* hdata) {
   return EIGD_OK;
 }
 
+int eigd_csr_update_values_dev(eigd_mat* A, const double* dvals) {
+  EIGD_REQUIRE(A && dvals, "null argument");
+  if (A->nnz > 0)
+    EIGD_HIP(hipMemcpyAsync(A->data, dvals, sizeof(double) * A->nnz, hipMemcpyDeviceToDevice, A->ctx->stream));
+  return EIGD_OK;
+}
+
 int eigd_mat_free(eigd_mat* A) {
   if (!A) return EIGD_OK;
   if (A->ctx && A->ctx->stream) (void)hipStreamSynchronize(A->ctx->stream);

@@ -467,6 +467,12 @@ class CSRMatrix:
         call("eigd_spmm_on", X.ctx.h, self.h, X.ptr, X.ld, Y.ptr, Y.ld, X.k, float(alpha), float(beta))  # on X's stream
         return Y
 
+    def update_values_device(self, vals):
+        """new values (device block of nnz doubles, in this matrix's CSR order), same sparsity"""
+        if vals.n * vals.k != self.nnz:
+            raise ValueError("value count does not match the matrix")
+        call("eigd_csr_update_values_dev", self.h, vals.ptr)
+
     def spmv_bytes(self, k=1):
         """algorithmic bytes of one product"""
         if k == 1:
@@ -569,6 +575,10 @@ class Factor:
         data = np.ascontiguousarray(A.data, dtype=np.float64)
         call("eigd_factor_refactor", self.h, hptr(data))
 
+    def refactor_device(self, vals):
+        """numeric refactorisation from CSR values that already live on the device (ElementAssembler.assemble)"""
+        call("eigd_factor_refactor_dev", self.h, vals.ptr)
+
     def solve_inplace(self, X, alpha=1.0):
         if X.n != self.n:
             raise ValueError("shape mismatch in factor solve")
@@ -655,3 +665,117 @@ class ElementBilinear:
         out = self.ctx.zeros(self.nelem, 1)
         self.accumulate(W, V, out)
         return out.get()[:, 0]
+
+
+class ElementAssembler:
+    """
+    Device-side assembly of element matrices into CSR values (the COO -> CSR loops of the reference's
+    harnesses, examples/buckling.py:152-176, 220-255).  The dof lists are analysed once; ``pattern()`` gives the scipy
+    CSR pattern, ``assemble(Me, scale)`` the values on the device, in that pattern's order and with a fixed summation
+    order (bitwise reproducible).  ``values_into(A, ...)`` / ``refactor(factor, ...)`` feed a CSRMatrix / Factor built on
+    the same pattern without a host round trip.
+    """
+
+    def __init__(self, ctx, elem_dofs, n):
+        elem_dofs = np.ascontiguousarray(elem_dofs, dtype=np.int32)
+        self.ctx = ctx
+        self.n = int(n)
+        self.nelem, self.nd = elem_dofs.shape
+        h = c_vp()
+        call("eigd_assembler_create", ctx.h, self.n, self.nelem, self.nd, hptr(elem_dofs), C.byref(h))
+        self.h = h
+        nnz = C.c_int64()
+        call("eigd_assembler_nnz", self.h, C.byref(nnz))
+        self.nnz = int(nnz.value)
+        self._cache = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) is not None and self.ctx.h is not None:
+                _ffi.lib().eigd_assembler_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def pattern(self):
+        """scipy CSR matrix with the assembled sparsity (values zero)"""
+        from scipy import sparse
+
+        ip = np.empty(self.n + 1, dtype=np.int32)
+        ix = np.empty(max(self.nnz, 1), dtype=np.int32)
+        call("eigd_assembler_pattern", self.h, hptr(ip), hptr(ix))
+        return sparse.csr_matrix((np.zeros(self.nnz), ix[: self.nnz], ip), shape=(self.n, self.n))
+
+    def _upload(self, key, arr):
+        """element matrices / scale factors are uploaded once per distinct host array"""
+        ent = self._cache.get(key)
+        if ent is None or ent[0] is not arr:
+            a = np.ascontiguousarray(arr, dtype=np.float64)
+            buf = _Buffer(self.ctx, max(a.nbytes, 8))
+            call("eigd_h2d", self.ctx.h, c_vp(buf.ptr), hptr(a), a.nbytes)
+            ent = (arr, buf)
+            self._cache[key] = ent
+        return ent[1]
+
+    def assemble(self, Me, scale=None, out=None):
+        """
+        CSR values (device block nnz x 1) of sum_e scale[e] P_e^T Me P_e; Me: (nd, nd) shared or (nelem, nd, nd) numpy
+        array, or a device block of nelem * nd * nd doubles (per-element matrices made on the device)
+        """
+        if isinstance(Me, DeviceBlock):
+            if Me.n * Me.k != self.nelem * self.nd * self.nd:
+                raise ValueError("element matrix block does not match the dof list")
+            sp = scale.ptr if isinstance(scale, DeviceBlock) else (
+                c_vp(None) if scale is None else c_vp(self._upload("scale", scale).ptr))
+            vals = out if out is not None else self.ctx.empty(max(self.nnz, 1), 1)
+            call("eigd_assemble", self.h, Me.ptr, 1, sp, vals.ptr)
+            return vals
+        Me = np.asarray(Me, dtype=np.float64)
+        per_elem = 1 if Me.ndim == 3 else 0
+        if Me.shape[-2:] != (self.nd, self.nd) or (per_elem and Me.shape[0] != self.nelem):
+            raise ValueError("element matrix shape does not match the dof list")
+        if isinstance(scale, DeviceBlock):
+            sp = scale.ptr
+        elif scale is None:
+            sp = c_vp(None)
+        else:
+            if np.shape(scale) != (self.nelem,):
+                raise ValueError("one scale factor per element expected")
+            sp = c_vp(self._upload("scale", scale).ptr)
+        vals = out if out is not None else self.ctx.empty(max(self.nnz, 1), 1)
+        call("eigd_assemble", self.h, c_vp(self._upload("Me", Me).ptr), per_elem, sp, vals.ptr)
+        return vals
+
+    def values_to_host(self, vals):
+        return vals.get()[: self.nnz, 0]
+
+
+class ElementLinearMatrices:
+    """
+    Element matrices that are linear in the element's dof values, ``Me[e] = sum_m (L[m] . u_e) Q[m]`` (device):
+    the stress stiffness of a linear pre-buckling state (examples/buckling.py:220-255).  ``full_dofs``: nelem x nd
+    indices into the FULL dof vector; ``L``: (nterms, nd); ``Q``: (nterms, nd, nd).
+    """
+
+    def __init__(self, ctx, full_dofs, L, Q):
+        full_dofs = np.ascontiguousarray(full_dofs, dtype=np.int32)
+        L = np.ascontiguousarray(L, dtype=np.float64)
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        self.ctx = ctx
+        self.nelem, self.nd = full_dofs.shape
+        self.nterms = L.shape[0]
+        if L.shape != (self.nterms, self.nd) or Q.shape != (self.nterms, self.nd, self.nd):
+            raise ValueError("L / Q shapes do not match the dof list")
+        self._dofs = _Buffer(ctx, full_dofs.nbytes)
+        call("eigd_h2d", ctx.h, c_vp(self._dofs.ptr), hptr(full_dofs), full_dofs.nbytes)
+        self._L = _Buffer(ctx, L.nbytes)
+        call("eigd_h2d", ctx.h, c_vp(self._L.ptr), hptr(L), L.nbytes)
+        self._Q = _Buffer(ctx, Q.nbytes)
+        call("eigd_h2d", ctx.h, c_vp(self._Q.ptr), hptr(Q), Q.nbytes)
+
+    def __call__(self, u_full):
+        """u_full: device block (nfull x 1) -> device block of nelem * nd * nd element-matrix entries"""
+        out = self.ctx.empty(self.nelem * self.nd * self.nd, 1)
+        call("eigd_elem_linear_matrices", self.ctx.h, self.nelem, self.nd, c_vp(self._dofs.ptr), u_full.ptr, self.nterms,
+             c_vp(self._L.ptr), c_vp(self._Q.ptr), out.ptr)
+        return out

@@ -85,6 +85,18 @@ class SpLuOperator(LinearOperator):
             self._refine(Xin, Xout, alpha)
         return Xout
 
+    def refactor_device(self, vals, indefinite_matrix=None):
+        """
+        numeric refactorisation from CSR values on the device (``ElementAssembler.assemble``; the pattern must be the
+        one this operator was built on).  The positive definite case needs nothing else; for an indefinite result pass
+        the device CSRMatrix holding the same values (``indefinite_matrix``) for the refinement step.
+        """
+        self.factor.refactor_device(vals)
+        self.negative_pivots = self.factor.stats()["negative_pivots"]
+        if self.negative_pivots > 0 and indefinite_matrix is None:
+            raise ValueError("indefinite refactorisation: pass the device matrix for the refinement step")
+        self._mat_dev = indefinite_matrix if self.negative_pivots > 0 else None
+
     def refactor(self, mat):
         """numeric refactorisation with new values on the same sparsity pattern"""
         csr = mat.tocsr().astype(np.float64)

@@ -162,6 +162,29 @@ class BucklingColumn:
         Ge[:, 1::2, 1::2] = G4
         return Ge
 
+    def stress_stiffness_tables(self):
+        """
+        (full_dofs, L, Q) with Ge_unit[e] = sum_m (L[m] . u_e) Q[m]: the Gauss-point form of element_G for the device
+        (eigd_amd.device.ElementLinearMatrices).  m runs over 4 Gauss points x 3 stress components.
+        """
+        mesh = self.mesh
+        full = np.empty((mesh.nelems, 8), dtype=np.int32)
+        full[:, ::2] = 2 * mesh.conn
+        full[:, 1::2] = 2 * mesh.conn + 1
+        L, Q = [], []
+        for eta in GAUSS:
+            for xi in GAUSS:
+                _, Nx, Ny, detJ = mesh.shape_derivs(xi, eta)
+                CB = self.C0 @ _Bmat(Nx, Ny)                      # stresses of the unit-stiffness material, 3 x 8
+                Te = [np.outer(Nx, Nx), np.outer(Ny, Ny), np.outer(Nx, Ny) + np.outer(Ny, Nx)]
+                for i in range(3):
+                    G8 = np.zeros((8, 8))
+                    G8[0::2, 0::2] = detJ * Te[i]
+                    G8[1::2, 1::2] = detJ * Te[i]
+                    L.append(CB[i])
+                    Q.append(G8)
+        return full, np.array(L), np.array(Q)
+
     def geometric_stiffness(self, u_full):
         self.Ge_unit = self.element_G(u_full)
         scale = self.rhoE**self.p + self.rho0_G

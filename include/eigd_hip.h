@@ -74,6 +74,8 @@ int eigd_timer_stop_ms(eigd_ctx* ctx, double* ms);
 int eigd_csr_upload(eigd_ctx* ctx, int n, int64_t nnz, const int32_t* hindptr, const int32_t* hindices,
                     const double* hdata, eigd_mat** out);
 int eigd_csr_update_values(eigd_mat* A, const double* hdata);
+/* the same with the values already on the device (e.g. from eigd_assemble) */
+int eigd_csr_update_values_dev(eigd_mat* A, const double* dvals);
 int eigd_mat_free(eigd_mat* A);
 int eigd_spmm(eigd_mat* A, const double* dX, int ldx, double* dY, int ldy, int k, double alpha, double beta);
 /* same product enqueued on another context of the same device */
@@ -105,6 +107,8 @@ int eigd_symbolic_get_i64(eigd_symbolic* s, const char* name, int64_t* out, int6
 int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* s, const double* hdata /* CSR values, full matrix */,
                        eigd_factor** out);
 int eigd_factor_refactor(eigd_factor* f, const double* hdata);
+/* the same with the CSR values already on the device (e.g. from eigd_assemble): no host round trip */
+int eigd_factor_refactor_dev(eigd_factor* f, const double* dvals);
 int eigd_factor_free(eigd_factor* f);
 /* X (n x k row-major, ld) <- alpha * M^{-1} X ; any k >= 1 (processed in column blocks of <= 32) */
 int eigd_factor_solve(eigd_factor* f, double* dX, int ldx, int k, double alpha);
@@ -186,6 +190,27 @@ int eigd_scatter_cols(eigd_ctx* ctx, int n, int ksrc, const double* dSrc, int ld
 int eigd_elem_bilinear(eigd_ctx* ctx, int nelem, int nd, const int32_t* d_edofs, const double* dMe, int per_elem,
                        const double* dscale, const double* dW, int ldw, const double* dV, int ldv, int k, double alpha,
                        double* dOut);
+
+/* ---- element assembly on the device ------------------------------------
+ * The COO -> CSR assembly loops of the harnesses (examples/buckling.py:152-176, 220-255;
+ * natural_frequency.py:134-160, 205-236; thermal.py:126-148, 192-214): K = sum_e scale[e] * P_e^T Me P_e.
+ * eigd_assembler_create analyses the dof lists once (host): CSR pattern of the assembled matrix (rows sorted) and,
+ * per stored entry, the list of element entries that add into it.  eigd_assemble then forms the CSR VALUES on the
+ * device in that fixed order (no atomics; bitwise reproducible); they feed eigd_csr_update_values_dev and
+ * eigd_factor_refactor_dev without visiting the host.  elem_dofs: nelem x nd (host), -1 = constrained dof. */
+typedef struct eigd_assembler eigd_assembler;
+int eigd_assembler_create(eigd_ctx* ctx, int n, int nelem, int nd, const int32_t* elem_dofs, eigd_assembler** out);
+int eigd_assembler_free(eigd_assembler* a);
+int eigd_assembler_nnz(eigd_assembler* a, int64_t* nnz);
+int eigd_assembler_pattern(eigd_assembler* a, int32_t* hindptr /* n + 1 */, int32_t* hindices /* nnz */);
+/* dMe: nelem x nd x nd (per_elem != 0) or one shared nd x nd matrix; dscale: nelem or NULL; dvals: nnz (device) */
+int eigd_assemble(eigd_assembler* a, const double* dMe, int per_elem, const double* dscale, double* dvals);
+/* element matrices linear in the element's dof values, Me[e] = sum_m (L[m] . u_e) Q[m]: the stress (geometric)
+ * stiffness of the linear pre-buckling state (examples/buckling.py:220-255) with L = C0 B at the Gauss points and
+ * Q = detJ * (dN dN^T terms).  d_edofs: nelem x nd dofs of the FULL vector du; dL: nterms x nd; dQ: nterms x nd x nd;
+ * dOut: nelem x nd x nd (feeds eigd_assemble with per_elem = 1). */
+int eigd_elem_linear_matrices(eigd_ctx* ctx, int nelem, int nd, const int32_t* d_edofs, const double* du, int nterms,
+                              const double* dL, const double* dQ, double* dOut);
 
 #ifdef __cplusplus
 }

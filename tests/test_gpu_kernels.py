@@ -364,3 +364,65 @@ def test_tiny_and_disconnected_matrices(ctx):
         assert np.array_equal(CSRMatrix(ctx, A).apply(ctx.from_host(x)).get()[:, 0], A @ x)
         Xm = rng.normal(size=(n, 5))
         assert np.array_equal(CSRMatrix(ctx, A).apply(ctx.from_host(Xm)).get(), A @ Xm)
+
+
+def test_device_assembly_matches_host_assembly_and_feeds_the_factor(ctx):
+    """element assembly on the device = scipy COO assembly; values go straight into SpMV and refactor"""
+    import eigd_amd as eg
+    from eigd_amd.device import CSRMatrix, ElementAssembler
+    from eigd_amd.problems import BucklingColumn
+
+    col = BucklingColumn(24, 31, seed=3)
+    K = col.stiffness()                                  # host assembly (vectorised scipy COO -> CSR)
+    asm = ElementAssembler(ctx, col.elem_dofs, col.n)
+    P = asm.pattern()
+    assert P.nnz == K.nnz and np.array_equal(P.indptr, K.indptr) and np.array_equal(P.indices, K.indices)
+    scale = col.rhoE**col.p + col.rho0_K
+    vals = asm.assemble(col.Ke0, scale)
+    v = asm.values_to_host(vals)
+    assert np.abs(v - K.data).max() <= 4e-16 * np.abs(K.data).max()      # same sums, possibly another order
+    assert np.array_equal(asm.values_to_host(asm.assemble(col.Ke0, scale)), v)   # reproducible
+    # per-element matrices
+    Ke = scale[:, None, None] * col.Ke0[None]
+    assert np.abs(asm.values_to_host(asm.assemble(Ke)) - K.data).max() <= 4e-16 * np.abs(K.data).max()
+    # new densities: assemble on the device, update the SpMV matrix and the factor without a host round trip
+    fac = eg.SpLuOperator(K.tocsc(), ctx=ctx)
+    dK = CSRMatrix(ctx, K)
+    rho2 = np.random.default_rng(1).uniform(0.4, 1.0, size=col.mesh.nelems)
+    scale2 = rho2**col.p + col.rho0_K
+    vals2 = asm.assemble(col.Ke0, scale2)
+    dK.update_values_device(vals2)
+    fac.refactor_device(vals2)
+    col2 = BucklingColumn(24, 31, rhoE=rho2)
+    K2 = col2.stiffness()
+    x = np.random.default_rng(2).normal(size=col.n)
+    y = dK.apply(ctx.from_host(x)).get()[:, 0]
+    assert np.linalg.norm(y - K2 @ x) <= 1e-14 * np.linalg.norm(K2 @ x)
+    b = np.random.default_rng(3).normal(size=(col.n, 3))
+    X = fac(b)
+    assert np.linalg.norm(K2 @ X - b) <= 1e-11 * np.linalg.norm(b)
+    with pytest.raises(ValueError):
+        asm.assemble(np.zeros((7, 7)))
+
+
+def test_stress_stiffness_on_the_device_matches_the_host_formula(ctx):
+    """geometric stiffness G(u): element matrices linear in u made on the device, assembled on the device"""
+    from scipy.sparse.linalg import splu as host_lu
+
+    from eigd_amd.device import ElementAssembler, ElementLinearMatrices
+    from eigd_amd.problems import BucklingColumn
+
+    col = BucklingColumn(17, 23, seed=5)
+    K = col.stiffness()
+    u = col.full_vector(host_lu(K.tocsc()).solve(col.f[col.reduced]))
+    G = col.geometric_stiffness(u)                      # host: element_G + COO assembly
+    full, L, Q = col.stress_stiffness_tables()
+    Ge_dev = ElementLinearMatrices(ctx, full, L, Q)(ctx.from_host(u))
+    Ge = Ge_dev.get()[:, 0].reshape(col.mesh.nelems, 8, 8)
+    assert np.abs(Ge - col.Ge_unit).max() <= 1e-13 * np.abs(col.Ge_unit).max()
+    asm = ElementAssembler(ctx, col.elem_dofs, col.n)
+    scale = col.rhoE**col.p + col.rho0_G
+    vals = asm.values_to_host(asm.assemble(Ge_dev, scale))
+    P = asm.pattern()
+    Gd = sparse.csr_matrix((vals, P.indices, P.indptr), shape=P.shape)
+    assert abs(Gd - G).max() <= 1e-13 * abs(G).max()
