@@ -62,7 +62,7 @@ struct FrontArrays {
 };
 
 constexpr int kPlaneCols = 4 + 8 + 16 + 32;  // one set of carry planes per sweep width
-constexpr int kMaxS = 3;  // children per front with a carry plane of their own; further children share an extra plane
+constexpr int kMaxS = 4;  // children per front with a carry plane of their own; further children share an extra plane
 
 __device__ __forceinline__ int find_slot(const int* __restrict__ pref, int na, int idx) {
   int lo = 0, hi = na;
@@ -519,6 +519,7 @@ struct WgRec {
   int64_t pvoff;         // the parent's first row in V, -1 for a root
   int64_t scratch;       // 1: surplus child (slot >= kMaxS): its carry goes to the scratch plane, at its own border rows
   int64_t ftoff;         // the front's block in the transposed copy Ft
+  int64_t ldt;           // leading dimension of T as the sweeps read it: d in the packed panel
 };
 
 struct LevelArgs {
@@ -655,7 +656,7 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
     const bool own = rt < nst;
     const int row0 = own ? rt * TW : ns + (rt - nst) * TW;
     const int rows = min(TW, (own ? ns : d) - row0);
-    const int64_t ld = own ? ns : d;
+    const int64_t ld = own ? w.ldt : d;
     const int wd = min(TW, ns - ct * TW);
     const double* Ap = (own ? Tf : Ff) + static_cast<int64_t>(ct) * TW * ld + row0 + ar;
 #pragma unroll
@@ -750,7 +751,7 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
       const bool own = rt < nst;
       const int row0 = own ? rt * TW : ns + (rt - nst) * TW;
       const int rows = min(TW, (own ? ns : d) - row0);
-      const int ld = own ? ns : d;
+      const int ld = own ? static_cast<int>(w.ldt) : d;
       const double* Ab = (own ? Tf : Ff) + row0;  // uniform base, 32-bit lane offsets (a tile spans < 2^31 doubles)
       const ptrdiff_t zoff = fa.zero - Ab;        // masked lanes read the zero word
 #pragma unroll
@@ -881,7 +882,7 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
   const int wc = min(TW, ns - c0t);
   const int nown = nst - ct;
   const int64_t vbase = w.voff;
-  const double* Tp = Tb + w.toff + static_cast<int64_t>(c0t) * ns;   // T(r, c0t + o) at o*ns + r
+  const double* Tp = Tb + w.toff + static_cast<int64_t>(c0t) * w.ldt;  // T(r, c0t + o) at o*ldt + r
   const double* Mp = F + w.foff + static_cast<int64_t>(c0t) * d;     // M21(r, c0t + o) at o*d + r
   const int* __restrict__ bout = fa.bout + w.bptr;
   const int ar = threadIdx.x & (TW - 1), ajb = threadIdx.x >> 6;
@@ -920,7 +921,7 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
       }
     }
     const double* Ap = (border ? Mp : Tp) + rbase + ar;
-    const int64_t ld = border ? d : ns;
+    const int64_t ld = border ? d : w.ldt;
 #pragma unroll
     for (int it = 0; it < TILE_IT; ++it) {
       const int j = ajb + it * (kThreads / TW);
@@ -1018,7 +1019,7 @@ __global__ __launch_bounds__(128) void fwd_wave_kernel(FrontArrays fa, const WgR
     const bool own = rt < 1;
     const int row0 = own ? 0 : ns + (rt - 1) * TW;
     const int rows = min(TW, (own ? ns : d) - row0);
-    const int ld = own ? ns : d;
+    const int ld = own ? static_cast<int>(w.ldt) : d;
     const double* Ab = (own ? Tb + w.toff : F + w.foff) + row0;
     const bool rok = lane < rows;
     // carries on the tile's rows and where the results go (border tiles)
@@ -1163,6 +1164,26 @@ __global__ __launch_bounds__(kThreads) void transpose_front_kernel(FrontArrays f
   }
 }
 
+// Pk(r, o) = [T; M21](r, o), column-major d x ns per front: the panel the sweeps stream, one contiguous block per
+// front, the fronts of a level next to each other in the order their workgroups are launched
+__global__ __launch_bounds__(kThreads) void pack_front_kernel(FrontArrays fa, const int* __restrict__ tr_pref,
+                                                             int nfronts, const int64_t* __restrict__ pkoff,
+                                                             const double* __restrict__ F,
+                                                             const double* __restrict__ Tb, double* __restrict__ Pk) {
+  const int f = find_slot(tr_pref, nfronts, blockIdx.x);
+  const int ns = fa.ns[f], d = ns + fa.bs[f];
+  const int nct = (ns + TW - 1) / TW;
+  const int local = blockIdx.x - tr_pref[f];
+  const int rt = local / nct, ct = local - rt * nct;
+  const int gr = rt * TW + (threadIdx.x & (TW - 1));
+  if (gr >= d) return;
+  const double* src = (gr < ns) ? Tb + fa.toff[f] + gr : F + fa.foff[f] + gr;
+  const int64_t lds = (gr < ns) ? ns : d;
+  double* dst = Pk + pkoff[f] + gr;
+  for (int go = ct * TW + (threadIdx.x >> 6); go < min(ns, (ct + 1) * TW); go += kThreads / TW)
+    dst[static_cast<int64_t>(go) * d] = src[static_cast<int64_t>(go) * lds];
+}
+
 }  // namespace eigd
 
 using namespace eigd;
@@ -1186,6 +1207,7 @@ struct eigd_factor {
   int64_t* d_toff = nullptr;
   double *d_T = nullptr, *d_aux = nullptr;  // aux: {0.0, (int) -1}
   std::vector<int> h_fwd_ptr, h_bwd_ptr;  // per level: first workgroup record
+  std::vector<char> h_lvl_two;            // per level: every front has at most two children (two-plane kernels)
   std::vector<int> h_fwd_nsingle;         // per level: leading records of single-column-tile fronts (own kernel)
   std::vector<int> h_bwd_nsingle;         // per level: leading backward records of single-column-tile fronts
   // narrow sweeps (k <= 8): one record per single-tile front and level, the transposed copy of [T; M21]
@@ -1194,6 +1216,8 @@ struct eigd_factor {
   int64_t* d_ftoff = nullptr;
   int* d_tr_pref = nullptr;
   double* d_Ft = nullptr;
+  int64_t* d_pkoff = nullptr;  // packed sweep panels (level-major), nullptr: the sweeps read F and T
+  double* d_Pk = nullptr;
   int64_t ft_doubles = 0;
   int n_tr = 0;
   std::vector<int> ov_lvl_ptr;       // per level: range of overflow rows (extra rows of V after the sumd front rows)
@@ -1299,6 +1323,11 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false) {
     hipLaunchKernelGGL(transpose_front_kernel, dim3(f->n_tr), dim3(kThreads), 0, st, fa, f->d_tr_pref, s.nfronts, f->d_ftoff,
                        f->d_F, f->d_T, f->d_Ft);
     EIGD_LAUNCH_CHECK();
+    if (f->d_Pk != nullptr) {
+      hipLaunchKernelGGL(pack_front_kernel, dim3(f->n_tr), dim3(kThreads), 0, st, fa, f->d_tr_pref, s.nfronts, f->d_pkoff,
+                         f->d_F, f->d_T, f->d_Pk);
+      EIGD_LAUNCH_CHECK();
+    }
   }
   int flag[2] = {0, 0};
   EIGD_HIP(hipMemcpyAsync(flag, f->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1338,6 +1367,8 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     la.kb = kb;
     return la;
   };
+  const double* sF = f->d_Pk ? f->d_Pk : f->d_F;  // the panels [T; M21]: packed copy, or in place (F and T)
+  const double* sT = f->d_Pk ? f->d_Pk : f->d_T;
   // ---- forward: leaves -> root.  Y receives S z, the border rows of V the carries.
   for (int l = 0; l < s.nlevels; ++l) {
     const int nov = f->ov_lvl_ptr[l + 1] - f->ov_lvl_ptr[l];
@@ -1349,17 +1380,17 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
       EIGD_LAUNCH_CHECK();
     }
     const int nwg = f->h_fwd_ptr[l + 1] - f->h_fwd_ptr[l], nsingle = f->h_fwd_nsingle[l];
-    const bool two = f->nslot <= 2;
+    const bool two = f->h_lvl_two[l] != 0;  // no front of this level has more than two children
     const int nwave = f->h_wave_ptr[l + 1] - f->h_wave_ptr[l];
     bool narrow = false;
     if (KPT <= wave_max_kpt) {
       if (nwave > 0) {  // narrow sweep: one wave per tile of the single-tile fronts
         if (two)
           hipLaunchKernelGGL((fwd_wave_kernel<KB, 2>), dim3(nwave), dim3(128), 0, st, fa, f->d_wave_wg + f->h_wave_ptr[l],
-                             f->d_F, f->d_T, dIn, ldin, alpha, wV, wY, kb);
+                             sF, sT, dIn, ldin, alpha, wV, wY, kb);
         else
           hipLaunchKernelGGL((fwd_wave_kernel<KB, kMaxS + 1>), dim3(nwave), dim3(128), 0, st, fa,
-                             f->d_wave_wg + f->h_wave_ptr[l], f->d_F, f->d_T, dIn, ldin, alpha, wV, wY, kb);
+                             f->d_wave_wg + f->h_wave_ptr[l], sF, sT, dIn, ldin, alpha, wV, wY, kb);
         EIGD_LAUNCH_CHECK();
         narrow = true;
       }
@@ -1367,19 +1398,19 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     if (!narrow && nsingle > 0) {
       if (two)
         hipLaunchKernelGGL((fwd_level_kernel<KPT, true, kDeepSingle<KPT>, 2>), dim3(nsingle), dim3(kThreads), 0, st, fa,
-                           level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
+                           level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), sF, sT, dIn, ldin, alpha, wV, wY);
       else
         hipLaunchKernelGGL((fwd_level_kernel<KPT, true, kDeepSingle<KPT>, kMaxS + 1>), dim3(nsingle), dim3(kThreads), 0,
-                           st, fa, level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
+                           st, fa, level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), sF, sT, dIn, ldin, alpha, wV, wY);
       EIGD_LAUNCH_CHECK();
     }
     if (nwg > nsingle) {
       if (two)
         hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, 2>), dim3(nwg - nsingle), dim3(kThreads), 0, st, fa,
-                           level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), f->d_F, f->d_T, dIn, ldin, alpha, wV, wY);
+                           level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), sF, sT, dIn, ldin, alpha, wV, wY);
       else
         hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, kMaxS + 1>), dim3(nwg - nsingle), dim3(kThreads), 0, st,
-                           fa, level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), f->d_F, f->d_T, dIn, ldin, alpha, wV,
+                           fa, level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), sF, sT, dIn, ldin, alpha, wV,
                            wY);
       EIGD_LAUNCH_CHECK();
     }
@@ -1394,7 +1425,7 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
         const int nsb = f->h_bwd_nsingle[l];
         if (nwg > nsb) {
           hipLaunchKernelGGL(bwd_level_kernel<KPT>, dim3(nwg - nsb), dim3(kThreads), 0, st, fa,
-                             level_args(f->d_bwd_wg + f->h_bwd_ptr[l] + nsb), f->d_F, f->d_T, wY, dX, ldx);
+                             level_args(f->d_bwd_wg + f->h_bwd_ptr[l] + nsb), sF, sT, wY, dX, ldx);
           EIGD_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(bwd_wave_kernel<KB>, dim3(nwave), dim3(64), 0, st, fa, f->d_wave_wg + f->h_wave_ptr[l],
@@ -1404,7 +1435,7 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
       }
     }
     hipLaunchKernelGGL(bwd_level_kernel<KPT>, dim3(nwg), dim3(kThreads), 0, st, fa,
-                       level_args(f->d_bwd_wg + f->h_bwd_ptr[l]), f->d_F, f->d_T, wY, dX, ldx);
+                       level_args(f->d_bwd_wg + f->h_bwd_ptr[l]), sF, sT, wY, dX, ldx);
     EIGD_LAUNCH_CHECK();
   }
   return EIGD_OK;
@@ -1511,7 +1542,8 @@ int eigd_factor_free(eigd_factor* f) {
                   f->d_F,         f->d_Inv,         f->d_V,          f->d_Y,        f->d_flag,  f->d_fwd_wg,
                   f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_ov_dst,   f->d_ov_ptr, f->d_ov_src,
                   f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux,      f->d_bout,  f->d_tickets,
-                  f->d_P,         f->d_wave_wg,     f->d_ftoff,      f->d_tr_pref,  f->d_Ft};
+                  f->d_P,         f->d_wave_wg,     f->d_ftoff,      f->d_tr_pref,  f->d_Ft,
+                  f->d_pkoff,     f->d_Pk};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;
@@ -1602,14 +1634,28 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   // chains longer than split_min tiles are cut into groups of about split_len tiles (at most split_maxg groups)
   const int split_min = env_int("EIGD_SPLIT_MIN", 4), split_len = std::max(1, env_int("EIGD_SPLIT_LEN", 4));
   const int split_maxg = std::max(1, env_int("EIGD_SPLIT_MAXG", 12)), split_nfl = env_int("EIGD_SPLIT_NFL", 128);
+  // packed sweep panels: level by level in launch order, every front one contiguous d x ns block
+  const bool packed = env_int("EIGD_PACKED", 0) != 0;
+  std::vector<int64_t> pkoff(static_cast<size_t>(nf) + 1, 0);
+  {
+    int64_t off = 0;
+    for (int l = 0; l < s.nlevels; ++l)
+      for (int q = s.lvl_ptr[l]; q < s.lvl_ptr[l + 1]; ++q) {
+        const int fr = s.lvl_fronts[q];
+        pkoff[fr] = off;
+        off += (static_cast<int64_t>(s.f_ns[fr]) + s.f_bs[fr]) * s.f_ns[fr];
+      }
+    pkoff[nf] = off;
+  }
   auto front_numbers = [&](WgRec& w, int fr) {
     w.f = fr;
     w.ns = s.f_ns[fr];
     w.bs = s.f_bs[fr];
     w.c0 = s.f_c0[fr];
     w.voff = s.f_voff[fr];
-    w.foff = s.f_foff[fr];
-    w.toff = toff[fr];
+    w.foff = packed ? pkoff[fr] : s.f_foff[fr];
+    w.toff = packed ? pkoff[fr] : toff[fr];
+    w.ldt = packed ? s.f_ns[fr] + s.f_bs[fr] : s.f_ns[fr];
     w.bptr = s.f_bptr[fr];
     w.ftoff = ftoff[fr];
     const int par = s.f_parent[fr];
@@ -1695,7 +1741,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   size_t free_b = 0, total_b = 0;
   EIGD_HIP(hipMemGetInfo(&free_b, &total_b));
   const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + toff[nf] +
-                                        ftoff[nf] + (2 * nplanes + 1) * v_rows * KBMAX + n_slabs * TW * KBMAX) +
+                                        (packed ? 2 : 1) * ftoff[nf] + (2 * nplanes + 1) * v_rows * KBMAX + n_slabs * TW * KBMAX) +
                       16 * s.a_src.size() + (size_t(64) << 20);
   if (need > free_b) {
     set_error("factor needs %.2f GiB of device memory, %.2f GiB free", need / 1073741824.0, free_b / 1073741824.0);
@@ -1706,6 +1752,9 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   f->sym = &h->s;
   f->h_fwd_ptr = h_fwd_ptr;
   f->h_fwd_nsingle = h_fwd_nsingle;
+  f->h_lvl_two.assign(static_cast<size_t>(s.nlevels), 1);
+  for (int q = 0; q < nf; ++q)
+    if (nchild[q] > 2) f->h_lvl_two[s.f_level[q]] = 0;
   f->h_bwd_nsingle = h_bwd_nsingle;
   f->h_wave_ptr = h_wave_ptr;
   f->ft_doubles = ftoff[nf];
@@ -1739,6 +1788,9 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   UP(d_bwd_wg, bwd_wg)
   UP(d_wave_wg, wave_wg)
   UP(d_ftoff, ftoff)
+  if (packed) {
+    UP(d_pkoff, pkoff)
+  }
   UP(d_tr_pref, tr_pref)
   UP(d_bout, bout)
   UP(d_tri_pref, tri_pref)
@@ -1773,6 +1825,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   rc = dmalloc(&f->d_T, static_cast<size_t>(f->t_doubles));
   rc = dmalloc(&f->d_aux, 2);
   rc = dmalloc(&f->d_Ft, static_cast<size_t>(f->ft_doubles));
+  if (packed) rc = dmalloc(&f->d_Pk, static_cast<size_t>(std::max<int64_t>(pkoff[nf], 1)));
   rc = dmalloc(&f->d_P, static_cast<size_t>(n_slabs) * TW * KBMAX);
   if (rc == EIGD_OK) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_tickets), sizeof(int) * f->n_tickets);

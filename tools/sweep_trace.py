@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""a few k=32 and k=4 sweeps on the C3 factor, for kernel traces (development aid)"""
+"""a few sweeps of the widths given on the command line (default 4 32) on the C3 factor, for kernel traces"""
 import os
 import sys
 
@@ -14,7 +14,7 @@ col = BucklingColumn(706, 706, seed=0)
 K = col.stiffness()
 F = Factor(ctx, K, coords=col.dof_coords())
 rng = np.random.default_rng(0)
-for k in (4, 32):
+for k in ([int(a) for a in sys.argv[1:]] or [4, 32]):
     B = ctx.from_host(rng.normal(size=(K.shape[0], k)))
     for _ in range(3):
         F.solve_inplace(B)
