@@ -527,6 +527,7 @@ struct LevelArgs {
   double* P;      // partial slabs, 64 x KBMAX each
   int* tickets;   // one per split tile, zero between sweeps
   int kb;
+  int kd;         // rows of the LDS tiles this launch was given (multiple of 8, <= 64): the longest product of the level
 };
 
 constexpr int TILE_IT = TW * TW / kThreads;  // 16 matrix elements per lane and tile
@@ -603,14 +604,16 @@ __device__ __forceinline__ bool fold_groups(const WgRec& w, const LevelArgs& la,
 // step t+1 are in flight while step t multiplies.  Masked lanes load from a zero word (address select): a branch
 // around the load would serialise the loads of a tile.
 template <int KPT, bool SINGLE, bool DEEP, int NSL>  // NSL: carry planes compiled in (2: binary trees, else kMaxS + 1)
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((SINGLE && KPT == 4) ? 3 : 1)))
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((SINGLE && (KPT == 4 || (KPT == 8 && !DEEP))) ? 3 : 1)))
 void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
                                                             const double* __restrict__ Tb, const double* X, int ldx,
                                                             double alpha, double* V, double* __restrict__ Y) {
   using T = Tile<KPT>;
   constexpr int IT = KPT;  // vector elements per lane: (64 x KB) / 256
-  __shared__ double As[TW * TLD];
-  __shared__ double Bs[TW * T::BLD];
+  extern __shared__ double lds_tiles[];  // la.kd (+ 1 spare) rows of the matrix tile, as many of the vector block
+  double* const As = lds_tiles;
+  const int kdl = SINGLE ? la.kd : TW;  // (a constant where the fronts have several column tiles: folded LDS offsets)
+  double* const Bs = lds_tiles + ((SINGLE && KPT == 4) ? 0 : (kdl + 1) * TLD);  // (the direct-fragment path has no matrix tile)
   const WgRec w = la.wg[blockIdx.x];
   const int kb = la.kb;
   const int ns = w.ns;
@@ -667,13 +670,14 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
   };
   auto commit_a = [&](const double (&av)[TILE_IT]) {
 #pragma unroll
-    for (int it = 0; it < TILE_IT; ++it) As[(ajb + it * (kThreads / TW)) * TLD + ar] = av[it];  // As[k][o] = R(row0 + o, ct*64 + k)
+    for (int it = 0; it < TILE_IT; ++it)  // As[k][o] = R(row0 + o, ct*64 + k); rows past the allocation -> spare row kdl
+      As[min(ajb + it * (kThreads / TW), kdl) * TLD + ar] = av[it];
   };
   auto commit_b = [&]() {
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
       const int idx = threadIdx.x + e * kThreads;
-      Bs[(idx / T::KB) * T::BLD + (idx & (T::KB - 1))] = bv[e];
+      Bs[min(idx / T::KB, kdl) * T::BLD + (idx & (T::KB - 1))] = bv[e];
     }
   };
   // carries on the rows of border tile rt and where its results go (rows of the parent), in the lane's output layout
@@ -803,7 +807,7 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
 #pragma unroll
       for (int e = h; e < h + HB; ++e) {
         const int idx = threadIdx.x + e * kThreads;
-        Bs[(idx / T::KB) * T::BLD + (idx & (T::KB - 1))] = vh[e - h];
+        Bs[min(idx / T::KB, kdl) * T::BLD + (idx & (T::KB - 1))] = vh[e - h];
       }
       asm volatile("" ::: "memory");  // keep the halves apart: the second half's loads are not hoisted above these stores
     }
@@ -814,7 +818,7 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
       commit_a(cur);
       __syncthreads();
       if (nxt < w.s1) fetch_a(nxt, 0, cur);
-      if (rt >= nst) fetch_carry(rt, cg, di);
+      if (rt >= nst) fetch_carry(rt, cg, di);  // (requested a tile ahead they would cost the third workgroup per CU)
 #pragma unroll
       for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
       T::mac(As, Bs, ns, acc);
@@ -864,14 +868,16 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
 //   x1(ct) = sum_{rt >= ct} T(rt, ct)^T y(rt)  -  sum_bt M21(bt, ct)^T x_border(bt)
 // y = S z from the forward sweep (Y); x_border are rows of the caller's block Out that the ancestors' launches
 // have already written (bout = their row numbers).  The solution goes straight to Out.
-template <int KPT>
+template <int KPT, bool SINGLE>  // SINGLE: fronts with one column tile, LDS tiles of la.kd rows
 __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
                                                             const double* __restrict__ Tb,
                                                             const double* __restrict__ Y, double* Out, int ldo) {
   using T = Tile<KPT>;
   constexpr int IT = KPT;
-  __shared__ double As[TW * TLD];
-  __shared__ double Bs[TW * T::BLD];
+  extern __shared__ double lds_tiles[];
+  double* const As = lds_tiles;
+  const int kdl = SINGLE ? la.kd : TW;
+  double* const Bs = lds_tiles + (kdl + 1) * TLD;
   const WgRec w = la.wg[blockIdx.x];
   const int ct = w.tile;
   const int kb = la.kb;
@@ -931,11 +937,12 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int it = 0; it < TILE_IT; ++it) As[ar * TLD + ajb + it * (kThreads / TW)] = av[it];  // As[k][o] = R(rbase + k, c0t + o)
+    for (int it = 0; it < TILE_IT; ++it)  // As[k][o] = R(rbase + k, c0t + o); rows past the allocation -> spare row kdl
+      As[min(ar, kdl) * TLD + ajb + it * (kThreads / TW)] = av[it];
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
       const int idx = threadIdx.x + e * kThreads;
-      Bs[(idx / T::KB) * T::BLD + (idx & (T::KB - 1))] = bv[e];
+      Bs[min(idx / T::KB, kdl) * T::BLD + (idx & (T::KB - 1))] = bv[e];
     }
   };
 
@@ -1137,6 +1144,169 @@ __global__ __launch_bounds__(64) void bwd_wave_kernel(FrontArrays fa, const WgRe
   }
 }
 
+
+// ------------------------------------------------------------------ thin fronts (few own columns), 16 or 32 columns
+// Two or three levels above the leaves the fronts have a handful of own columns and a long border: almost no flops,
+// but every tile step of the workgroup kernels above is a round of dependent loads with two workgroups per CU to hide
+// it.  These fronts get one WAVE per unit of work, no LDS, no barrier: the MFMA operands are loaded from global
+// memory straight into the operand layout (lane (i, k) of v_mfma_f64_16x16x4: A[i][k] and B[k][i]), everything a
+// wave needs is requested in one or two rounds, and 12 to 16 waves per CU are in flight.
+//
+// forward: wave = 16-row blocks rb, rb + 2, ... of [T; M21] (two waves per front).  K = own columns (NKS steps of 4).
+template <int KB, int NKS, int NSL>
+__global__ __launch_bounds__(128) void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
+                                                       const double* __restrict__ F, const double* __restrict__ Tb,
+                                                       const double* X, int ldx, double alpha, double* V,
+                                                       double* __restrict__ Y, int kb) {
+  constexpr int NB = KB / 16;
+  const WgRec w = recs[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ns = w.ns, d = ns + w.bs;
+  const int nslot = ((w.flags & 2) != 0) ? fa.nslot : 0;
+  const int64_t vslot = fa.vrows * KB, vbase = w.voff;
+  // v1 = alpha * X[own rows] + carries, as B operands: lane (k, n) holds v1[4 s + k][16 nb + n]
+  double b[NKS][NB];
+  {
+    int xi[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) xi[s] = *((4 * s + lk < ns) ? fa.v_src + vbase + 4 * s + lk : fa.neg1);
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int o = 4 * s + lk, n = 16 * nb + li;
+        const bool ok = xi[s] >= 0 && n < kb;
+        double v = alpha * *(ok ? X + static_cast<int64_t>(xi[s]) * ldx + n : fa.zero);
+        const double* cp = V + (vbase + o) * KB + n;
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) v += *((ok && sl < nslot) ? cp + sl * vslot : fa.zero);
+        b[s][nb] = v;
+      }
+  }
+  double* Vout = V + static_cast<int64_t>(w.slot) * vslot;
+  const double* Tf = Tb + w.toff;
+  const double* Ff = F + w.foff;
+  const int nrb = (d + 15) >> 4;
+  for (int rb = wave; rb < nrb; rb += 2) {
+    const int r = 16 * rb + li;  // the row this lane feeds as A operand
+    double a[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      const int o = 4 * s + lk;
+      const double* p = (r < ns) ? Tf + static_cast<int64_t>(o) * w.ldt + r : Ff + static_cast<int64_t>(o) * d + r;
+      a[s] = *((o < ns && r < d) ? p : fa.zero);
+    }
+    // what the results meet: lane (reg, nb) <-> row 16 rb + lk + 4 reg, column 16 nb + li
+    int di[4];
+    double sg[4], cg[4][NB];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int ro = 16 * rb + lk + 4 * reg;
+      const bool border = ro >= ns && ro < d;
+      di[reg] = *(border ? fa.rel + w.bptr + (ro - ns) : fa.neg1);
+      sg[reg] = *((ro < ns) ? fa.sgn + w.c0 + ro : fa.zero);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = 16 * nb + li;
+        const double* cp = V + (vbase + ro) * KB + n;
+        double v = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) v += *((border && n < kb && sl < nslot) ? cp + sl * vslot : fa.zero);
+        cg[reg][nb] = v;
+      }
+    }
+    double4_t c[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) c[nb] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) c[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s][nb], c[nb], 0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one wait, then the stores back to back
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int ro = 16 * rb + lk + 4 * reg;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = 16 * nb + li;
+        if (ro < ns) {
+          if (n < kb) Y[(vbase + ro) * kb + n] = sg[reg] * c[nb][reg];
+        } else if (di[reg] >= 0 && n < kb) {
+          const int64_t drow = (w.scratch != 0) ? vbase + ro : w.pvoff + di[reg];
+          Vout[drow * KB + n] = cg[reg][nb] - c[nb][reg];
+        }
+      }
+    }
+  }
+}
+
+// backward: wave = (front, block of 16 own columns); K = all d rows of the front in chunks of 32, from the transposed
+// copy Ft (row r of [T; M21] at r * ns).  The border rows of the caller's block are found through bout, which the
+// wave holds lane by lane (bs <= 320) and reads with ds_bpermute: no dependent index round per chunk.
+template <int KB>
+__global__ __launch_bounds__(64) void bwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
+                                                      const double* __restrict__ Ft, const double* __restrict__ Y,
+                                                      double* Out, int ldo, int kb) {
+  constexpr int NB = KB / 16;
+  const WgRec w = recs[blockIdx.x];
+  const int ob = blockIdx.y;
+  const int ns = w.ns, bs = w.bs, d = ns + bs;
+  if (16 * ob >= ns) return;
+  const int lane = threadIdx.x;
+  const int li = lane & 15, lk = lane >> 4;
+  const int64_t vbase = w.voff;
+  const int* __restrict__ bout = fa.bout + w.bptr;
+  const double* Fp = Ft + w.ftoff;
+  const int o = 16 * ob + li;
+  const bool ook = o < ns;
+  int I[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) I[q] = *((64 * q + lane < bs) ? bout + 64 * q + lane : fa.neg1);
+  int oi[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int oo = 16 * ob + lk + 4 * reg;
+    oi[reg] = *((oo < ns) ? fa.v_src + vbase + oo : fa.neg1);
+  }
+  double4_t c[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) c[nb] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int nchunk = (d + 31) >> 5;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    double a[8], b[8][NB];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k = 32 * ch + 4 * s + lk;
+      a[s] = *((k < d && ook) ? Fp + static_cast<int64_t>(k) * ns + o : fa.zero);
+      const int e = k - ns;  // border entry
+      const int r0 = __shfl(I[0], e & 63), r1 = __shfl(I[1], e & 63), r2 = __shfl(I[2], e & 63), r3 = __shfl(I[3], e & 63);
+      const int r4 = __shfl(I[4], e & 63);
+      const int q = e >> 6;
+      const int ri = (e < 0 || k >= d) ? -1 : (q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : q == 3 ? r3 : r4);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = 16 * nb + li;
+        const double* p = (e < 0) ? Y + (vbase + k) * kb + n : Out + static_cast<int64_t>(ri) * ldo + n;
+        const double v = *((n < kb && (e < 0 || ri >= 0)) ? p : fa.zero);
+        b[s][nb] = (e < 0) ? v : -v;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) c[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s][nb], c[nb], 0, 0, 0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = 16 * nb + li;
+      if (oi[reg] >= 0 && n < kb) Out[static_cast<int64_t>(oi[reg]) * ldo + n] = c[nb][reg];
+    }
+}
+
 // Ft(r, o) = [T; M21](r, o), row-major d x ns per front: 64 x 64 tiles through LDS
 __global__ __launch_bounds__(kThreads) void transpose_front_kernel(FrontArrays fa, const int* __restrict__ tr_pref,
                                                                   int nfronts, const int64_t* __restrict__ ftoff,
@@ -1207,7 +1377,10 @@ struct eigd_factor {
   int64_t* d_toff = nullptr;
   double *d_T = nullptr, *d_aux = nullptr;  // aux: {0.0, (int) -1}
   std::vector<int> h_fwd_ptr, h_bwd_ptr;  // per level: first workgroup record
+  std::vector<int> h_thin_fwd, h_thin_bwd;  // per level: 4, 8 or 16 K-steps (of 4 own columns) of the wave-per-block kernels, 0: the tile kernels
+  std::vector<int> h_fwd_kd, h_bwd_kd;    // per level: LDS tile rows of the single-column-tile launches (multiple of 8)
   std::vector<char> h_lvl_two;            // per level: every front has at most two children (two-plane kernels)
+  std::vector<char> h_lvl_leaf;           // per level: no front has children (kernels without carry loads)
   std::vector<int> h_fwd_nsingle;         // per level: leading records of single-column-tile fronts (own kernel)
   std::vector<int> h_bwd_nsingle;         // per level: leading backward records of single-column-tile fronts
   // narrow sweeps (k <= 8): one record per single-tile front and level, the transposed copy of [T; M21]
@@ -1342,9 +1515,6 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false) {
   return EIGD_OK;
 }
 
-// second matrix tile in flight in the single-column-tile forward kernel: where the registers are free anyway
-template <int KPT>
-constexpr bool kDeepSingle = true;
 
 template <int KPT>
 int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, int* wT, const double* dIn, int ldin,
@@ -1359,14 +1529,21 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     const char* v = std::getenv("EIGD_WAVE_MAX_KPT");
     return (v && *v) ? std::atoi(v) : 2;
   }();
-  auto level_args = [&](const WgRec* wg) {
+  // second matrix tile in flight in the single-column-tile forward kernel: off, the registers buy a third workgroup per CU
+  static const bool deep_single = [] {
+    const char* v = std::getenv("EIGD_DEEP");
+    return (v && *v) ? std::atoi(v) != 0 : false;
+  }();
+  auto level_args = [&](const WgRec* wg, int kd = TW) {
     LevelArgs la;
     la.wg = wg;
     la.P = wP;
     la.tickets = wT;
     la.kb = kb;
+    la.kd = kd;
     return la;
   };
+  auto lds_bytes = [](int kd) { return static_cast<unsigned>(sizeof(double) * (kd + 1) * (TLD + Tile<KPT>::BLD)); };
   const double* sF = f->d_Pk ? f->d_Pk : f->d_F;  // the panels [T; M21]: packed copy, or in place (F and T)
   const double* sT = f->d_Pk ? f->d_Pk : f->d_T;
   // ---- forward: leaves -> root.  Y receives S z, the border rows of V the carries.
@@ -1381,11 +1558,15 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     }
     const int nwg = f->h_fwd_ptr[l + 1] - f->h_fwd_ptr[l], nsingle = f->h_fwd_nsingle[l];
     const bool two = f->h_lvl_two[l] != 0;  // no front of this level has more than two children
+    const bool leaf = f->h_lvl_leaf[l] != 0;  // ... has children at all
     const int nwave = f->h_wave_ptr[l + 1] - f->h_wave_ptr[l];
     bool narrow = false;
     if (KPT <= wave_max_kpt) {
       if (nwave > 0) {  // narrow sweep: one wave per tile of the single-tile fronts
-        if (two)
+        if (leaf)
+          hipLaunchKernelGGL((fwd_wave_kernel<KB, 0>), dim3(nwave), dim3(128), 0, st, fa, f->d_wave_wg + f->h_wave_ptr[l],
+                             sF, sT, dIn, ldin, alpha, wV, wY, kb);
+        else if (two)
           hipLaunchKernelGGL((fwd_wave_kernel<KB, 2>), dim3(nwave), dim3(128), 0, st, fa, f->d_wave_wg + f->h_wave_ptr[l],
                              sF, sT, dIn, ldin, alpha, wV, wY, kb);
         else
@@ -1395,23 +1576,64 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
         narrow = true;
       }
     }
+    if constexpr (KPT >= 4) {
+      const int nks = f->h_thin_fwd[l];
+      if (!narrow && nwave > 0 && nks > 0) {  // thin fronts: one wave per block of rows, operands straight from memory
+        const WgRec* recs = f->d_wave_wg + f->h_wave_ptr[l];
+#define EIGD_THIN_FWD(NKS, NSLV)                                                                                       \
+  hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV>), dim3(nwave), dim3(128), 0, st, fa, recs, sF, sT, dIn, ldin, alpha, \
+                     wV, wY, kb)
+        if (leaf && nks == 4)
+          EIGD_THIN_FWD(4, 0);
+        else if (leaf && nks == 8)
+          EIGD_THIN_FWD(8, 0);
+        else if (leaf)
+          EIGD_THIN_FWD(16, 0);
+        else if (nks == 4 && two)
+          EIGD_THIN_FWD(4, 2);
+        else if (nks == 4)
+          EIGD_THIN_FWD(4, kMaxS + 1);
+        else if (nks == 8 && two)
+          EIGD_THIN_FWD(8, 2);
+        else if (nks == 8)
+          EIGD_THIN_FWD(8, kMaxS + 1);
+        else if (two)
+          EIGD_THIN_FWD(16, 2);
+        else
+          EIGD_THIN_FWD(16, kMaxS + 1);
+#undef EIGD_THIN_FWD
+        EIGD_LAUNCH_CHECK();
+        narrow = true;
+      }
+    }
     if (!narrow && nsingle > 0) {
-      if (two)
-        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, kDeepSingle<KPT>, 2>), dim3(nsingle), dim3(kThreads), 0, st, fa,
-                           level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), sF, sT, dIn, ldin, alpha, wV, wY);
+      const int kd = (KPT == 4) ? TW : f->h_fwd_kd[l];  // (the direct-fragment path reads all 64 rows of the block)
+      const LevelArgs la = level_args(f->d_fwd_wg + f->h_fwd_ptr[l], kd);
+      auto lds_bytes = [](int kd) {  // (shadows the general one: the direct-fragment path keeps only the vector block)
+        return static_cast<unsigned>(sizeof(double) * (kd + 1) * ((KPT == 4 ? 0 : TLD) + Tile<KPT>::BLD));
+      };
+      if (leaf)
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, false, 0>), dim3(nsingle), dim3(kThreads), lds_bytes(kd), st, fa, la,
+                           sF, sT, dIn, ldin, alpha, wV, wY);
+      else if (two && deep_single)
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, true, 2>), dim3(nsingle), dim3(kThreads), lds_bytes(kd), st, fa, la,
+                           sF, sT, dIn, ldin, alpha, wV, wY);
+      else if (two)
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, false, 2>), dim3(nsingle), dim3(kThreads), lds_bytes(kd), st, fa, la,
+                           sF, sT, dIn, ldin, alpha, wV, wY);
       else
-        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, kDeepSingle<KPT>, kMaxS + 1>), dim3(nsingle), dim3(kThreads), 0,
-                           st, fa, level_args(f->d_fwd_wg + f->h_fwd_ptr[l]), sF, sT, dIn, ldin, alpha, wV, wY);
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, false, kMaxS + 1>), dim3(nsingle), dim3(kThreads), lds_bytes(kd), st,
+                           fa, la, sF, sT, dIn, ldin, alpha, wV, wY);
       EIGD_LAUNCH_CHECK();
     }
     if (nwg > nsingle) {
       if (two)
-        hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, 2>), dim3(nwg - nsingle), dim3(kThreads), 0, st, fa,
-                           level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), sF, sT, dIn, ldin, alpha, wV, wY);
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, 2>), dim3(nwg - nsingle), dim3(kThreads), lds_bytes(TW), st,
+                           fa, level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), sF, sT, dIn, ldin, alpha, wV, wY);
       else
-        hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, kMaxS + 1>), dim3(nwg - nsingle), dim3(kThreads), 0, st,
-                           fa, level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), sF, sT, dIn, ldin, alpha, wV,
-                           wY);
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, kMaxS + 1>), dim3(nwg - nsingle), dim3(kThreads),
+                           lds_bytes(TW), st, fa, level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), sF, sT, dIn, ldin,
+                           alpha, wV, wY);
       EIGD_LAUNCH_CHECK();
     }
   }
@@ -1420,23 +1642,30 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     const int nwg = f->h_bwd_ptr[l + 1] - f->h_bwd_ptr[l];
     if (nwg == 0) continue;
     const int nwave = f->h_wave_ptr[l + 1] - f->h_wave_ptr[l];
-    if (KPT <= wave_max_kpt) {
-      if (nwave > 0) {  // narrow sweep: the single-tile fronts go wave by wave, the others as always
-        const int nsb = f->h_bwd_nsingle[l];
-        if (nwg > nsb) {
-          hipLaunchKernelGGL(bwd_level_kernel<KPT>, dim3(nwg - nsb), dim3(kThreads), 0, st, fa,
-                             level_args(f->d_bwd_wg + f->h_bwd_ptr[l] + nsb), sF, sT, wY, dX, ldx);
-          EIGD_LAUNCH_CHECK();
-        }
-        hipLaunchKernelGGL(bwd_wave_kernel<KB>, dim3(nwave), dim3(64), 0, st, fa, f->d_wave_wg + f->h_wave_ptr[l],
-                           f->d_Ft, wY, dX, ldx, kb);
-        EIGD_LAUNCH_CHECK();
-        continue;
-      }
+    const int nsb = f->h_bwd_nsingle[l];
+    const bool narrow = KPT <= wave_max_kpt && nwave > 0;  // narrow sweep: the single-tile fronts go wave by wave
+    bool thin = false;
+    if constexpr (KPT >= 4) thin = !narrow && nwave > 0 && f->h_thin_bwd[l] > 0;
+    if (nwg > nsb) {  // fronts with several column tiles: full 64-row tiles
+      hipLaunchKernelGGL((bwd_level_kernel<KPT, false>), dim3(nwg - nsb), dim3(kThreads), lds_bytes(TW), st, fa,
+                         level_args(f->d_bwd_wg + f->h_bwd_ptr[l] + nsb), sF, sT, wY, dX, ldx);
+      EIGD_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(bwd_level_kernel<KPT>, dim3(nwg), dim3(kThreads), 0, st, fa,
-                       level_args(f->d_bwd_wg + f->h_bwd_ptr[l]), sF, sT, wY, dX, ldx);
-    EIGD_LAUNCH_CHECK();
+    if (narrow) {
+      hipLaunchKernelGGL(bwd_wave_kernel<KB>, dim3(nwave), dim3(64), 0, st, fa, f->d_wave_wg + f->h_wave_ptr[l], f->d_Ft,
+                         wY, dX, ldx, kb);
+      EIGD_LAUNCH_CHECK();
+    } else if (thin) {
+      if constexpr (KPT >= 4) {
+        hipLaunchKernelGGL(bwd_thin_kernel<KB>, dim3(nwave, f->h_thin_bwd[l] / 4), dim3(64), 0, st, fa,
+                           f->d_wave_wg + f->h_wave_ptr[l], f->d_Ft, wY, dX, ldx, kb);
+        EIGD_LAUNCH_CHECK();
+      }
+    } else if (nsb > 0) {  // single-column-tile fronts: LDS tiles as tall as the level needs
+      hipLaunchKernelGGL((bwd_level_kernel<KPT, true>), dim3(nsb), dim3(kThreads), lds_bytes(f->h_bwd_kd[l]), st, fa,
+                         level_args(f->d_bwd_wg + f->h_bwd_ptr[l], f->h_bwd_kd[l]), sF, sT, wY, dX, ldx);
+      EIGD_LAUNCH_CHECK();
+    }
   }
   return EIGD_OK;
 }
@@ -1752,10 +1981,41 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   f->sym = &h->s;
   f->h_fwd_ptr = h_fwd_ptr;
   f->h_fwd_nsingle = h_fwd_nsingle;
+  f->h_lvl_leaf.assign(static_cast<size_t>(s.nlevels), 1);
+  for (int q = 0; q < nf; ++q)
+    if (nchild[q] > 0) f->h_lvl_leaf[s.f_level[q]] = 0;
   f->h_lvl_two.assign(static_cast<size_t>(s.nlevels), 1);
   for (int q = 0; q < nf; ++q)
     if (nchild[q] > 2) f->h_lvl_two[s.f_level[q]] = 0;
   f->h_bwd_nsingle = h_bwd_nsingle;
+  f->h_fwd_kd.assign(static_cast<size_t>(s.nlevels), 8);
+  f->h_bwd_kd.assign(static_cast<size_t>(s.nlevels), 8);
+  {
+    // levels for the wave-per-block kernels: every single-column-tile front has at most EIGD_THIN_NS_FWD / _BWD own
+    // columns (forward: all of them pay off; backward: up to 32, beyond that the waves of a front re-read too much)
+    // and a border of <= 320
+    const int thin_fwd = std::min(TW, env_int("EIGD_THIN_NS_FWD", TW)), thin_bwd = std::min(TW, env_int("EIGD_THIN_NS_BWD", 32));
+    std::vector<int> mxns(static_cast<size_t>(s.nlevels), 0), mxbs(static_cast<size_t>(s.nlevels), 0);
+    for (int q = 0; q < nf; ++q) {
+      if (s.f_ns[q] > TW) continue;
+      mxns[s.f_level[q]] = std::max<int>(mxns[s.f_level[q]], s.f_ns[q]);
+      mxbs[s.f_level[q]] = std::max<int>(mxbs[s.f_level[q]], s.f_bs[q]);
+    }
+    f->h_thin_fwd.assign(static_cast<size_t>(s.nlevels), 0);
+    f->h_thin_bwd.assign(static_cast<size_t>(s.nlevels), 0);
+    for (int l = 0; l < s.nlevels; ++l) {
+      const int nks = (mxns[l] <= 16) ? 4 : (mxns[l] <= 32) ? 8 : 16;
+      if (mxns[l] > 0 && mxns[l] <= thin_fwd) f->h_thin_fwd[l] = nks;
+      if (mxns[l] > 0 && mxns[l] <= thin_bwd && mxbs[l] <= 320) f->h_thin_bwd[l] = nks;
+    }
+  }
+  for (int q = 0; q < nf; ++q) {
+    if (s.f_ns[q] > TW) continue;
+    const int l = s.f_level[q];
+    const int bsq = (s.f_parent[q] >= 0) ? std::min<int>(TW, s.f_bs[q]) : 0;
+    f->h_fwd_kd[l] = std::max(f->h_fwd_kd[l], (s.f_ns[q] + 7) & ~7);
+    f->h_bwd_kd[l] = std::max(f->h_bwd_kd[l], (std::max<int>(s.f_ns[q], bsq) + 7) & ~7);
+  }
   f->h_wave_ptr = h_wave_ptr;
   f->ft_doubles = ftoff[nf];
   f->n_tr = tr_pref[nf];
@@ -1903,9 +2163,13 @@ static int solve_blocks(eigd_factor* f, hipStream_t st, double* wV, double* wY, 
       const char* v = std::getenv("EIGD_SWEEP_MIN_KPT");
       return (v && *v) ? std::atoi(v) : 1;
     }();
+    static const bool kpt2 = [] {  // EIGD_SWEEP_KPT2: the 8-column kernels (off: 5..8 columns run through the 16-column
+      const char* v = std::getenv("EIGD_SWEEP_KPT2");  // kernels, whose single-tile levels are MFMA wave kernels)
+      return (v && *v) ? std::atoi(v) != 0 : false;
+    }();
     if (kb <= 4 && min_kpt <= 1)
       rc = sweep<1>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
-    else if (kb <= 8 && min_kpt <= 2)
+    else if (kb <= 8 && min_kpt <= 2 && kpt2)
       rc = sweep<2>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else if (kb <= 16)
       rc = sweep<4>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);

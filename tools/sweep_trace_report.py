@@ -7,7 +7,7 @@ import sys
 path = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-sw = [r for r in rows if any(t in r["Kernel_Name"] for t in ("level_kernel", "wave_kernel", "overflow"))]
+sw = [r for r in rows if any(t in r["Kernel_Name"] for t in ("level_kernel", "wave_kernel", "thin_kernel", "overflow"))]
 # split into sweeps: a sweep starts at a forward kernel that follows a backward kernel
 sweeps, cur, prev_bwd = [], [], True
 for r in sw:
