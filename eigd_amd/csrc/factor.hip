@@ -858,8 +858,8 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
     T::mac(As, Bs, min(TW, ns - ct * TW), acc);
     __syncthreads();
   }
+  if (rt >= nst) fetch_carry(rt, cg, di);  // in flight while the groups of a split chain are joined
   if (w.G > 1 && !fold_groups<KPT>(w, la, acc, reinterpret_cast<int*>(As))) return;
-  if (rt >= nst) fetch_carry(rt, cg, di);
   store_tile(rt, acc, cg, di);
   }
 }
@@ -963,9 +963,8 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
     T::mac(As, Bs, kdim, acc);
     __syncthreads();
   }
-  if (w.G > 1 && !fold_groups<KPT>(w, la, acc, reinterpret_cast<int*>(As))) return;
-  // destination rows first, ONE explicit wait, then the stores: an index load inside each masked store block would
-  // make every store wait for the one before it (vmcnt(0) per block)
+  // destination rows first (in flight while the groups of a split chain are joined), ONE explicit wait, then the
+  // stores: an index load inside each masked store block would make every store wait for the one before it
   int oi[T::NOUT];
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) {
@@ -973,6 +972,7 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
     T::coords(t, o, c);
     oi[t] = *((o < wc && c < kb) ? fa.v_src + vbase + c0t + o : fa.neg1);
   }
+  if (w.G > 1 && !fold_groups<KPT>(w, la, acc, reinterpret_cast<int*>(As))) return;
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) {
@@ -1861,7 +1861,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     return (v && *v) ? std::atoi(v) : dflt;
   };
   // chains longer than split_min tiles are cut into groups of about split_len tiles (at most split_maxg groups)
-  const int split_min = env_int("EIGD_SPLIT_MIN", 4), split_len = std::max(1, env_int("EIGD_SPLIT_LEN", 4));
+  const int split_min = env_int("EIGD_SPLIT_MIN", 3), split_len = std::max(1, env_int("EIGD_SPLIT_LEN", 3));
   const int split_maxg = std::max(1, env_int("EIGD_SPLIT_MAXG", 12)), split_nfl = env_int("EIGD_SPLIT_NFL", 128);
   // packed sweep panels: level by level in launch order, every front one contiguous d x ns block
   const bool packed = env_int("EIGD_PACKED", 0) != 0;

@@ -41,6 +41,7 @@ namespace eigd {
 
 constexpr int kTileRows = 32;    // matrix rows per SpMM tile
 constexpr int kTileLds = 40 * 1024;  // LDS budget of the staged X rows (bytes)
+constexpr int kTileNnz = 1024;       // non-zeros of a tile staged through LDS (more: read from global memory)
 constexpr int kNnzTile = 2048;   // products staged per workgroup (16 KiB of LDS)
 constexpr int kMaxRowsTile = 256;
 
@@ -163,16 +164,42 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled_kernel(int n, int k, int 
                                                              const uint16_t* __restrict__ lidx,
                                                              const double* __restrict__ vals,
                                                              const double* __restrict__ X, int ldx,
-                                                             double* __restrict__ Y, int ldy, double alpha, double beta) {
+                                                             double* __restrict__ Y, int ldy, double alpha, double beta,
+                                                             int umax) {
   extern __shared__ double Xs[];
   constexpr int RP = kThreads / KP;
   constexpr int LD = KP + 1;
+  // the tile's non-zeros (values, local column numbers) go through LDS too: requested with the X rows, coalesced,
+  // instead of a dependent round trip per 8 non-zeros of a row in the product loop
+  double* const Vs = Xs + static_cast<size_t>(umax) * LD;
+  uint16_t* const Ls = reinterpret_cast<uint16_t*>(Vs + kTileNnz);
   // contiguous tile ranges per XCD (workgroups are dealt round-robin over the 8 XCDs): neighbouring tiles share
   // most of their X rows, this keeps that reuse inside one L2
   const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
   const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
   const int u0 = tile_ptr[tile], nu = tile_ptr[tile + 1] - u0;
+  const int rend = min(n, (tile + 1) * kTileRows);
+  const int e0 = indptr[tile * kTileRows], tnz = indptr[rend] - e0;
+  const bool staged = tnz <= kTileNnz;  // (a tile with very long rows reads its non-zeros from global memory)
+  constexpr int NQ = kTileNnz / kThreads;
+  constexpr int NR = (kTileRows + RP - 1) / RP;  // rows per lane; their extents are requested with everything else
+  int ra[NR], rz[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int r = tile * kTileRows + rr + i * RP;
+    ra[i] = (r < rend) ? indptr[r] - e0 : 0;
+    rz[i] = (r < rend) ? indptr[r + 1] - e0 : 0;
+  }
+  double sv[NQ];
+  uint16_t sl[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int e = threadIdx.x + q * kThreads;
+    const bool ok = staged && e < tnz;
+    sv[q] = ok ? vals[e0 + e] : 0.0;
+    sl[q] = ok ? lidx[e0 + e] : uint16_t(0);
+  }
   constexpr int SU = 16;  // staged rows per lane and trip: all their loads are in flight together
   for (int j0 = 0; j0 < nu; j0 += SU * RP) {
     int col[SU];
@@ -190,9 +217,45 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled_kernel(int n, int k, int 
       if (j < nu) Xs[j * LD + c] = x[q];
     }
   }
+  if (staged) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int e = threadIdx.x + q * kThreads;
+      if (e < tnz) {
+        Vs[e] = sv[q];
+        Ls[e] = sl[q];
+      }
+    }
+  }
   __syncthreads();
   if (c >= k) return;
-  const int rend = min(n, (tile + 1) * kTileRows);
+  if (staged) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int r = tile * kTileRows + rr + i * RP;
+      if (r >= rend) break;
+      const int a = ra[i], z = rz[i];
+      double s = 0.0;
+      int e = a;
+      for (; e + 8 <= z; e += 8) {  // eight non-zeros per trip: their LDS reads are in flight together
+        int li[8];
+        double v[8], x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          li[q] = Ls[e + q];
+          v[q] = Vs[e + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = Xs[li[q] * LD + c];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s = __dadd_rn(s, __dmul_rn(v[q], x[q]));
+      }
+      for (; e < z; ++e) s = __dadd_rn(s, __dmul_rn(Vs[e], Xs[Ls[e] * LD + c]));
+      double* yp = Y + static_cast<int64_t>(r) * ldy + c;
+      *yp = (beta == 0.0) ? alpha * s : alpha * s + beta * (*yp);
+    }
+    return;
+  }
   for (int r = tile * kTileRows + rr; r < rend; r += RP) {
     const int a = indptr[r], z = indptr[r + 1];
     double s = 0.0;
@@ -368,13 +431,15 @@ int eigd_spmm_on(eigd_ctx* ctx, eigd_mat* A, const double* dX, int ldx, double* 
     const int rp = kThreads / kp;
     const dim3 grid((A->n + rp - 1) / rp);
     const size_t tile_lds = sizeof(double) * static_cast<size_t>(A->umax) * (kp + 1);
+    const size_t tile_lds_all = tile_lds + static_cast<size_t>(kTileNnz) * (sizeof(double) + sizeof(uint16_t));
     if (A->ntiles > 0 && tile_lds <= static_cast<size_t>(kTileLds)) {
       const int per_xcd = (A->ntiles + 7) / 8;
       const dim3 tgrid(per_xcd * 8);
 #define EIGD_SPMM_TILED(KP)                                                                                            \
   case KP:                                                                                                             \
-    hipLaunchKernelGGL(spmm_tiled_kernel<KP>, tgrid, dim3(kThreads), tile_lds, st, A->n, kb, A->ntiles, per_xcd,        \
-                       A->tile_ptr, A->ucols, A->indptr, A->lidx, A->data, dX + c0, ldx, dY + c0, ldy, alpha, beta);   \
+    hipLaunchKernelGGL(spmm_tiled_kernel<KP>, tgrid, dim3(kThreads), tile_lds_all, st, A->n, kb, A->ntiles, per_xcd,    \
+                       A->tile_ptr, A->ucols, A->indptr, A->lidx, A->data, dX + c0, ldx, dY + c0, ldy, alpha, beta,    \
+                       A->umax);                                                                                       \
     break;
       switch (kp) {
         EIGD_SPMM_TILED(2)

@@ -17,7 +17,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = []
 prev_fwd = False
 for i, r in enumerate(rows):
-    fwd = "fwd_level" in r["Kernel_Name"]
+    fwd = any(t in r["Kernel_Name"] for t in ("fwd_level", "fwd_thin", "fwd_wave"))
     if fwd and not prev_fwd:
         starts.append(i)
     prev_fwd = fwd or ("overflow" in r["Kernel_Name"])
@@ -29,11 +29,11 @@ for w in range(len(starts)):
     sweep = other = gaps = 0.0
     prev = t0
     by = defaultdict(float)
-    kpt = re.search(r"level_kernel<(\d+)", seq[0]["Kernel_Name"]).group(1)
+    kpt = re.search(r"_kernel<(\d+)", seq[0]["Kernel_Name"]).group(1)
     for r in seq:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         name = r["Kernel_Name"].split("(")[0].replace("void eigd::", "").replace("eigd::", "")
-        if "level_kernel" in name:
+        if any(t in name for t in ("level_kernel", "thin_kernel", "wave_kernel", "overflow")):
             sweep += (e - prev) / 1e3
         else:
             other += (e - s) / 1e3
@@ -46,7 +46,7 @@ for w in range(len(starts)):
             totals[kname] += v
         tot_gap += gaps
     top = ", ".join(f"{k} {v:.0f}" for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:6])
-    print(f"sweep {w:3d} KPT {kpt}: sweep {sweep:7.1f}  other {other:7.1f}  gaps {gaps:6.1f} us | {top}")
+    print(f"sweep {w:3d} width {kpt}: sweep {sweep:7.1f}  other {other:7.1f}  gaps {gaps:6.1f} us | {top}")
     if w in which or (w - len(starts)) in which:
         prev = t0
         for r in seq:

@@ -13,7 +13,7 @@ from eigd_amd.problems import BucklingColumn  # noqa: E402
 ctx = default_context()
 col = BucklingColumn(706, 706, seed=0)
 K = col.stiffness()
-F = Factor(ctx, K, coords=col.dof_coords())
+F = Factor(ctx, K, coords=col.dof_coords(), leaf_size=int(os.environ.get("LEAF", "0")))
 rng = np.random.default_rng(0)
 out = []
 for k in (1, 4, 8, 16, 32):
