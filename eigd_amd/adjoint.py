@@ -297,8 +297,17 @@ def _total_derivative_device(dPhi, dPhib, dpsi, lam, lamb, dAdx, dBdx, dfdx, adj
     Phi_sel = None
     if not all(d or cb is None for d, cb in zip(dev_cb, (dAdx, dBdx))):
         Phi_sel = (Phi_host if Phi_host is not None else dPhi.get())[:, sel]
-    for cb, W, sign, on_dev in ((dAdx, WA, 1.0, dev_cb[0]), (dBdx, WB, sB, dev_cb[1])):
+    # device callbacks that can accumulate (ElementBilinear) share one device vector: one D2H, one host addition
+    acc = None
+    fused = [on_dev and hasattr(cb, "accumulate") and getattr(cb, "nelem", -1) == len(dfdx)
+             for cb, on_dev in zip((dAdx, dBdx), dev_cb)]
+    for cb, W, sign, on_dev, fuse in ((dAdx, WA, 1.0, dev_cb[0], fused[0]), (dBdx, WB, sB, dev_cb[1], fused[1])):
         if cb is None:
+            continue
+        if fuse:
+            if acc is None:
+                acc = Phi_sel_dev.ctx.zeros(len(dfdx), 1)
+            cb.accumulate(W, Phi_sel_dev, acc, alpha=sign)
             continue
         if on_dev:
             dfdx += sign * cb(W, Phi_sel_dev)
@@ -309,6 +318,8 @@ def _total_derivative_device(dPhi, dPhib, dpsi, lam, lamb, dAdx, dBdx, dfdx, adj
                 dfdx += sign * cb(Wh[:, q].copy(), Phi_sel[:, q])
         else:
             dfdx += sign * cb(Wh, Phi_sel)
+    if acc is not None:
+        dfdx += acc.get()[:, 0]
     return dfdx
 
 
