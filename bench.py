@@ -296,8 +296,8 @@ def main():
                   f"({time.perf_counter() - t0:.1f}s)")
 
     # ------------------------------------------------------------------ roofline of the dominant kernels (HIP events)
-    # The k-column triangular sweep (fwd_level_kernel + bwd_level_kernel, one launch per tree level and direction) is
-    # where a step spends most of its time.  One "launch" below = one sweep of N columns through the factor.
+    # The k-column triangular sweep (fwd_thin/fwd_level + bwd_thin/bwd_level kernels, one launch per tree level and
+    # direction) is where a step spends most of its time.  One "launch" below = one sweep of N columns through the factor.
     # Algorithmic bytes: every entry of L once per direction (2 * 8 * nnz(L)) plus the block
     # read and written once (16 n N).  HBM traffic: FETCH_SIZE (doubled, the guide's gfx950 correction, calibrated on
     # a stream of known size in the same run) + WRITE_SIZE from the PMC passes under profiles/; C3 default only.
@@ -313,9 +313,10 @@ def main():
     sweep_bytes = factor.factor.solve_bytes(N)
     default_c3 = (args.nx, args.ny, N, args.ordering) == (706, 706, 32, "geometric")
     achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
-    roofline = {"kernel": "fwd_level_kernel + bwd_level_kernel (one sweep of the factor, all tree levels)",
+    roofline = {"kernel": "fwd_thin_kernel + fwd_level_kernel + bwd_thin_kernel + bwd_level_kernel (one sweep of the factor, "
+                          "all tree levels)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": 6579000000 if default_c3 else None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": 7022000000 if default_c3 else None,
                 "traffic_source": "profiles/r01_pmc_fetch_sweep_coldot.csv + r01_pmc_write_sweep_coldot.csv",
                 "bytes_per_launch": sweep_bytes, "us_per_launch": round(sweep_ms * 1e3, 1), "columns": N,
                 "nnzL": fstats["nnzL"]}

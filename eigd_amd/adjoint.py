@@ -70,6 +70,10 @@ class DeviceProblem:
         """X <- X - BPhi (Phi^T X)   (residual-side projector P)"""
         return X.project(self.BPhi, self.Phi)
 
+    def project_r_norm2(self, X):
+        """project_r followed by the squared column norms of the result (device block; see DeviceBlock.project_norm2)"""
+        return X.project_norm2(self.BPhi, self.Phi)
+
     def project_s(self, X):
         """X <- X - Phi (BPhi^T X)   (solution-side projector P^T)"""
         return X.project(self.Phi, self.BPhi)
@@ -545,8 +549,7 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     Ta = enqueue_operator(0, lo, hi, int(np.count_nonzero(~done)))
     for j in range(1, maxiter + 1):
         h = _cgs2(W, Ta, j, c0=lo)                       # ref 1254-1256 (Gram-Schmidt vs all previous W)
-        prob.project_r(Ta)                               # ref 1257
-        hn2 = Ta.colnorm2_dev()                          # ref 1259: the norms stay on the device ...
+        hn2 = prob.project_r_norm2(Ta)                   # ref 1257 + 1259: the norms stay on the device ...
         jlast = j
         cur = (lo, hi)
         nxt = None

@@ -344,8 +344,12 @@ template <int NQ>
 __global__ __launch_bounds__(kThreads) void gemm_nn_direct_kernel(int n, int ku, int kx, const double* __restrict__ U,
                                                                  int64_t rsu, const double* __restrict__ C,
                                                                  double* __restrict__ X, int ldx, double alpha,
-                                                                 double beta) {
+                                                                 double beta, double* __restrict__ normpart) {
+  // normpart != nullptr: the squared column norms of the result are left as one partial sum per workgroup and
+  // column (normpart[blockIdx.x * kx + b]) -- the norm pass over X that would follow a projection is folded in
   extern __shared__ double Cs[];  // ku x cs_stride(kx)
+  __shared__ double nred[kThreads / 64][64];
+  double nsq[4] = {0.0, 0.0, 0.0, 0.0};
   const int tid = threadIdx.x;
   const int cld = cs_stride(kx);
   for (int q = tid; q < ku * kx; q += kThreads) Cs[(q / kx) * cld + q % kx] = C[q];
@@ -395,8 +399,27 @@ __global__ __launch_bounds__(kThreads) void gemm_nn_direct_kernel(int n, int ku,
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = lk + 4 * reg;  // f64 MFMA result map: row = (l>>4) + 4*reg, col = l&15
-        if (r < rows && b < kx) X[(base + r) * ldx + b] = outv[reg];
+        if (r < rows && b < kx) {
+          X[(base + r) * ldx + b] = outv[reg];
+          nsq[tb] += outv[reg] * outv[reg];
+        }
       }
+    }
+  }
+  if (normpart != nullptr) {  // fixed order: the lane's groups, its four row quarters, the four waves
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      double v = nsq[tb];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lk == 0) nred[wave][tb * 16 + li] = v;
+    }
+    __syncthreads();
+    if (tid < kx) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < kThreads / 64; ++w) v += nred[w][tid];
+      normpart[static_cast<int64_t>(blockIdx.x) * kx + tid] = v;
     }
   }
 }
@@ -569,20 +592,27 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
   return EIGD_OK;
 }
 
+// normpart / nparts: see gemm_nn_direct_kernel (row-major U only); *nparts = number of partial sums per column
 static int gemm_nn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu,
-                          const double* dC, double* dX, int ldx, double alpha, double beta) {
+                          const double* dC, double* dX, int ldx, double alpha, double beta, double* normpart = nullptr,
+                          int* nparts = nullptr) {
   const size_t cs_bytes = sizeof(double) * (ku * ((kx % 32 == 0) ? kx + 16 : kx) + kRB * (ku + 1));
   if (csu == 1 && ku <= 64) {  // row-major U: wave-private streaming without LDS staging
     const size_t cbytes = sizeof(double) * ku * ((kx % 32 == 0) ? kx + 16 : kx);
     const int nbd = grid_for_rows(n, 64);
+    if (nparts) *nparts = nbd;
     if (ku <= 32)
       hipLaunchKernelGGL(gemm_nn_direct_kernel<8>, dim3(nbd), dim3(kThreads), cbytes, ctx->stream, n, ku, kx, dU, rsu, dC,
-                         dX, ldx, alpha, beta);
+                         dX, ldx, alpha, beta, normpart);
     else
       hipLaunchKernelGGL(gemm_nn_direct_kernel<16>, dim3(nbd), dim3(kThreads), cbytes, ctx->stream, n, ku, kx, dU, rsu, dC,
-                         dX, ldx, alpha, beta);
+                         dX, ldx, alpha, beta, normpart);
     EIGD_LAUNCH_CHECK();
     return EIGD_OK;
+  }
+  if (normpart != nullptr) {
+    set_error("internal: fused column norms need a row-major U");
+    return EIGD_E_INTERNAL;
   }
   // a grid-stride kernel whose workgroups do not all fit the chip at once runs a second, thinly occupied round:
   // launch exactly what is resident
@@ -631,6 +661,29 @@ int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu
   int rc = gemm_tn_device(ctx, n, ku, kx, dV, ldv, 1, dX, ldx, &dC, nullptr);
   if (rc) return rc;
   return gemm_nn_device(ctx, n, ku, kx, dU, ldu, 1, dC, dX, ldx, -1.0, 1.0);
+}
+
+static int publish_norm2(eigd_ctx* ctx, const double* dOut, int k);
+
+int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv,
+                       double* dX, int ldx, double* dOut) {
+  EIGD_REQUIRE(ctx && dU && dV && dX && dOut, "null argument");
+  EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx && ldu >= ku && ldv >= ku,
+               "bad shape n=%d ku=%d kx=%d", n, ku, kx);
+  // scratch: [C (ku x kx)] [partials of C, later the partial squared norms]
+  const int nbd = grid_for_rows(n, 64);
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(ku) * kx + static_cast<size_t>(nbd) * kx));
+  if (rc) return rc;
+  double* dC = nullptr;
+  rc = gemm_tn_device(ctx, n, ku, kx, dV, ldv, 1, dX, ldx, &dC, nullptr);
+  if (rc) return rc;
+  double* normpart = ctx->scratch + static_cast<size_t>(ku) * kx;  // (the partials of C are spent by now)
+  int nparts = 0;
+  rc = gemm_nn_device(ctx, n, ku, kx, dU, ldu, 1, dC, dX, ldx, -1.0, 1.0, normpart, &nparts);
+  if (rc) return rc;
+  rc = reduce_to_host(ctx, normpart, nparts, kx, dOut, nullptr);
+  if (rc) return rc;
+  return publish_norm2(ctx, dOut, kx);
 }
 
 int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout) {
@@ -860,7 +913,11 @@ int eigd_colnorm2_dev(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, do
   EIGD_LAUNCH_CHECK();
   rc = reduce_to_host(ctx, partial, nb, k, dOut, nullptr);
   if (rc) return rc;
-  // copy for the host, in stream order right behind the reduction; eigd_colnorm2_fetch collects it
+  return publish_norm2(ctx, dOut, k);
+}
+
+// copy for the host, in stream order right behind the reduction; eigd_colnorm2_fetch collects it
+static int publish_norm2(eigd_ctx* ctx, const double* dOut, int k) {
   if (!ctx->pinned) {
     EIGD_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), sizeof(double) * 2 * kMaxK, hipHostMallocDefault));
     EIGD_HIP(hipEventCreateWithFlags(&ctx->ev_pinned, hipEventDisableTiming));

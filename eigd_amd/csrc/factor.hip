@@ -1953,7 +1953,9 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
       }
       const int nbt_b = (s.f_parent[fr] >= 0) ? nbt : 0;
       for (int t = 0; t < nst; ++t)
-        push_chain(nst == 1 ? bwd_wg : bmulti, bwd_slabs, fr, t, nst - t + nbt_b, split_level, 0);
+        // (a single-column-tile front is never split: the wave kernels run it in one piece, and a column's solution
+        // must not depend on the width of the sweep it is part of)
+        push_chain(nst == 1 ? bwd_wg : bmulti, bwd_slabs, fr, t, nst - t + nbt_b, split_level && nst > 1, 0);
     }
     h_fwd_nsingle[l] = static_cast<int>(fwd_wg.size()) - h_fwd_ptr[l];
     h_bwd_nsingle[l] = static_cast<int>(bwd_wg.size()) - h_bwd_ptr[l];

@@ -314,6 +314,15 @@ class DeviceBlock:
         call("eigd_project", self.ctx.h, self.n, U.k, self.k, U.ptr, U.ld, V.ptr, V.ld, self.ptr, self.ld)
         return self
 
+    def project_norm2(self, U, V):
+        """project(U, V), then the squared column norms of the result: as colnorm2_dev (device block + pinned copy for
+        ctx.fetch_colnorm2), but formed while the projection writes the block -- no extra pass over it"""
+        if U.k > 64 or self.k > 64:
+            return self.project(U, V).colnorm2_dev()
+        out = self.ctx.empty(1, self.k)
+        call("eigd_project_norm2", self.ctx.h, self.n, U.k, self.k, U.ptr, U.ld, V.ptr, V.ld, self.ptr, self.ld, out.ptr)
+        return out
+
     def gather_cols(self, cols):
         cols = np.ascontiguousarray(cols, dtype=np.int32)
         out = self.ctx.empty(self.n, len(cols))

@@ -140,6 +140,10 @@ int eigd_gemm_nn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t
 /* fused oblique projector X <- X - U (V^T X), coefficient matrix stays on the device (26-30) */
 int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv, double* dX,
                  int ldx);
+/* the projector followed by the squared column norms of the result (1257 + 1259 of sibk in one pass over X):
+ * dOut (device, kx) receives them; a pinned copy is left for eigd_colnorm2_fetch as after eigd_colnorm2_dev */
+int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv,
+                       double* dX, int ldx, double* dOut);
 /* column-wise dots  out[c] = sum_r X[r,c] Y[r,c]  (HOST out, length k); inner products / norms
  * of 1157-1158, 1219, 1233, 1259, 1504, 1537 batched over the modes                     */
 int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout);

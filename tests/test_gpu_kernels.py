@@ -320,6 +320,30 @@ def test_fused_gram_schmidt_step_and_device_norms(ctx, ns, k, c0):
     assert relerr(out, ref) < 1e-13
 
 
+@pytest.mark.parametrize("n,ku,k", [(7001, 7, 5), (20000, 32, 32), (4099, 33, 17), (333, 3, 64)])
+def test_projection_with_fused_column_norms(ctx, n, ku, k):
+    """X <- X - U (V^T X) and the squared column norms of the result in one pass (sibk lines 1257 + 1259)"""
+    rng = np.random.default_rng(n + k)
+    U, V, X = rng.normal(size=(n, ku)), rng.normal(size=(n, ku)) / n, rng.normal(size=(n, k))
+    dU, dV = ctx.from_host(U), ctx.from_host(V)
+    dX = ctx.from_host(X)
+    n2 = dX.project_norm2(dU, dV)
+    got = dX.get()
+    ref = X - U @ (V.T @ X)
+    assert relerr(got, ref) < 1e-13
+    assert np.allclose(n2.get()[0], (got * got).sum(axis=0), rtol=1e-13, atol=0.0)
+    assert np.allclose(ctx.fetch_colnorm2(k), (got * got).sum(axis=0), rtol=1e-13, atol=0.0)
+    # a strided view: the neighbouring columns stay untouched
+    if k >= 5:
+        dY = ctx.from_host(X)
+        n2v = dY.cols(1, 4).project_norm2(dU, dV)
+        out = dY.get()
+        assert np.array_equal(out[:, :1], X[:, :1]) and np.array_equal(out[:, 4:], X[:, 4:])
+        assert relerr(out[:, 1:4], ref[:, 1:4]) < 1e-13
+        assert np.allclose(n2v.get()[0], (out[:, 1:4] ** 2).sum(axis=0), rtol=1e-13, atol=0.0)
+        ctx.fetch_colnorm2(3)
+
+
 def test_split_chain_hand_off_is_reproducible_over_many_sweeps(ctx):
     """the in-launch hand-off of partial blocks (big fronts near the root) gives the same bits sweep after sweep"""
     from eigd_amd.device import Factor
