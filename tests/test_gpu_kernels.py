@@ -186,8 +186,9 @@ def test_factor_column_independence_and_refactor(ctx):
     rng = np.random.default_rng(3)
     B = rng.normal(size=(A.shape[0], 32))
     Xall = F.solve_inplace(ctx.from_host(B)).get()
-    X4 = F.solve_inplace(ctx.from_host(B[:, 4:8])).get()
-    assert np.array_equal(Xall[:, 4:8], X4)
+    for lo, hi in ((4, 8), (0, 16), (8, 16), (3, 4), (5, 30)):  # the 4-, 16- and 32-column kernels, full and ragged blocks
+        Xp = F.solve_inplace(ctx.from_host(B[:, lo:hi])).get()
+        assert np.array_equal(Xall[:, lo:hi], Xp), (lo, hi)
     A2 = A + sparse.identity(A.shape[0]) * 0.5
     F.refactor(A2.tocsr())
     X = F.solve_inplace(ctx.from_host(B)).get()
