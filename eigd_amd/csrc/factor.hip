@@ -54,6 +54,7 @@ struct FrontArrays {
   int nslot;            // carry planes a parent reads (forward sweep): V is nslot (+1 scratch) planes of vrows rows
   int64_t vrows;
   const int* v_src;     // per row of V: the row of the caller's block it holds (own rows), -1 for border rows
+  const int* cmask;     // per row of V: bit s set = carry plane s holds a child's contribution on this row
   const int* bout;      // per border entry (bptr): its row in the caller's block
   double* sgn;          // +-1 per (permuted) column: A = L S L^T with S = diag(sgn); all +1 for a positive definite matrix
   const double* zero;   // one 0.0 and ...
@@ -1168,9 +1169,12 @@ __global__ __launch_bounds__(128) void fwd_thin_kernel(FrontArrays fa, const WgR
   // v1 = alpha * X[own rows] + carries, as B operands: lane (k, n) holds v1[4 s + k][16 nb + n]
   double b[NKS][NB];
   {
-    int xi[NKS];
+    int xi[NKS], mo[NKS];  // planes no child wrote on a row are not read (mo: which ones did)
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) xi[s] = *((4 * s + lk < ns) ? fa.v_src + vbase + 4 * s + lk : fa.neg1);
+    for (int s = 0; s < NKS; ++s) {
+      xi[s] = *((4 * s + lk < ns) ? fa.v_src + vbase + 4 * s + lk : fa.neg1);
+      mo[s] = (NSL > 0) ? *((4 * s + lk < ns && nslot > 0) ? fa.cmask + vbase + 4 * s + lk : reinterpret_cast<const int*>(fa.zero)) : 0;
+    }
 #pragma unroll
     for (int s = 0; s < NKS; ++s)
 #pragma unroll
@@ -1180,7 +1184,7 @@ __global__ __launch_bounds__(128) void fwd_thin_kernel(FrontArrays fa, const WgR
         double v = alpha * *(ok ? X + static_cast<int64_t>(xi[s]) * ldx + n : fa.zero);
         const double* cp = V + (vbase + o) * KB + n;
 #pragma unroll
-        for (int sl = 0; sl < NSL; ++sl) v += *((ok && sl < nslot) ? cp + sl * vslot : fa.zero);
+        for (int sl = 0; sl < NSL; ++sl) v += *((ok && ((mo[s] >> sl) & 1)) ? cp + sl * vslot : fa.zero);
         b[s][nb] = v;
       }
   }
@@ -1188,6 +1192,13 @@ __global__ __launch_bounds__(128) void fwd_thin_kernel(FrontArrays fa, const WgR
   const double* Tf = Tb + w.toff;
   const double* Ff = F + w.foff;
   const int nrb = (d + 15) >> 4;
+  // the plane masks of all rows, lane by lane (fronts of up to 384 rows): read with ds_bpermute in the row blocks, so
+  // that their carry loads do not wait for a mask load of their own
+  const bool mreg = NSL > 0 && nslot > 0 && d <= 384;
+  int M[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q)
+    M[q] = (NSL > 0) ? *((mreg && 64 * q + lane < d) ? fa.cmask + vbase + 64 * q + lane : reinterpret_cast<const int*>(fa.zero)) : 0;
   for (int rb = wave; rb < nrb; rb += 2) {
     const int r = 16 * rb + li;  // the row this lane feeds as A operand
     double a[NKS];
@@ -1198,21 +1209,36 @@ __global__ __launch_bounds__(128) void fwd_thin_kernel(FrontArrays fa, const WgR
       a[s] = *((o < ns && r < d) ? p : fa.zero);
     }
     // what the results meet: lane (reg, nb) <-> row 16 rb + lk + 4 reg, column 16 nb + li
-    int di[4];
+    int di[4], mk[4];
     double sg[4], cg[4][NB];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int ro = 16 * rb + lk + 4 * reg;
       const bool border = ro >= ns && ro < d;
       di[reg] = *(border ? fa.rel + w.bptr + (ro - ns) : fa.neg1);
+      mk[reg] = (NSL > 0) ? *((border && nslot > 0 && !mreg) ? fa.cmask + vbase + ro : reinterpret_cast<const int*>(fa.zero)) : 0;
       sg[reg] = *((ro < ns) ? fa.sgn + w.c0 + ro : fa.zero);
+    }
+    if (NSL > 0 && mreg) {
+      const int q = rb >> 2;  // the row block's rows sit in one of the six registers
+      const int Mq = (q == 0) ? M[0] : (q == 1) ? M[1] : (q == 2) ? M[2] : (q == 3) ? M[3] : (q == 4) ? M[4] : M[5];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ro = 16 * rb + lk + 4 * reg;
+        const int m = __shfl(Mq, ro & 63);
+        mk[reg] = (ro >= ns && ro < d) ? m : 0;
+      }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int ro = 16 * rb + lk + 4 * reg;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int n = 16 * nb + li;
         const double* cp = V + (vbase + ro) * KB + n;
         double v = 0.0;
 #pragma unroll
-        for (int sl = 0; sl < NSL; ++sl) v += *((border && n < kb && sl < nslot) ? cp + sl * vslot : fa.zero);
+        for (int sl = 0; sl < NSL; ++sl) v += *((n < kb && ((mk[reg] >> sl) & 1)) ? cp + sl * vslot : fa.zero);
         cg[reg][nb] = v;
       }
     }
@@ -1398,6 +1424,7 @@ struct eigd_factor {
   int n_tri = 0, n_m21 = 0;
   int64_t *d_a_src = nullptr, *d_a_dst = nullptr;
   int* d_v_src = nullptr;
+  int* d_cmask = nullptr;
   double *d_data = nullptr, *d_F = nullptr, *d_Inv = nullptr, *d_V = nullptr, *d_Y = nullptr, *d_sgn = nullptr;
   int n_negative = 0;
   int* d_flag = nullptr;
@@ -1420,6 +1447,7 @@ struct eigd_factor {
     a.nslot = nslot;
     a.vrows = v_rows;
     a.v_src = d_v_src;
+    a.cmask = d_cmask;
     a.bout = d_bout;
     a.sgn = d_sgn;
     a.zero = d_aux;
@@ -1767,7 +1795,7 @@ int eigd_factor_free(eigd_factor* f) {
   if (f->ctx && f->ctx->stream) (void)hipStreamSynchronize(f->ctx->stream);
   void* ptrs[] = {f->d_c0,        f->d_ns,          f->d_bs,         f->d_parent,   f->d_rel,   f->d_foff,
                   f->d_voff,      f->d_ioff,        f->d_bptr,       f->d_lvl_fronts, f->d_pref_chunks,
-                  f->d_pref_tiles, f->d_cs_child,   f->d_a_src,      f->d_a_dst,    f->d_v_src, f->d_data,
+                  f->d_pref_tiles, f->d_cs_child,   f->d_a_src,      f->d_a_dst,    f->d_v_src, f->d_data,   f->d_cmask,
                   f->d_F,         f->d_Inv,         f->d_V,          f->d_Y,        f->d_flag,  f->d_fwd_wg,
                   f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_ov_dst,   f->d_ov_ptr, f->d_ov_src,
                   f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux,      f->d_bout,  f->d_tickets,
@@ -2007,7 +2035,8 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     f->h_thin_bwd.assign(static_cast<size_t>(s.nlevels), 0);
     for (int l = 0; l < s.nlevels; ++l) {
       const int nks = (mxns[l] <= 16) ? 4 : (mxns[l] <= 32) ? 8 : 16;
-      if (mxns[l] > 0 && mxns[l] <= thin_fwd) f->h_thin_fwd[l] = nks;
+      // (with carries to gather, the 16-step forward variant needs 244 VGPRs: those levels stay with the tile kernels)
+      if (mxns[l] > 0 && mxns[l] <= (f->h_lvl_leaf[l] ? thin_fwd : std::min(thin_fwd, 32))) f->h_thin_fwd[l] = nks;
       if (mxns[l] > 0 && mxns[l] <= thin_bwd && mxbs[l] <= 320) f->h_thin_bwd[l] = nks;
     }
   }
@@ -2065,6 +2094,19 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   UP(d_a_src, s.a_src)
   UP(d_a_dst, s.a_dst)
   UP(d_v_src, s.v_src)
+  {
+    // which carry planes hold a contribution on which row: child number q of a front writes plane q at the parent's
+    // rows rel(border); the summed surplus children arrive in plane nslot - 1
+    std::vector<int> cmask(static_cast<size_t>(s.sumd), 0);
+    for (int c = 0; c < nf; ++c) {
+      const int p = s.f_parent[c];
+      if (p < 0 || s.f_bs[c] == 0) continue;
+      const int bit = (child_no[c] >= kMaxS) ? nslot - 1 : child_no[c];
+      const int64_t b0 = s.f_bptr[c];
+      for (int i = 0; i < s.f_bs[c]; ++i) cmask[static_cast<size_t>(s.f_voff[p] + s.rel[b0 + i])] |= 1 << bit;
+    }
+    UP(d_cmask, cmask)
+  }
 #undef UP
   int64_t maxsrc = 0;
   for (int64_t e : s.a_src) maxsrc = std::max(maxsrc, e);
