@@ -1267,44 +1267,49 @@ __global__ __launch_bounds__(128) void fwd_thin_kernel(FrontArrays fa, const WgR
   }
 }
 
-// backward: wave = (front, block of 16 own columns); K = all d rows of the front in chunks of 32, from the transposed
-// copy Ft (row r of [T; M21] at r * ns).  The border rows of the caller's block are found through bout, which the
-// wave holds lane by lane (bs <= 320) and reads with ds_bpermute: no dependent index round per chunk.
-template <int KB>
+// backward: wave = front (all NOB blocks of 16 own columns: the gathered rows are loaded once); K = all d rows of the
+// front in chunks of 4 CH, from the transposed copy Ft (row r of [T; M21] at r * ns: a K-step reads whole rows).  The
+// border rows of the caller's block are found through bout, which the wave holds lane by lane (bs <= 320) and reads
+// with ds_bpermute: no dependent index round per chunk.
+template <int KB, int NOB, int CH>
 __global__ __launch_bounds__(64) void bwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
                                                       const double* __restrict__ Ft, const double* __restrict__ Y,
                                                       double* Out, int ldo, int kb) {
   constexpr int NB = KB / 16;
   const WgRec w = recs[blockIdx.x];
-  const int ob = blockIdx.y;
   const int ns = w.ns, bs = w.bs, d = ns + bs;
-  if (16 * ob >= ns) return;
   const int lane = threadIdx.x;
   const int li = lane & 15, lk = lane >> 4;
   const int64_t vbase = w.voff;
   const int* __restrict__ bout = fa.bout + w.bptr;
   const double* Fp = Ft + w.ftoff;
-  const int o = 16 * ob + li;
-  const bool ook = o < ns;
   int I[5];
 #pragma unroll
   for (int q = 0; q < 5; ++q) I[q] = *((64 * q + lane < bs) ? bout + 64 * q + lane : fa.neg1);
-  int oi[4];
+  int oi[NOB][4];
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const int oo = 16 * ob + lk + 4 * reg;
-    oi[reg] = *((oo < ns) ? fa.v_src + vbase + oo : fa.neg1);
-  }
-  double4_t c[NB];
+  for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) c[nb] = double4_t{0.0, 0.0, 0.0, 0.0};
-  const int nchunk = (d + 31) >> 5;
+    for (int reg = 0; reg < 4; ++reg) {
+      const int oo = 16 * ob + lk + 4 * reg;
+      oi[ob][reg] = *((oo < ns) ? fa.v_src + vbase + oo : fa.neg1);
+    }
+  double4_t c[NOB][NB];
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) c[ob][nb] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int nchunk = (d + 4 * CH - 1) / (4 * CH);
   for (int ch = 0; ch < nchunk; ++ch) {
-    double a[8], b[8][NB];
+    double a[CH][NOB], b[CH][NB];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int k = 32 * ch + 4 * s + lk;
-      a[s] = *((k < d && ook) ? Fp + static_cast<int64_t>(k) * ns + o : fa.zero);
+    for (int s = 0; s < CH; ++s) {
+      const int k = 4 * CH * ch + 4 * s + lk;
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        const int o = 16 * ob + li;
+        a[s][ob] = *((k < d && o < ns) ? Fp + static_cast<int64_t>(k) * ns + o : fa.zero);
+      }
       const int e = k - ns;  // border entry
       const int r0 = __shfl(I[0], e & 63), r1 = __shfl(I[1], e & 63), r2 = __shfl(I[2], e & 63), r3 = __shfl(I[3], e & 63);
       const int r4 = __shfl(I[4], e & 63);
@@ -1319,18 +1324,23 @@ __global__ __launch_bounds__(64) void bwd_thin_kernel(FrontArrays fa, const WgRe
       }
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < CH; ++s)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) c[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s][nb], c[nb], 0, 0, 0);
+      for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          c[ob][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][ob], b[s][nb], c[ob][nb], 0, 0, 0);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg)
+  for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int n = 16 * nb + li;
-      if (oi[reg] >= 0 && n < kb) Out[static_cast<int64_t>(oi[reg]) * ldo + n] = c[nb][reg];
-    }
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = 16 * nb + li;
+        if (oi[ob][reg] >= 0 && n < kb) Out[static_cast<int64_t>(oi[ob][reg]) * ldo + n] = c[ob][nb][reg];
+      }
 }
 
 // Ft(r, o) = [T; M21](r, o), row-major d x ns per front: 64 x 64 tiles through LDS
@@ -1685,8 +1695,14 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
       EIGD_LAUNCH_CHECK();
     } else if (thin) {
       if constexpr (KPT >= 4) {
-        hipLaunchKernelGGL(bwd_thin_kernel<KB>, dim3(nwave, f->h_thin_bwd[l] / 4), dim3(64), 0, st, fa,
-                           f->d_wave_wg + f->h_wave_ptr[l], f->d_Ft, wY, dX, ldx, kb);
+        const WgRec* recs = f->d_wave_wg + f->h_wave_ptr[l];
+        const int nks = f->h_thin_bwd[l];
+        if (nks == 4)
+          hipLaunchKernelGGL((bwd_thin_kernel<KB, 1, 8>), dim3(nwave), dim3(64), 0, st, fa, recs, f->d_Ft, wY, dX, ldx, kb);
+        else if (nks == 8)
+          hipLaunchKernelGGL((bwd_thin_kernel<KB, 2, 8>), dim3(nwave), dim3(64), 0, st, fa, recs, f->d_Ft, wY, dX, ldx, kb);
+        else
+          hipLaunchKernelGGL((bwd_thin_kernel<KB, 4, 4>), dim3(nwave), dim3(64), 0, st, fa, recs, f->d_Ft, wY, dX, ldx, kb);
         EIGD_LAUNCH_CHECK();
       }
     } else if (nsb > 0) {  // single-column-tile fronts: LDS tiles as tall as the level needs
@@ -2022,9 +2038,8 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   f->h_bwd_kd.assign(static_cast<size_t>(s.nlevels), 8);
   {
     // levels for the wave-per-block kernels: every single-column-tile front has at most EIGD_THIN_NS_FWD / _BWD own
-    // columns (forward: all of them pay off; backward: up to 32, beyond that the waves of a front re-read too much)
-    // and a border of <= 320
-    const int thin_fwd = std::min(TW, env_int("EIGD_THIN_NS_FWD", TW)), thin_bwd = std::min(TW, env_int("EIGD_THIN_NS_BWD", 32));
+    // columns and (backward) a border of <= 320
+    const int thin_fwd = std::min(TW, env_int("EIGD_THIN_NS_FWD", TW)), thin_bwd = std::min(TW, env_int("EIGD_THIN_NS_BWD", TW));
     std::vector<int> mxns(static_cast<size_t>(s.nlevels), 0), mxbs(static_cast<size_t>(s.nlevels), 0);
     for (int q = 0; q < nf; ++q) {
       if (s.f_ns[q] > TW) continue;
@@ -2037,7 +2052,10 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
       const int nks = (mxns[l] <= 16) ? 4 : (mxns[l] <= 32) ? 8 : 16;
       // (with carries to gather, the 16-step forward variant needs 244 VGPRs: those levels stay with the tile kernels)
       if (mxns[l] > 0 && mxns[l] <= (f->h_lvl_leaf[l] ? thin_fwd : std::min(thin_fwd, 32))) f->h_thin_fwd[l] = nks;
-      if (mxns[l] > 0 && mxns[l] <= thin_bwd && mxbs[l] <= 320) f->h_thin_bwd[l] = nks;
+      // (backward: one wave per front -- with more than 32 own columns only where the level has fronts enough to
+      // fill the chip that way)
+      const int nfl = h_wave_ptr[l + 1] - h_wave_ptr[l];
+      if (mxns[l] > 0 && mxns[l] <= thin_bwd && mxbs[l] <= 320 && (nks < 16 || nfl >= 1024)) f->h_thin_bwd[l] = nks;
     }
   }
   for (int q = 0; q < nf; ++q) {
