@@ -258,6 +258,47 @@ def test_fronts_with_many_children_use_the_surplus_plane(ctx, nb, k):
     assert relerr(X1, ref[:, :1]) < 1e-12
 
 
+def lap3d(m):
+    eye = sparse.identity(m)
+    T = sparse.diags([-1.0, 2.2, -1.0], [-1, 0, 1], shape=(m, m))
+    A = sparse.kron(sparse.kron(T, eye), eye) + sparse.kron(sparse.kron(eye, T), eye) + sparse.kron(sparse.kron(eye, eye), T)
+    A = A.tocsr()
+    A.sort_indices()
+    return A
+
+
+def hub_matrix(nx, ny, hub, seed=0):
+    """a 2-D grid whose every node is coupled to most of a dense hub block: thin fronts with borders of several hundred rows"""
+    rng = np.random.default_rng(seed)
+    A = grid_matrix(nx, ny, 1, seed=seed)
+    C = sparse.random(A.shape[0], hub, density=0.6, random_state=seed, data_rvs=lambda k: rng.uniform(-0.01, 0.01, k))
+    M = sparse.bmat([[A, C], [C.T, sparse.identity(hub) * 5.0]]).tocsr()
+    M.sort_indices()
+    return M
+
+
+@pytest.mark.parametrize("case", ["lap3d", "hub"])
+def test_single_tile_fronts_with_long_borders(ctx, case):
+    """3-D and hub problems: single-column-tile fronts whose borders exceed what the wave kernels hold in registers
+    (bs > 320: tile kernels; d > 384: plane masks loaded per row block), levels that mix single- and multi-tile fronts"""
+    from eigd_amd.device import Factor, Symbolic
+
+    A = lap3d(24) if case == "lap3d" else hub_matrix(40, 8, 420)
+    sym = Symbolic(A, leaf_size=16 if case == "lap3d" else 24)
+    ns, bs = sym.array("f_ns"), sym.array("f_bs")
+    assert ((ns <= 64) & (bs > 320)).any() and ((ns <= 32) & (ns + bs > 384)).any() == (case == "hub")
+    F = Factor(ctx, A, symbolic=sym)
+    lu = splu(A.tocsc())
+    rng = np.random.default_rng(5)
+    for k in (3, 12, 32):
+        B = rng.normal(size=(A.shape[0], k))
+        X = F.solve_inplace(ctx.from_host(B)).get()
+        assert relerr(X, lu.solve(B)) < 1e-11, (case, k)
+    Xall = F.solve_inplace(ctx.from_host(B)).get()
+    Xp = F.solve_inplace(ctx.from_host(B[:, 8:12])).get()
+    assert np.array_equal(Xall[:, 8:12], Xp)
+
+
 def test_fem_like_ill_conditioned_factor(ctx):
     """Q4 plate-like stencil with a 1e6 stiffness contrast (SIMP void/solid), solved to SuperLU accuracy"""
     from eigd_amd.device import Factor
