@@ -69,6 +69,29 @@ def test_spmm_matches_scipy(ctx, k):
     assert np.array_equal(Y, A @ X)
 
 
+@pytest.mark.parametrize("k", [5, 32])
+def test_spmm_tiles_with_many_nonzeros_and_mixed_rows(ctx, k):
+    """banded rows (41 non-zeros each: a 32-row tile holds more than the 1024 non-zeros staged through LDS), a few
+    empty rows and one dense row in between: the tiled kernel's direct path and the fallback, bit-identical to scipy"""
+    from eigd_amd.device import CSRMatrix
+
+    n = 5003
+    rng = np.random.default_rng(k)
+    offs = list(range(-20, 21))
+    A = sparse.diags([rng.uniform(-1.0, 1.0, n - abs(o)) for o in offs], offs, shape=(n, n)).tolil()
+    A[100:103, :] = 0.0
+    A = A.tocsr()
+    A.eliminate_zeros()
+    A.sort_indices()
+    X = rng.normal(size=(n, k))
+    assert np.array_equal(CSRMatrix(ctx, A).apply(ctx.from_host(X)).get(), A @ X)
+    B = A.tolil()
+    B[2500, :] = rng.uniform(-1.0, 1.0, n)  # one full row: the column list of its tile no longer fits LDS
+    B = B.tocsr()
+    B.sort_indices()
+    assert np.array_equal(CSRMatrix(ctx, B).apply(ctx.from_host(X)).get(), B @ X)
+
+
 @pytest.mark.parametrize("n,k", [(1, 1), (257, 1), (10007, 5), (50000, 32), (4099, 64)])
 def test_column_kernels(ctx, n, k):
     rng = np.random.default_rng(n + k)
