@@ -39,6 +39,104 @@ def ritz_to_eigs(theta, sigma, mode):
     return lam, np.argsort(-1.0 / lam)
 
 
+def complex_step_eigh(T):
+    """
+    eigh of the reduced matrix; a complex T carries forward derivatives in its imaginary part (reference ``_eigh``,
+    1387-1414): lam_i + i q_i^T dT q_i and q_i + i sum_{j: lam_j != lam_i} q_j (q_j^T dT q_i) / (lam_i - lam_j).
+    """
+    if not np.issubdtype(T.dtype, np.complexfloating):
+        return np.linalg.eigh(T)
+    lam, Q = np.linalg.eigh(T.real)
+    D = Q.T @ T.imag @ Q
+    gap = lam[None, :] - lam[:, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        Cf = np.where(gap == 0.0, 0.0, D / gap)
+    return lam + 1j * np.diag(D), Q + 1j * (Q @ Cf)
+
+
+class _DualLanczosDevice:
+    """
+    Lanczos basis in complex-step (dual-number) arithmetic on the device: every vector is a pair of real n-vectors
+    (value, forward derivative), every product drops the term with two derivative factors (1e-40 relative at the
+    reference's step of 1e-20, far below rounding), nothing is conjugated (reference inner product ``y.dot(B @ x)``,
+    1503).  Real kernels only: B = Br + i Bi is two CSR matrices, the factor an SpLuOperator built on a complex matrix.
+    """
+
+    def __init__(self, ctx, Br, Bi, factor, n, nvec):
+        from .operators import DeviceOperator
+
+        self.ctx, self.n, self.fac = ctx, n, factor
+        self.Br, self.Bi = DeviceOperator(ctx, Br), DeviceOperator(ctx, Bi)
+        self.Vr, self.Vi = ctx.stack(nvec, n, 1), ctx.stack(nvec, n, 1)
+        self.BVr, self.BVi = ctx.stack(nvec, n, 1), ctx.stack(nvec, n, 1)
+        self.wr, self.wi, self.t = ctx.empty(n, 1), ctx.empty(n, 1), ctx.empty(n, 1)
+
+    def apply_B(self, vr, vi, wr, wi):
+        """(wr + i wi) = (Br + i Bi)(vr + i vi)"""
+        self.Br.apply(vr, wr)
+        self.Br.apply(vi, wi)
+        self.Bi.apply(vr, self.t)
+        wi.assign_lincomb([(1.0, wi), (1.0, self.t)])
+
+    def normalize_into(self, vr, vi, j):
+        """V[j] = v / sqrt(v . B v), BV[j] = B V[j]; returns the complex norm"""
+        self.apply_B(vr, vi, self.wr, self.wi)
+        re = float(vr.coldot(self.wr)[0])
+        im = float(vr.coldot(self.wi)[0]) + float(vi.coldot(self.wr)[0])
+        br = np.sqrt(re)
+        beta = complex(br, 0.5 * im / br)
+        cr, ci = 1.0 / br, -beta.imag / (br * br)  # 1 / beta
+        self.Vr[j].assign_lincomb([(cr, vr)])
+        self.Vi[j].assign_lincomb([(cr, vi), (ci, vr)])
+        self.BVr[j].assign_lincomb([(cr, self.wr)])
+        self.BVi[j].assign_lincomb([(cr, self.wi), (ci, self.wr)])
+        return beta
+
+    def project_out(self, vr, vi, j0, ns):
+        """v <- v - V[:, j0:j0+ns] (BV^T v), twice (as the real path); returns the summed complex coefficients"""
+        tot = np.zeros(ns, dtype=complex)
+        for _ in range(2):
+            hr = self.BVr.dot(vr, ns=ns, j0=j0)
+            hi = self.BVr.dot(vi, ns=ns, j0=j0) + self.BVi.dot(vr, ns=ns, j0=j0)
+            self.Vr.axpy_into(vi, hi, alpha=-1.0, j0=j0)
+            self.Vi.axpy_into(vi, hr, alpha=-1.0, j0=j0)
+            self.Vr.axpy_into(vr, hr, alpha=-1.0, j0=j0)
+            tot += hr[:, 0] + 1j * hi[:, 0]
+        return tot
+
+    def apply_op(self, j, vr, vi):
+        """v = factor(B V[j])"""
+        vr.copy_from(self.BVr[j])
+        vi.copy_from(self.BVi[j])
+        self.fac.solve_device_dual(vr, vi)
+
+    def axpy_basis(self, vr, vi, coef, j):
+        """v += coef * V[j] for a complex scalar"""
+        vi.assign_lincomb([(1.0, vi), (coef.real, self.Vi[j]), (coef.imag, self.Vr[j])])
+        vr.assign_lincomb([(1.0, vr), (coef.real, self.Vr[j])])
+
+    def times(self, Y, m):
+        """V[:, :m] @ Y for a complex m x q matrix -> host complex array"""
+        Y = np.asarray(Y, dtype=complex)
+        q = Y.shape[1]
+        outr, outi, tmp = self.ctx.empty(self.n, q), self.ctx.empty(self.n, q), self.ctx.empty(self.n, q)
+        self.Vr.times_into(outr, np.ascontiguousarray(Y.real), ns=m)
+        self.Vr.times_into(outi, np.ascontiguousarray(Y.imag), ns=m)
+        self.Vi.times_into(tmp, np.ascontiguousarray(Y.real), ns=m)
+        outi.assign_lincomb([(1.0, outi), (1.0, tmp)])
+        return outr.get() + 1j * outi.get()
+
+    def basis_to_host(self, m):
+        from ._ffi import call, hptr
+
+        out = []
+        for st in (self.Vr, self.Vi):
+            Vt = np.empty((m, self.n))
+            call("eigd_d2h", self.ctx.h, hptr(Vt), st.ptr, 8 * self.n * m)
+            out.append(Vt.T)
+        return out[0] + 1j * out[1]
+
+
 def _check_shapes(A, B, factor):
     n = A.shape[1]
     if A.shape != (n, n):
@@ -307,8 +405,8 @@ class BasicLanczos(_AdjointAPI):
 
     def solve(self, A, B, factor, sigma):
         n = _check_shapes(A, B, factor)
-        if np.issubdtype(np.dtype(A.dtype), np.complexfloating):
-            raise TypeError("the MI355X path is real (float64); the complex-step check runs on the CPU reference")
+        if np.issubdtype(np.dtype(A.dtype), np.complexfloating) or np.issubdtype(np.dtype(B.dtype), np.complexfloating):
+            return self._solve_complex_step(A, B, factor, sigma, n)
         self.factor = aslinearoperator(factor)
         self.B = aslinearoperator(B)
         self.A = aslinearoperator(A)
@@ -383,6 +481,108 @@ class BasicLanczos(_AdjointAPI):
         self._nV = self.m_max + 1
         self._V_host = None
         return self.lam0, self.Phi
+
+
+def _solve_complex_step(self, A, B, factor, sigma, n):
+    """
+    The reference's complex-step evaluation (ref 1453-1650 with complex A, B and a complex SuperLU,
+    examples/buckling.py:1014-1023): the same recurrence in dual-number arithmetic on the device.  Eigenvalues,
+    eigenvectors and Lanczos coefficients come back complex, imaginary part = step * forward derivative.  Forward
+    evaluation only, as in the reference (its adjoint stage is never run on complex data).
+    """
+    from scipy import sparse
+
+    if not (isinstance(factor, SpLuOperator) and factor._imag_dev is not None):
+        raise TypeError("the complex-step path needs an eigd_amd.SpLuOperator built on the complex shifted matrix")
+    if not sparse.issparse(B):
+        raise TypeError("the complex-step path needs B as a scipy sparse matrix")
+    Bc = sparse.csr_matrix(B).astype(np.complex128)
+    Bc.sort_indices()
+    Br = sparse.csr_matrix((Bc.data.real.copy(), Bc.indices, Bc.indptr), shape=Bc.shape)
+    Bi = sparse.csr_matrix((Bc.data.imag.copy(), Bc.indices, Bc.indptr), shape=Bc.shape)
+    self.factor, self.B, self.A, self.sigma = aslinearoperator(factor), aslinearoperator(B), aslinearoperator(A), sigma
+    ctx = self._ctx or factor.ctx
+    mm = self.m_max
+    dev = _DualLanczosDevice(ctx, Br, Bi, factor, n, mm + 1)
+    self._dev, self._prob = dev, None
+    self.alpha = np.zeros(mm, dtype=complex)
+    self.beta = np.zeros(mm, dtype=complex)
+
+    v0 = np.random.default_rng(12345).uniform(size=n, low=-1.0, high=1.0)  # ref 1514-1515
+    vr, vi = ctx.from_host(v0), ctx.zeros(n, 1)
+    dev.normalize_into(vr, vi, 0)
+
+    def reduced(m):  # ref 1416-1439 with the complex _eigh
+        T = np.diag(self.alpha[:m]) + np.diag(self.beta[: m - 1], 1) + np.diag(self.beta[: m - 1], -1)
+        theta, Y = complex_step_eigh(T)
+        lam, indices = ritz_to_eigs(theta, self.sigma, self.mode)
+        return theta, Y, T, lam, indices
+
+    Nchk = self.N if self.Ntarget is None else self.Ntarget
+    self.m = mm
+    Sr = Si = BSr = BSi = None
+    for i in range(1, mm + 1):
+        dev.apply_op(i - 1, vr, vi)                                        # ref 1524
+        if i > 1:
+            dev.axpy_basis(vr, vi, -self.beta[i - 2], i - 2)              # ref 1526
+        if self.ortho_type == "full":
+            h = dev.project_out(vr, vi, 0, i)                             # ref 1529-1534
+            self.alpha[i - 1] = h[i - 1]
+        else:
+            j0 = max(0, i - 2)                                             # ref 1563: the two previous vectors
+            h = dev.project_out(vr, vi, j0, i - j0)
+            self.alpha[i - 1] = h[-1]
+            if Sr is not None:                                             # ref 1571-1574
+                for _ in range(2):
+                    hr = BSr.tdot(vr)
+                    hi = BSr.tdot(vi) + BSi.tdot(vr)
+                    vi.add_product(Sr, hi, alpha=-1.0, beta=1.0)
+                    vi.add_product(Si, hr, alpha=-1.0, beta=1.0)
+                    vr.add_product(Sr, hr, alpha=-1.0, beta=1.0)
+        self.beta[i - 1] = dev.normalize_into(vr, vi, i)                   # ref 1537-1538
+        if i >= 2:
+            theta, Y, T, lam, indices = reduced(i)
+            Y0 = Y[:, indices]
+            if self._converged(self.beta[i - 1], Y0[i - 1, :], Nchk, self.tol):
+                self.m = i
+                break
+            if self.ortho_type == "selective":                             # ref 1596-1605
+                errs = np.abs(self.beta[i - 1] * Y0[i - 1, :])
+                conv = [j for j in range(i) if errs[j] < np.sqrt(self.tol)]
+                if conv:
+                    S = dev.times(Y0[:, conv], i)
+                    Sr, Si = ctx.from_host(np.ascontiguousarray(S.real)), ctx.from_host(np.ascontiguousarray(S.imag))
+                    BSr, BSi = ctx.empty(n, len(conv)), ctx.empty(n, len(conv))
+                    tmp = ctx.empty(n, len(conv))
+                    dev.Br.apply(Sr, BSr)
+                    dev.Br.apply(Si, BSi)
+                    dev.Bi.apply(Sr, tmp)
+                    BSi.assign_lincomb([(1.0, BSi), (1.0, tmp)])
+                else:
+                    Sr = Si = BSr = BSi = None
+
+    self.theta, self.Y, self.T, self.lam, self.indices = reduced(self.m)
+    if self.Ntarget is not None:                                           # ref 1615-1625
+        self.N = self.Ntarget
+        while self.N < self.m and _is_close(self.lam[self.indices[self.N - 1]].real, self.lam[self.indices[self.N]].real,
+                                            self.eig_atol):
+            self.N += 1
+    elif _is_close(self.lam[self.indices[self.N - 1]].real, self.lam[self.indices[self.N]].real, self.eig_atol):
+        warnings.warn(f"BasicLanczos: Ritz values {self.N} and {self.N+1} are numerically repeated.")
+    sel = self.indices[: self.N]
+    self.lam0 = self.lam[sel]
+    self.Y0 = self.Y[:, sel]
+    self.eig_res = np.abs(self.beta[-1] * self.Y0[-1, :])                  # ref 1640-1645
+    self.fail = bool(np.any(self.eig_res > self.tol))
+    self.Phi = dev.times(self.Y0, self.m)                                  # ref 1648
+    self._phi_token = self.Phi
+    self._m = self.m
+    self._nV = self.m_max + 1
+    self._V_host = None
+    return self.lam0, self.Phi
+
+
+BasicLanczos._solve_complex_step = _solve_complex_step
 
 
 class IRAM(_AdjointAPI):

@@ -565,6 +565,20 @@ def sibk(
 # --------------------------------------------------------------------------
 # eigen-solvers
 # --------------------------------------------------------------------------
+def complex_step_eigh(T):
+    """eigh; for a complex T the imaginary part is a forward derivative of the real symmetric problem (ref 1387-1414):
+    d(lam_i) = q_i^T dT q_i, d(q_i) = sum_{j != i, lam_j != lam_i} q_j (q_j^T dT q_i) / (lam_i - lam_j)."""
+    if not np.issubdtype(T.dtype, np.complexfloating):
+        return np.linalg.eigh(T)
+    lam, Q = np.linalg.eigh(T.real)
+    D = Q.T @ T.imag @ Q
+    w = lam + 1j * np.diag(D)
+    gap = lam[None, :] - lam[:, None]  # gap[i, j] = lam[j] - lam[i]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        C = np.where(gap == 0.0, 0.0, D / gap)
+    return w, Q + 1j * (Q @ C)
+
+
 def ritz_to_eigs(theta, sigma, mode):
     """Undo the spectral transformation and give the sort order (ref 1432-1437, 1960-1965)."""
     if mode == "normal":
@@ -621,7 +635,9 @@ class _AdjointMixin:
 
 
 class BasicLanczos(_AdjointMixin):
-    """Un-restarted shift-invert Lanczos with B-orthogonalisation (ref 1331-1650). Real dtype only."""
+    """Un-restarted shift-invert Lanczos with B-orthogonalisation (ref 1331-1650).  Complex matrices follow the
+    reference's complex-step semantics: products are not conjugated and the reduced problem treats imaginary parts
+    as forward derivatives (``_eigh``, ref 1387-1414)."""
 
     def __init__(self, N=10, m=60, tol=1e-14, Ntarget=None, eig_atol=1e-5, mode="normal", ortho_type="full"):
         self.N, self.m_max, self.tol, self.Ntarget = N, m, tol, Ntarget
@@ -644,7 +660,7 @@ class BasicLanczos(_AdjointMixin):
     def _reduced(self, m):
         """eigh of the leading m x m tridiagonal + sort (ref 1416-1439)."""
         T = np.diag(self.alpha[:m]) + np.diag(self.beta[: m - 1], 1) + np.diag(self.beta[: m - 1], -1)
-        theta, Y = np.linalg.eigh(T)
+        theta, Y = complex_step_eigh(T)
         lam, indices = ritz_to_eigs(theta, self.sigma, self.mode)
         return theta, Y, T, lam, indices
 
@@ -675,9 +691,10 @@ class BasicLanczos(_AdjointMixin):
         inner = lambda x, y: y.dot(Bm @ x)  # ref 1503: one SpMV per inner product
 
         mm = self.m_max
-        self.alpha = np.zeros(mm)
-        self.beta = np.zeros(mm)
-        self.V = np.zeros((n, mm + 1))
+        dtype = A.dtype  # ref 1483: complex matrices switch every array to complex
+        self.alpha = np.zeros(mm, dtype=dtype)
+        self.beta = np.zeros(mm, dtype=dtype)
+        self.V = np.zeros((n, mm + 1), dtype=dtype)
         V = self.V
         V[:, 0] = np.random.default_rng(12345).uniform(size=n, low=-1.0, high=1.0)
         V[:, 0] /= np.sqrt(inner(V[:, 0], V[:, 0]))
@@ -716,10 +733,10 @@ class BasicLanczos(_AdjointMixin):
         if self.Ntarget is not None:  # ref 1615-1625
             self.N = self.Ntarget
             while self.N < self.m and is_close(
-                self.lam[self.indices[self.N - 1]], self.lam[self.indices[self.N]], self.eig_atol
+                self.lam[self.indices[self.N - 1]].real, self.lam[self.indices[self.N]].real, self.eig_atol
             ):
                 self.N += 1
-        elif is_close(self.lam[self.indices[self.N - 1]], self.lam[self.indices[self.N]], self.eig_atol):
+        elif is_close(self.lam[self.indices[self.N - 1]].real, self.lam[self.indices[self.N]].real, self.eig_atol):
             warnings.warn(f"BasicLanczos: Ritz values {self.N} and {self.N+1} are numerically repeated.")
         sel = self.indices[: self.N]
         self.lam0 = self.lam[sel]

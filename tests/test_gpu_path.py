@@ -712,3 +712,48 @@ def test_eigsh_mod_function_returns_the_lanczos_relation():
     assert eg.eigsh_mod(K, k=6, M=M, sigma=sigma, OPinv=fac, ncv=40, return_eigenvectors=False).shape == (6,)
     with pytest.raises(ValueError):
         eg.eigsh_mod(K, k=6, M=M)                                       # not the shift-invert path
+
+
+def test_g6_complex_step_point_on_the_device():
+    """the reference's complex-step evaluation of C1 (complex K/G, complex SuperLU, BasicLanczos with its
+    complex _eigh) in dual-number arithmetic on the device, against the reference's own numbers and the oracle"""
+    import eigd_amd as eg
+    from scipy.sparse.linalg import splu
+    from test_oracle_golden import _complex_csr, check_complex_step_solution
+
+    g = load_golden("g6_buckling50_complexstep")
+    K, G = _complex_csr(g, "K"), _complex_csr(g, "G")
+    sigma = float(g["sigma"])
+    mat = (K + sigma * G).tocsc()
+    fac = eg.SpLuOperator(mat)
+    assert fac.dtype == np.complex128
+    # the operator itself against complex SuperLU (reference 11-23): vector, block and real right-hand sides
+    lu = splu(mat)
+    rng = np.random.default_rng(0)
+    b = rng.normal(size=mat.shape[0]) + 1e-20j * rng.normal(size=mat.shape[0])
+    x, xr = fac(b), lu.solve(b)
+    assert relerr(x.real, xr.real) < 1e-11 and relerr(x.imag, xr.imag) < 1e-9
+    Bk = rng.normal(size=(mat.shape[0], 3))
+    X, Xr = fac(Bk), lu.solve(Bk.astype(complex))
+    assert relerr(X.real, Xr.real) < 1e-11 and relerr(X.imag, Xr.imag) < 1e-9
+    from oracle import eigd_oracle as orc
+
+    for ortho in ("full", "selective"):
+        fac.count = 0
+        tol = 0.0 if ortho == "full" else 1e-12  # (selective reorthogonalisation needs a tolerance to select by)
+        s = eg.BasicLanczos(N=6, m=60, tol=tol, mode="buckling", ortho_type=ortho)
+        lam, Phi = s.solve(G, K, fac, sigma)
+        assert lam.dtype == np.complex128 and Phi.dtype == np.complex128 and fac.count == s.m
+        if ortho == "selective":
+            so = orc.BasicLanczos(N=6, m=60, tol=tol, mode="buckling", ortho_type=ortho)
+            so.solve(G, K, orc.SpLuOperator(mat), sigma)
+            assert abs(s.m - so.m) <= 1
+        if ortho == "full":
+            check_complex_step_solution(g, s)
+            assert np.abs(s.alpha - g["alpha"]).max() < 1e-8 * np.abs(g["alpha"]).max()
+            assert np.abs(s.V.T @ (K @ s.V[:, : s.m]) - np.eye(s.m + 1, s.m)).max() < 1e-9  # non-conjugated B-orthonormality
+        else:
+            assert np.abs(lam.real - g["lam"].real).max() < 1e-8 * np.abs(g["lam"].real).max()
+            assert np.abs(lam.imag - g["lam"].imag).max() < 1e-6 * np.abs(g["lam"].imag).max()
+    with pytest.raises(TypeError):
+        eg.IRAM(N=6, mode="buckling").solve(G, K, fac, sigma)          # ARPACK is real only (scipy raises the same)

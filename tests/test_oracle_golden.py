@@ -197,6 +197,47 @@ def test_iram_g1_buckling_eigs_and_adjoint():
     assert relerr(psi, g["psir"]) < 1e-8
 
 
+def _complex_csr(g, name):
+    from scipy import sparse
+
+    return sparse.csr_matrix((g[name + "_re"] + 1j * g[name + "_im"], g[name + "_indices"], g[name + "_indptr"]),
+                             shape=tuple(g[name + "_shape"]))
+
+
+def check_complex_step_solution(g, s):
+    """lam, Phi, alpha, beta of a complex-step BasicLanczos run against the reference's (G6); the imaginary parts are
+    step * derivative: compared relative to their own size"""
+    dh = float(g["dh"])
+    assert s.m == int(g["m"]) and s.N == int(g["N"])
+    assert np.abs(s.lam0.real - g["lam"].real).max() < 1e-10 * np.abs(g["lam"].real).max()
+    assert np.abs(s.lam0.imag - g["lam"].imag).max() < 1e-8 * np.abs(g["lam"].imag).max()
+    for q in range(s.N):
+        sg = np.sign(np.dot(s.Phi[:, q].real, g["Phi"][:, q].real))
+        assert relerr(sg * s.Phi[:, q].real, g["Phi"][:, q].real) < 1e-8, q
+        assert relerr(sg * s.Phi[:, q].imag, g["Phi"][:, q].imag) < 1e-6, q
+    # the reference's own use of the result: the tanh aggregate of examples/buckling.py:702-722 and its CS derivative
+    lam, Q = s.lam0, np.zeros((int(g["reduced"].max()) + 1 + 1, s.N), dtype=complex)
+    Q[g["reduced"]] = s.Phi
+    eta = np.tanh(100.0 * (lam - 0.0)) - np.tanh(100.0 * (lam - 50.0))
+    eta = eta / np.sum(eta)
+    node = int(g["node"])
+    h = sum(eta[i] * Q[node, i] * Q[node, i] for i in range(s.N))
+    assert abs(h.real - g["h"].real) < 1e-10 * abs(g["h"].real)
+    assert abs(h.imag / dh - float(g["cs"])) < 1e-7 * abs(float(g["cs"]))
+
+
+def test_basiclanczos_g6_complex_step():
+    """the oracle's complex-step semantics against the reference's own CS evaluation of C1"""
+    g = load_golden("g6_buckling50_complexstep")
+    K, G = _complex_csr(g, "K"), _complex_csr(g, "G")
+    sigma = float(g["sigma"])
+    factor = orc.SpLuOperator((K + sigma * G).tocsc())
+    s = orc.BasicLanczos(N=6, m=60, tol=0.0, mode="buckling")
+    s.solve(G, K, factor, sigma)
+    check_complex_step_solution(g, s)
+    assert np.abs(s.alpha - g["alpha"]).max() < 1e-9 * np.abs(g["alpha"]).max()
+
+
 def test_error_behaviour():
     with pytest.raises(ValueError):
         orc.BasicLanczos(mode="nope")

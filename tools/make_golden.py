@@ -318,6 +318,51 @@ def case_g5():
     save("g5_units", **f)
 
 
+# ---------------------------------------------------------------- G6 -------
+def case_g6():
+    """complex-step point of C1: the reference's own CS evaluation (buckling.py:1014-1023) on the 50x50
+    column -- design variables x + i*1e-20*p, complex K/G, complex SuperLU, BasicLanczos with its complex _eigh."""
+    import_reference()
+    import buckling
+
+    np.random.seed(0)
+    topo = buckling.make_model(
+        nx=50, ny=50, Lx=1.0, Ly=1.0, N=6, sigma=3.0, solver_type="BasicLanczos",
+        adjoint_method="sibk",
+        adjoint_options={"lanczos_guess": True, "update_guess": False, "bs_target": 1},
+        deriv_type="tensor",
+    )
+    node = (8 + 1) * 16 + 16
+    topo.initialize(store=True)
+    x0 = np.array(topo.x)
+    h0 = topo.get_eigenvector_aggregate(100.0, node, mode="tanh")
+    lam_real = np.array(topo.eig_solver.lam0)
+    pert = np.random.uniform(size=topo.x.shape)
+    dh = 1e-20
+    topo.x = np.array(x0).astype(complex)
+    topo.x.imag += dh * pert
+    topo.initialize()
+    h1 = topo.get_eigenvector_aggregate(100.0, node, mode="tanh")
+    s = topo.eig_solver
+    K, G = topo.Kr.tocsr(), topo.Gr.tocsr()
+    K.sort_indices()
+    G.sort_indices()
+    assert np.iscomplexobj(K.data) and np.iscomplexobj(G.data)
+    f = {}
+    for name, M in (("K", K), ("G", G)):
+        f.update({name + "_indptr": M.indptr.astype(np.int32), name + "_indices": M.indices.astype(np.int32),
+                  name + "_re": M.data.real.copy(), name + "_im": M.data.imag.copy(),
+                  name + "_shape": np.array(M.shape, dtype=np.int64)})
+    f.update(
+        sigma=np.float64(topo.sigma), dh=np.float64(dh), node=np.int64(node), reduced=np.asarray(topo.reduced, dtype=np.int64),
+        lam_real_point=lam_real, h_real_point=np.float64(np.real(h0)),
+        lam=s.lam0, Phi=s.Phi, alpha=s.alpha, beta=s.beta, m=np.int64(s.m), N=np.int64(s.N), theta=s.theta,
+        indices=np.asarray(s.indices, dtype=np.int64), Y=s.Y, eig_res=s.eig_res, h=np.complex128(h1),
+        cs=np.float64(h1.imag / dh),
+    )
+    save("g6_buckling50_complexstep", **f)
+
+
 CASES = {
     "g1_basic": lambda: case_g1("BasicLanczos"),
     "g1_iram": lambda: case_g1("IRAM"),
@@ -329,6 +374,7 @@ CASES = {
     "g4_basic": lambda: case_g4("BasicLanczos"),
     "g4_iram": lambda: case_g4("IRAM"),
     "g5": case_g5,
+    "g6": case_g6,
 }
 
 if __name__ == "__main__":
