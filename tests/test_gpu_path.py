@@ -757,3 +757,82 @@ def test_g6_complex_step_point_on_the_device():
             assert np.abs(lam.imag - g["lam"].imag).max() < 1e-6 * np.abs(g["lam"].imag).max()
     with pytest.raises(TypeError):
         eg.IRAM(N=6, mode="buckling").solve(G, K, fac, sigma)          # ARPACK is real only (scipy raises the same)
+
+
+def test_c3_full_size_properties():
+    """
+    The benchmark configuration itself (BASELINE configs[2]: 706 x 706 Q4 column, 998 284 dof) with 8 modes, through
+    size-independent properties: eigen-residuals and K-orthonormality, adjoint residuals, linearity of the adjoint
+    solve in the right-hand side, mode sharding (a rank's columns are the columns of the full solve) and the
+    total derivative against a central difference of the eigenvalue part.
+    """
+    import eigd_amd as eg
+    from eigd_amd.device import ElementBilinear, default_context
+    from eigd_amd.problems import BucklingColumn
+
+    ctx = default_context()
+    col = BucklingColumn(706, 706, Lx=1.0, Ly=1.0, seed=0)
+    K = col.stiffness()
+    n = K.shape[0]
+    assert n == 998284
+    Kfac = eg.SpLuOperator(K, ctx=ctx, check_symmetry=False, coords=col.dof_coords())
+    u = col.full_vector(Kfac(col.f[col.reduced]))
+    G = col.geometric_stiffness(u)
+    sigma = 1.0                                                            # BLF_1 = 1.83 for this column
+    fac = eg.SpLuOperator((K + sigma * G).tocsr(), ctx=ctx, symbolic=Kfac.symbolic, check_symmetry=False)
+    assert fac.negative_pivots == 0
+    del Kfac
+    N = 8
+    s = eg.IRAM(N=N, m=33, mode="buckling", ctx=ctx)
+    lam, Phi = s.solve(G, K, fac, sigma)
+    assert 1.5 < lam[0] < 2.2 and np.all(np.diff(lam) > 0)
+    R = K @ Phi + (G @ Phi) * lam                                          # (K + lam G) phi = 0
+    assert np.linalg.norm(R, axis=0).max() < 1e-9 * np.linalg.norm(K @ Phi, axis=0).max()
+    assert np.abs(Phi.T @ (K @ Phi) - np.eye(N)).max() < 1e-10
+    rng = np.random.default_rng(1)
+    P1, P2 = rng.uniform(size=(n, N)), rng.uniform(size=(n, N))
+    psi1, data1 = s.solve_adjoint(P1, method="sibk", rtol=1e-10, update_guess=False, bs_target=1)
+    res, _ = s.eval_adjoint_residual_norm(P1, psi1, b_ortho=False)
+    assert res.max() < 1e-8 * np.linalg.norm(P1, axis=0).max()
+    psi2, _ = s.solve_adjoint(P2, method="sibk", rtol=1e-10, update_guess=False, bs_target=1)
+    psi12, _ = s.solve_adjoint(2.0 * P1 - 0.5 * P2, method="sibk", rtol=1e-10, update_guess=False, bs_target=1)
+    assert relerr(psi12, 2.0 * psi1 - 0.5 * psi2) < 1e-8
+
+    class OneOfTwo:  # rank 1 of 2 without a second process
+        rank, size = 1, 2
+
+        def allreduce_sum(self, a):
+            return a
+
+        def allreduce_max(self, x):
+            return x
+
+        def barrier(self):
+            pass
+
+    psi_r, _ = s.solve_adjoint(P1, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, comm=OneOfTwo())
+    assert relerr(psi_r[:, 1::2], psi1[:, 1::2]) < 1e-9                    # (reduction-tree shapes differ with the width)
+    # d(sum_i w_i ln lam_i)/d rhoE along a random direction against a central difference of the eigenvalues
+    w = rng.uniform(size=N)
+    dBdx = ElementBilinear(ctx, col.elem_dofs, col.Ke0, scale=col.dK_scale())
+    dAdx = ElementBilinear(ctx, col.elem_dofs, col.Ge_unit, scale=col.dG_scale())
+    zero = np.zeros((n, N))
+    dfdx = s.add_total_derivative(w, zero, zero, dAdx, dBdx, np.zeros(col.mesh.nelems), adj_corr_data={},
+                                  deriv_type="tensor")
+    p = rng.uniform(-1.0, 1.0, size=col.mesh.nelems)
+    h = 1e-5
+    f = []
+    from eigd_amd.problems import _assemble
+
+    rho0 = col.rhoE.copy()
+    for sgn in (+1.0, -1.0):
+        col.rhoE = rho0 + sgn * h * p
+        K2 = col.stiffness()                                               # frozen pre-buckling stresses, as dAdx
+        G2, _ = _assemble(col.mesh, (col.rhoE**col.p + col.rho0_G)[:, None, None] * col.Ge_unit, 2, col.free_map)
+        fac.refactor((K2 + sigma * G2).tocsr())
+        s2 = eg.IRAM(N=N, m=33, mode="buckling", ctx=ctx)
+        lam2, _ = s2.solve(G2, K2, fac, sigma)
+        f.append(float(np.dot(w, np.log(lam2))))
+    col.rhoE = rho0
+    fd = (f[0] - f[1]) / (2.0 * h)
+    assert abs(float(dfdx @ p) - fd) < 1e-5 * abs(fd)
