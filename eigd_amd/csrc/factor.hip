@@ -1308,7 +1308,8 @@ __global__ __launch_bounds__(64) void bwd_thin_kernel(FrontArrays fa, const WgRe
 #pragma unroll
       for (int ob = 0; ob < NOB; ++ob) {
         const int o = 16 * ob + li;
-        a[s][ob] = *((k < d && o < ns) ? Fp + static_cast<int64_t>(k) * ns + o : fa.zero);
+        // (rows of T above the diagonal block of these 16 columns hold zeros: wave-uniform test, not fetched)
+        a[s][ob] = *((k < d && o < ns && !(4 * CH * ch + 4 * s + 3 < 16 * ob)) ? Fp + static_cast<int64_t>(k) * ns + o : fa.zero);
       }
       const int e = k - ns;  // border entry
       const int r0 = __shfl(I[0], e & 63), r1 = __shfl(I[1], e & 63), r2 = __shfl(I[2], e & 63), r3 = __shfl(I[3], e & 63);
