@@ -316,7 +316,7 @@ def main():
     roofline = {"kernel": "fwd_thin_kernel + fwd_level_kernel + bwd_thin_kernel + bwd_level_kernel (one sweep of the factor, "
                           "all tree levels)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": 6380000000 if default_c3 else None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": 6350000000 if default_c3 else None,
                 "traffic_source": "profiles/r01_pmc_fetch_sweep_coldot.csv + r01_pmc_write_sweep_coldot.csv",
                 "bytes_per_launch": sweep_bytes, "us_per_launch": round(sweep_ms * 1e3, 1), "columns": N,
                 "nnzL": fstats["nnzL"]}
