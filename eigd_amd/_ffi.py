@@ -47,6 +47,7 @@ _SIGNATURES = {
     "eigd_timer_start": [c_vp],
     "eigd_timer_stop_ms": [c_vp, P(c_dbl)],
     "eigd_csr_upload": [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, P(c_vp)],
+    "eigd_csr_upload_rect": [c_vp, c_int, c_int, c_i64, c_vp, c_vp, c_vp, P(c_vp)],
     "eigd_csr_update_values": [c_vp, c_vp],
     "eigd_mat_free": [c_vp],
     "eigd_spmm": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_dbl],
@@ -92,6 +93,14 @@ _SIGNATURES = {
     "eigd_gather_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
     "eigd_scatter_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
     "eigd_elem_bilinear": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_vp],
+    "eigd_elem_linear_adjoint": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int,
+                                 c_dbl, c_vp],
+    "eigd_comm_unique_id": [c_vp],
+    "eigd_comm_init": [c_vp, c_int, c_int, c_vp, P(c_vp)],
+    "eigd_comm_destroy": [c_vp],
+    "eigd_comm_info": [c_vp, P(c_int), P(c_int)],
+    "eigd_allreduce_sum": [c_vp, c_vp, c_i64],
+    "eigd_allreduce_max": [c_vp, c_vp, c_i64],
 }
 EXPORTED = sorted(list(_SIGNATURES) + ["eigd_last_error"])
 

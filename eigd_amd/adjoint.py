@@ -291,39 +291,58 @@ def add_eig_total_derivative(lam, Phi, lamb, Phib, psi, dAdx, dBdx, dfdx, adj_co
 
 
 def _total_derivative_device(dPhi, dPhib, dpsi, lam, lamb, dAdx, dBdx, dfdx, adj_corr_data, mode, deriv_type, cols,
-                             Phi_host=None):
+                             Phi_host=None, comm=None):
+    """
+    ``cols`` restricts the sum to a rank's modes; with ``comm`` the partial sums of all ranks are then added by ONE
+    all-reduce -- on the device vector they were accumulated in when the callbacks are device callbacks (RCCL, no host
+    round trip), on a host vector for numpy callbacks.
+    """
     N = dPhi.k
-    WA, WB = device_derivative_weights(dPhi, dPhib, dpsi, lam, lamb, adj_corr_data, mode, cols)
     sel = np.arange(N) if cols is None else np.asarray(cols)
+    sharded = comm is not None and comm.size > 1
     sB = -1.0 if mode == "normal" else 1.0
-    dev_cb = [bool(getattr(cb, "device", False)) for cb in (dAdx, dBdx)]
-    Phi_sel_dev = dPhi if cols is None else dPhi.gather_cols(sel)
-    Phi_sel = None
-    if not all(d or cb is None for d, cb in zip(dev_cb, (dAdx, dBdx))):
-        Phi_sel = (Phi_host if Phi_host is not None else dPhi.get())[:, sel]
+    cbs = (dAdx, dBdx)
+    dev_cb = [bool(getattr(cb, "device", False)) for cb in cbs]
     # device callbacks that can accumulate (ElementBilinear) share one device vector: one D2H, one host addition
-    acc = None
     fused = [on_dev and hasattr(cb, "accumulate") and getattr(cb, "nelem", -1) == len(dfdx)
-             for cb, on_dev in zip((dAdx, dBdx), dev_cb)]
-    for cb, W, sign, on_dev, fuse in ((dAdx, WA, 1.0, dev_cb[0], fused[0]), (dBdx, WB, sB, dev_cb[1], fused[1])):
-        if cb is None:
-            continue
-        if fuse:
-            if acc is None:
-                acc = Phi_sel_dev.ctx.zeros(len(dfdx), 1)
-            cb.accumulate(W, Phi_sel_dev, acc, alpha=sign)
-            continue
-        if on_dev:
-            dfdx += sign * cb(W, Phi_sel_dev)
-            continue
-        Wh = W.get()
-        if deriv_type == "vector":
-            for q in range(len(sel)):
-                dfdx += sign * cb(Wh[:, q].copy(), Phi_sel[:, q])
-        else:
-            dfdx += sign * cb(Wh, Phi_sel)
+             for cb, on_dev in zip(cbs, dev_cb)]
+    any_fused = any(f and cb is not None for f, cb in zip(fused, cbs))
+    any_host = any(cb is not None and not f for f, cb in zip(fused, cbs))
+    ctx = dPhi.ctx
+    acc = ctx.zeros(len(dfdx), 1) if any_fused else None
+    host = np.zeros_like(dfdx) if (sharded and any_host) else dfdx
+    if len(sel) > 0:
+        WA, WB = device_derivative_weights(dPhi, dPhib, dpsi, lam, lamb, adj_corr_data, mode, cols)
+        Phi_sel_dev = dPhi if cols is None else dPhi.gather_cols(sel)
+        Phi_sel = None
+        if not all(d or cb is None for d, cb in zip(dev_cb, cbs)):
+            Phi_sel = (Phi_host if Phi_host is not None else dPhi.get())[:, sel]
+        for cb, W, sign, on_dev, fuse in ((dAdx, WA, 1.0, dev_cb[0], fused[0]), (dBdx, WB, sB, dev_cb[1], fused[1])):
+            if cb is None:
+                continue
+            if fuse:
+                cb.accumulate(W, Phi_sel_dev, acc, alpha=sign)
+                continue
+            if on_dev:
+                host += sign * cb(W, Phi_sel_dev)
+                continue
+            Wh = W.get()
+            if deriv_type == "vector":
+                for q in range(len(sel)):
+                    host += sign * cb(Wh[:, q].copy(), Phi_sel[:, q])
+            else:
+                host += sign * cb(Wh, Phi_sel)
     if acc is not None:
-        dfdx += acc.get()[:, 0]
+        if sharded:
+            if hasattr(comm, "allreduce_sum_device"):
+                comm.allreduce_sum_device(acc)               # RCCL, in place on the device
+                dfdx += acc.get()[:, 0]
+            else:
+                dfdx += comm.allreduce_sum(acc.get()[:, 0])
+        else:
+            dfdx += acc.get()[:, 0]
+    if sharded and any_host:
+        dfdx += comm.allreduce_sum(host)
     return dfdx
 
 

@@ -104,6 +104,69 @@ __global__ __launch_bounds__(kThreads) void elem_linear_matrices_kernel(int nele
   }
 }
 
+
+// Transpose of elem_linear_matrices with respect to u: for Me[e](u) = sum_m (L[m] . u_e) Q[m],
+//     g[e*nd + a] = alpha * scale[e] * sum_m L[m][a] * t_m,   t_m = sum_c w_e(:, c)^T Q[m] v_e(:, c),
+// i.e. d/du_e of sum_c w_c^T G(u) v_c per element -- the tensor form of the reference's
+// get_stress_stiffness_matrix_uderiv (examples/buckling.py:283-316: dfds, then C Be contraction).  The element
+// vectors are summed into the dof vector by a CSR product with the (fixed-order) dof <- element-entry incidence
+// matrix, so the path adjoint right-hand side is reproducible bit for bit.  KP lanes (one per column) share an element.
+constexpr int kMaxTerms = 16;
+
+template <int KP>
+__global__ __launch_bounds__(kThreads) void elem_linear_adjoint_kernel(int nelem, int nd, const int32_t* __restrict__ edofs,
+                                                                      int nterms, const double* __restrict__ L,
+                                                                      const double* __restrict__ Q,
+                                                                      const double* __restrict__ scale,
+                                                                      const double* __restrict__ W, int ldw,
+                                                                      const double* __restrict__ V, int ldv, int k,
+                                                                      double alpha, double* __restrict__ out) {
+  constexpr int EPB = kThreads / KP;
+  const int c = threadIdx.x % KP;
+  const int el = blockIdx.x * EPB + threadIdx.x / KP;
+  const bool valid = (el < nelem) && (c < k);
+  double w[8], v[8];
+  int dofs[8];
+  const int32_t* ed = edofs + static_cast<int64_t>(valid ? el : 0) * nd;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) dofs[a] = *((valid && a < nd) ? ed + a : &g_minus_one);
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    w[a] = *((dofs[a] >= 0) ? W + static_cast<int64_t>(dofs[a]) * ldw + c : &g_zero_fem);
+    v[a] = *((dofs[a] >= 0) ? V + static_cast<int64_t>(dofs[a]) * ldv + c : &g_zero_fem);
+  }
+  const int nd2 = nd * nd;
+  double g[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) g[a] = 0.0;
+  for (int m = 0; m < nterms; ++m) {
+    const double* Qm = Q + static_cast<int64_t>(m) * nd2;
+    double t = 0.0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      if (a < nd) {
+        double r = 0.0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+          if (b < nd) r += Qm[a * nd + b] * v[b];
+        t += w[a] * r;
+      }
+    }
+    // fixed butterfly: every lane of the element ends with the same sum over the columns
+#pragma unroll
+    for (int off = KP / 2; off > 0; off >>= 1) t += __shfl_xor(t, off, KP);
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+      if (a < nd) g[a] += L[m * nd + a] * t;
+  }
+  if (c == 0 && el < nelem) {
+    const double f = alpha * (scale ? scale[el] : 1.0);
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+      if (a < nd) out[static_cast<int64_t>(el) * nd + a] = f * g[a];
+  }
+}
+
 }  // namespace eigd
 
 using namespace eigd;
@@ -248,6 +311,38 @@ extern "C" int eigd_elem_bilinear(eigd_ctx* ctx, int nelem, int nd, const int32_
       return EIGD_E_INTERNAL;
   }
 #undef EIGD_EB_CASE
+  EIGD_LAUNCH_CHECK();
+  return EIGD_OK;
+}
+
+extern "C" int eigd_elem_linear_adjoint(eigd_ctx* ctx, int nelem, int nd, const int32_t* d_edofs, int nterms,
+                                        const double* dL, const double* dQ, const double* dscale, const double* dW,
+                                        int ldw, const double* dV, int ldv, int k, double alpha, double* dOut) {
+  EIGD_REQUIRE(ctx && d_edofs && dL && dQ && dW && dV && dOut, "null argument");
+  EIGD_REQUIRE(nelem > 0 && nd >= 1 && nd <= 8 && nterms >= 1 && nterms <= kMaxTerms && k >= 1 && k <= kMaxK &&
+                   ldw >= k && ldv >= k,
+               "bad shape nelem=%d nd=%d nterms=%d k=%d", nelem, nd, nterms, k);
+  const int kp = next_pow2(k);
+  const int epb = kThreads / kp;
+  const dim3 grid((nelem + epb - 1) / epb);
+#define EIGD_ELA_CASE(KP)                                                                                            \
+  case KP:                                                                                                           \
+    hipLaunchKernelGGL(elem_linear_adjoint_kernel<KP>, grid, dim3(kThreads), 0, ctx->stream, nelem, nd, d_edofs,     \
+                       nterms, dL, dQ, dscale, dW, ldw, dV, ldv, k, alpha, dOut);                                    \
+    break;
+  switch (kp) {
+    EIGD_ELA_CASE(1)
+    EIGD_ELA_CASE(2)
+    EIGD_ELA_CASE(4)
+    EIGD_ELA_CASE(8)
+    EIGD_ELA_CASE(16)
+    EIGD_ELA_CASE(32)
+    EIGD_ELA_CASE(64)
+    default:
+      set_error("internal: unexpected kp=%d", kp);
+      return EIGD_E_INTERNAL;
+  }
+#undef EIGD_ELA_CASE
   EIGD_LAUNCH_CHECK();
   return EIGD_OK;
 }

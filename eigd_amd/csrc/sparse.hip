@@ -23,7 +23,8 @@
 
 struct eigd_mat {
   eigd_ctx* ctx = nullptr;
-  int n = 0;
+  int n = 0;      // rows
+  int ncols = 0;  // columns (== n for the operators A, B; rectangular for gather / averaging maps)
   int64_t nnz = 0;
   int32_t* indptr = nullptr;
   int32_t* indices = nullptr;
@@ -285,12 +286,18 @@ extern "C" {
 
 int eigd_csr_upload(eigd_ctx* ctx, int n, int64_t nnz, const int32_t* hindptr, const int32_t* hindices,
                     const double* hdata, eigd_mat** out) {
+  return eigd_csr_upload_rect(ctx, n, n, nnz, hindptr, hindices, hdata, out);
+}
+
+int eigd_csr_upload_rect(eigd_ctx* ctx, int n, int ncols, int64_t nnz, const int32_t* hindptr, const int32_t* hindices,
+                         const double* hdata, eigd_mat** out) {
   EIGD_REQUIRE(ctx && hindptr && hindices && hdata && out, "null argument");
-  EIGD_REQUIRE(n > 0 && nnz >= 0 && nnz < (int64_t(1) << 31), "bad matrix size n=%d nnz=%lld", n, (long long)nnz);
+  EIGD_REQUIRE(n > 0 && ncols > 0 && nnz >= 0 && nnz < (int64_t(1) << 31), "bad matrix size %d x %d nnz=%lld", n, ncols,
+               (long long)nnz);
   EIGD_REQUIRE(hindptr[0] == 0 && hindptr[n] == nnz, "indptr does not match nnz");
   for (int i = 0; i < n; ++i) EIGD_REQUIRE(hindptr[i + 1] >= hindptr[i], "indptr not monotone at row %d", i);
   for (int64_t e = 0; e < nnz; ++e)
-    EIGD_REQUIRE(hindices[e] >= 0 && hindices[e] < n, "column index out of range at entry %lld", (long long)e);
+    EIGD_REQUIRE(hindices[e] >= 0 && hindices[e] < ncols, "column index out of range at entry %lld", (long long)e);
   *out = nullptr;
   // row blocks for the CSR-stream kernel
   std::vector<int32_t> rb;
@@ -317,7 +324,7 @@ int eigd_csr_upload(eigd_ctx* ctx, int n, int64_t nnz, const int32_t* hindptr, c
   int umax = 0;
   bool tiles_ok = true;
   {
-    std::vector<int32_t> cols, stamp(static_cast<size_t>(n), -1), pos(static_cast<size_t>(n), 0);
+    std::vector<int32_t> cols, stamp(static_cast<size_t>(ncols), -1), pos(static_cast<size_t>(ncols), 0);
     ucols.reserve(static_cast<size_t>(nnz) / 4 + 16);
     for (int t = 0; t < ntiles && tiles_ok; ++t) {
       const int r0 = t * kTileRows, r1 = std::min(n, r0 + kTileRows);
@@ -342,6 +349,7 @@ int eigd_csr_upload(eigd_ctx* ctx, int n, int64_t nnz, const int32_t* hindptr, c
   eigd_mat* A = new eigd_mat();
   A->ctx = ctx;
   A->n = n;
+  A->ncols = ncols;
   A->nnz = nnz;
   A->nblocks = static_cast<int>(rb.size()) - 1;
   if (tiles_ok) {

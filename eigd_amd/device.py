@@ -446,17 +446,15 @@ class CSRMatrix:
         A = sparse.csr_matrix(A)
         if A.dtype != np.float64:
             A = A.astype(np.float64)
-        if A.shape[0] != A.shape[1]:
-            raise ValueError("square matrix expected")
         self.ctx = ctx
         self.shape = A.shape
-        self.n = A.shape[0]
+        self.n, self.ncols = A.shape  # rectangular: the gather / averaging / filter maps of the design-variable chain
         self.nnz = int(A.nnz)
         ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
         ix = np.ascontiguousarray(A.indices, dtype=np.int32)
         dv = np.ascontiguousarray(A.data, dtype=np.float64)
         h = c_vp()
-        call("eigd_csr_upload", ctx.h, self.n, self.nnz, hptr(ip), hptr(ix), hptr(dv), C.byref(h))
+        call("eigd_csr_upload_rect", ctx.h, self.n, self.ncols, self.nnz, hptr(ip), hptr(ix), hptr(dv), C.byref(h))
         self.h = h
 
     def __del__(self):
@@ -470,8 +468,8 @@ class CSRMatrix:
     def apply(self, X, Y=None, alpha=1.0, beta=0.0):
         """Y = alpha A X + beta Y"""
         if Y is None:
-            Y = self.ctx.empty(X.n, X.k)
-        if X.n != self.n or (Y.n, Y.k) != (X.n, X.k):
+            Y = X.ctx.empty(self.n, X.k)
+        if X.n != self.ncols or (Y.n, Y.k) != (self.n, X.k):
             raise ValueError("shape mismatch in SpMM")
         call("eigd_spmm_on", X.ctx.h, self.h, X.ptr, X.ld, Y.ptr, Y.ld, X.k, float(alpha), float(beta))  # on X's stream
         return Y
@@ -508,6 +506,8 @@ class Symbolic:
         self.n = A.shape[0]
         ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
         ix = np.ascontiguousarray(A.indices, dtype=np.int32)
+        self.nnz = int(A.nnz)
+        self.pattern_key = self.pattern_fingerprint(ip, ix)
         h = c_vp()
         if coords is None:
             call("eigd_symbolic_create", self.n, hptr(ip), hptr(ix), int(leaf_size), int(panel_width), C.byref(h))
@@ -527,6 +527,20 @@ class Symbolic:
                 self.h = None
         except Exception:
             pass
+
+    @staticmethod
+    def pattern_fingerprint(indptr, indices):
+        import hashlib
+
+        hsh = hashlib.blake2b(digest_size=16)
+        hsh.update(np.ascontiguousarray(indptr, dtype=np.int32).tobytes())
+        hsh.update(np.ascontiguousarray(indices, dtype=np.int32).tobytes())
+        return hsh.hexdigest()
+
+    def check_pattern(self, A):
+        """a reused analysis must belong to the matrix: the numeric phase scatters the values through its index maps"""
+        if A.shape[0] != self.n or int(A.nnz) != self.nnz or self.pattern_fingerprint(A.indptr, A.indices) != self.pattern_key:
+            raise ValueError("the symbolic analysis was made for a different sparsity pattern")
 
     def array(self, name):
         s = self.sizes
@@ -560,6 +574,8 @@ class Factor:
         A.sort_indices()
         self.ctx = ctx
         self.n = A.shape[0]
+        if symbolic is not None:
+            symbolic.check_pattern(A)
         self.symbolic = symbolic if symbolic is not None else Symbolic(A, leaf_size, panel_width, coords)
         data = np.ascontiguousarray(A.data, dtype=np.float64)
         h = c_vp()
@@ -581,11 +597,14 @@ class Factor:
 
         A = sparse.csr_matrix(A)
         A.sort_indices()
+        self.symbolic.check_pattern(A)
         data = np.ascontiguousarray(A.data, dtype=np.float64)
         call("eigd_factor_refactor", self.h, hptr(data))
 
     def refactor_device(self, vals):
         """numeric refactorisation from CSR values that already live on the device (ElementAssembler.assemble)"""
+        if vals.n * vals.k < self.symbolic.nnz:
+            raise ValueError("fewer values than the analysed pattern has entries")
         call("eigd_factor_refactor_dev", self.h, vals.ptr)
 
     def solve_inplace(self, X, alpha=1.0):
@@ -787,4 +806,25 @@ class ElementLinearMatrices:
         out = self.ctx.empty(self.nelem * self.nd * self.nd, 1)
         call("eigd_elem_linear_matrices", self.ctx.h, self.nelem, self.nd, c_vp(self._dofs.ptr), u_full.ptr, self.nterms,
              c_vp(self._L.ptr), c_vp(self._Q.ptr), out.ptr)
+        return out
+
+    def adjoint(self, elem_dofs_dev, W, V, scale=None, alpha=1.0):
+        """
+        d/du_e of sum_c w_c^T Me(u) v_c per element (device block nelem * nd x 1, entry e*nd + a belongs to
+        full_dofs[e, a]): the tensor form of examples/buckling.py:283-316.  ``elem_dofs_dev`` is the device dof list
+        (a _Buffer, -1 = constrained) through which the n x k blocks W, V are gathered; ``scale`` a device block or None.
+        """
+        if (W.n, W.k) != (V.n, V.k):
+            raise ValueError("shape mismatch")
+        out = self.ctx.zeros(self.nelem * self.nd, 1)
+        sp = scale.ptr if scale is not None else c_vp(None)
+        tmp = out if W.k <= 64 else self.ctx.empty(self.nelem * self.nd, 1)
+        for c0 in range(0, W.k, 64):
+            c1 = min(W.k, c0 + 64)
+            dst = out if c0 == 0 else tmp
+            call("eigd_elem_linear_adjoint", self.ctx.h, self.nelem, self.nd, c_vp(elem_dofs_dev.ptr), self.nterms,
+                 c_vp(self._L.ptr), c_vp(self._Q.ptr), sp, W.cols(c0, c1).ptr, W.ld, V.cols(c0, c1).ptr, V.ld, c1 - c0,
+                 float(alpha), dst.ptr)
+            if c0 > 0:
+                out.assign_lincomb([(1.0, out), (1.0, tmp)])
         return out

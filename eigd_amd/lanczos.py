@@ -345,15 +345,8 @@ class _AdjointAPI:
         dPhib = Phib if isinstance(Phib, DeviceBlock) else ctx.from_host(Phib)
         dpsi = psi if isinstance(psi, DeviceBlock) else ctx.from_host(psi)
         cols = self._mode_columns(N, comm)
-        if cols is None:
-            return adj._total_derivative_device(self._prob.Phi, dPhib, dpsi, lam, lamb, dAdx, dBdx, dfdx,
-                                                adj_corr_data, self.mode, deriv_type, None, Phi_host=self.Phi)
-        part = np.zeros_like(dfdx)
-        adj._total_derivative_device(self._prob.Phi, dPhib, dpsi, lam, lamb, dAdx, dBdx, part, adj_corr_data,
-                                     self.mode, deriv_type, cols, Phi_host=self.Phi)
-        part = comm.allreduce_sum(part)
-        dfdx += part
-        return dfdx
+        return adj._total_derivative_device(self._prob.Phi, dPhib, dpsi, lam, lamb, dAdx, dBdx, dfdx, adj_corr_data,
+                                            self.mode, deriv_type, cols, Phi_host=self.Phi, comm=comm)
 
 
 class BasicLanczos(_AdjointAPI):

@@ -73,6 +73,10 @@ int eigd_timer_stop_ms(eigd_ctx* ctx, double* ms);
  * per-row summation order is scipy's (bit-identical result for alpha=1, beta=0). */
 int eigd_csr_upload(eigd_ctx* ctx, int n, int64_t nnz, const int32_t* hindptr, const int32_t* hindices,
                     const double* hdata, eigd_mat** out);
+/* rectangular n x ncols matrix (x has ncols rows, y has n): the gather / averaging / filter maps of the design-variable
+ * chain (examples/node_filter.py:160-217; element averages and their transposes, buckling.py:209-213, 866-870) */
+int eigd_csr_upload_rect(eigd_ctx* ctx, int n, int ncols, int64_t nnz, const int32_t* hindptr, const int32_t* hindices,
+                         const double* hdata, eigd_mat** out);
 int eigd_csr_update_values(eigd_mat* A, const double* hdata);
 /* the same with the values already on the device (e.g. from eigd_assemble) */
 int eigd_csr_update_values_dev(eigd_mat* A, const double* dvals);
@@ -215,6 +219,30 @@ int eigd_assemble(eigd_assembler* a, const double* dMe, int per_elem, const doub
  * dOut: nelem x nd x nd (feeds eigd_assemble with per_elem = 1). */
 int eigd_elem_linear_matrices(eigd_ctx* ctx, int nelem, int nd, const int32_t* d_edofs, const double* du, int nterms,
                               const double* dL, const double* dQ, double* dOut);
+
+/* transpose of the above with respect to u (path adjoint of the fundamental state, examples/buckling.py:283-316,
+ * 930-947, 974-979): dOut[e*nd + a] = alpha * scale[e] * sum_m L[m][a] * sum_c w_e(:,c)^T Q[m] v_e(:,c), with w_e, v_e
+ * gathered from the n x k blocks dW, dV through the (constrained = -1) dof list d_edofs; nterms <= 16.  The element
+ * vectors are summed into dofs by a CSR product with the incidence matrix (fixed order, reproducible). */
+int eigd_elem_linear_adjoint(eigd_ctx* ctx, int nelem, int nd, const int32_t* d_edofs, int nterms, const double* dL,
+                             const double* dQ, const double* dscale, const double* dW, int ldw, const double* dV,
+                             int ldv, int k, double alpha, double* dOut);
+
+/* ---- multi-GPU: the df/dx reduction over RCCL / xGMI ---------------------
+ * The per-mode adjoint solves are sharded over the ranks (one process per GPU); each rank sums the total-derivative
+ * contributions of its own modes (the loop over i of 93-134 / the column sum of 135-180) into a device vector, and
+ * ONE all-reduce (sum, fp64) of that vector completes df/dx.  eigd_comm_unique_id is called on rank 0, the 128 bytes
+ * travel to the other rank processes through the host, every rank then calls eigd_comm_init (collective).  The
+ * all-reduce is in place on a device buffer and ordered on the ctx stream; nranks == 1 needs no id and no RCCL. */
+#define EIGD_COMM_ID_BYTES 128
+typedef struct eigd_comm eigd_comm;
+int eigd_comm_unique_id(void* hid128);
+int eigd_comm_init(eigd_ctx* ctx, int nranks, int rank, const void* hid128, eigd_comm** out);
+int eigd_comm_destroy(eigd_comm* comm);
+int eigd_comm_info(eigd_comm* comm, int* nranks, int* rank);
+int eigd_allreduce_sum(eigd_comm* comm, double* dbuf, int64_t len);
+/* the same with max: the slowest rank's wall time of a timed region (bench.py) */
+int eigd_allreduce_max(eigd_comm* comm, double* dbuf, int64_t len);
 
 #ifdef __cplusplus
 }

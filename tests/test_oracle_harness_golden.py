@@ -1,0 +1,128 @@
+"""
+Pin the harness-side oracle (oracle/fe_oracle.py: element derivative callbacks, fundamental-path adjoint, node filter,
+aggregate functionals) and the oracle's total derivative to the outputs of the reference's own harness runs
+(``rhoEb``, ``dfdu0``, ``rhob``, ``xb``, ``ans``, KS / compliance values and gradients; tools/make_golden.py).  CPU only.
+"""
+import numpy as np
+import pytest
+
+from conftest import corr_from, csr_from, load_golden, relerr
+from oracle import eigd_oracle as orc
+from oracle import fe_oracle as fe
+
+TOL = 1e-8  # north_star: derivatives within 1e-8 relative
+
+
+def drop_rigid(data, nrigid=3):
+    """the natural-frequency harness discards the pairs that involve a rigid-body mode (natural_frequency.py:486-497)"""
+    out = {}
+    for i in data:
+        if i >= nrigid:
+            items = [(j, xi, eta) for j, xi, eta in data[i] if j >= nrigid]
+            if items:
+                out[i] = items
+    return out
+
+
+def test_filter_units_g7():
+    g = load_golden("g7_node_filter")
+    for ftype in ("spatial", "helmholtz"):
+        for proj in (False, True):
+            for use_map in (False, True):
+                kw = dict(dvmap=g["dvmap"], num_design_vars=int(g["num_design_vars"])) if use_map else {}
+                flt = fe.NodeFilter(g["conn"], g["X"], r0=float(g["r0"]), ftype=ftype, beta=float(g["beta"]),
+                                    eta=float(g["eta"]), projection=proj, **kw)
+                tag = f"{ftype}_{'proj' if proj else 'lin'}_{'map' if use_map else 'nomap'}_"
+                assert relerr(flt.apply(g[tag + "x"].copy()), g[tag + "rho"]) < 1e-12, tag
+                assert relerr(flt.apply_gradient(g["g"].copy(), g[tag + "x"].copy()), g[tag + "grad"]) < 1e-12, tag
+
+
+@pytest.mark.parametrize("solver", ["basiclanczos", "iram"])
+def test_g2_total_derivative_matches_reference_rhoEb(solver):
+    g = load_golden("g2_natfreq32x16_" + solver)
+    tab = fe.Q4Tables(g["conn"], g["X"])
+    C0 = fe.plane_stress_C0(float(g["E"]), float(g["nu"]))
+    rhoE, p, dens = g["rhoE"], float(g["p"]), float(g["density"])
+    n, N0 = g["Q0b"].shape
+    psi0 = np.zeros((n, N0))
+    psi0[:, 3:] = g["psi"]
+    data0 = drop_rigid(corr_from(g, "corr"))
+    rhoEb = orc.add_eig_total_derivative(
+        g["lam"], g["Phi"], g["lamb0"], g["Q0b"], psi0,
+        lambda w, v: fe.stiffness_deriv(tab, C0, rhoE, p, w, v), lambda w, v: fe.mass_deriv(tab, rhoE, dens, w, v),
+        np.zeros(tab.nelems), adj_corr_data=data0, mode="normal", deriv_type="tensor")
+    assert relerr(rhoEb, g["rhoEb"]) < TOL
+    # design-variable chain: element -> node -> filter -> design variables (natural_frequency.py:510-515)
+    flt = fe.NodeFilter(g["conn"], g["X"], r0=float(g["r0"]), dvmap=g["dvmap"], num_design_vars=int(g["num_design_vars"]))
+    assert abs(flt.F - csr_from(g, "F")).max() < 1e-15
+    assert relerr(fe.node_to_element(g["conn"], flt.apply(g["x"])), rhoE) < 1e-14
+    xb = flt.apply_gradient(fe.element_to_node(g["conn"], g["rhoEb"], tab.nnodes), g["x"])
+    assert relerr(xb, g["xb"]) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["g3_thermal32_eps1e-1_basiclanczos", "g3_thermal32_eps1e-8_basiclanczos",
+                                  "g3_thermal32_eps1e-8_iram"])
+def test_g3_total_derivative_matches_reference_rhoEb(name):
+    """the repeated-eigenvalue branch all the way to df/dx: xi / eta of the near-repeated pairs enter the weights"""
+    g = load_golden(name)
+    tab = fe.Q4Tables(g["conn"], g["X"])
+    rhoE, p = g["rhoE"], float(g["p"])
+    kappa, beta, hc, dens = float(g["kappa"]), float(g["th_beta"]), float(g["heat_capacity"]), float(g["density"])
+    data = corr_from(g, "corr")
+    cbA = lambda w, v: fe.thermal_stiffness_deriv(tab, rhoE, p, kappa, beta, w, v)  # noqa: E731
+    cbB = lambda w, v: fe.thermal_mass_deriv(tab, hc, dens, beta, w, v)              # noqa: E731
+    rhoEb = orc.add_eig_total_derivative(g["lam"], g["Phi"], g["lamb"], g["Qb"], g["psi"], cbA, cbB,
+                                         np.zeros(tab.nelems), adj_corr_data=data, mode="normal", deriv_type="tensor")
+    assert relerr(rhoEb, g["rhoEb"]) < TOL
+    # the adjoint seeds of the compliance functional and its value (thermal.py:428-442)
+    Qb, lamb = fe.thermal_compliance_seeds(g["lam"], g["Phi"], g["vec"])
+    assert relerr(Qb, g["Qb"]) < 1e-13 and relerr(lamb, g["lamb"]) < 1e-13
+    assert abs(fe.thermal_compliance(g["lam"], g["Phi"], g["vec"]) - float(g["compliance"])) < 1e-12 * abs(float(g["compliance"]))
+    # the oracle's own adjoint solve on the same (Phi, Qb) gives the same df/dx
+    K, M = csr_from(g, "K"), csr_from(g, "M")
+    sigma = float(g["sigma"])
+    psi, data2, _ = orc.sibk(g["Qb"], K, M, g["lam"], g["Phi"], sigma=sigma,
+                             factor=orc.SpLuOperator((K - sigma * M).tocsc()), rtol=1e-12)
+    rhoEb2 = orc.add_eig_total_derivative(g["lam"], g["Phi"], g["lamb"], g["Qb"], psi, cbA, cbB, np.zeros(tab.nelems),
+                                          adj_corr_data=data2, mode="normal", deriv_type="tensor")
+    assert relerr(rhoEb2, g["rhoEb"]) < TOL
+    flt = fe.NodeFilter(g["conn"], g["X"], r0=float(g["r0"]), dvmap=g["dvmap"], num_design_vars=int(g["num_design_vars"]))
+    xb = flt.apply_gradient(fe.element_to_node(g["conn"], g["rhoEb"], tab.nnodes), g["x"])
+    assert relerr(xb, g["xb"]) < 1e-12
+
+
+@pytest.mark.parametrize("solver", ["basiclanczos", "iram"])
+def test_g1_buckling_chain_with_path_adjoint(solver):
+    """finalize_adjoint of examples/buckling.py stage by stage: dfdu0, rhob (eigen part), path adjoint, xb, ans"""
+    g = load_golden("g1_buckling50_" + solver)
+    Kr = csr_from(g, "K")
+    hs = fe.BucklingHarness(g["conn"], g["X"], g["rhoE"], g["u"], g["reduced"], Kr, p=float(g["p"]),
+                            rho0_G=float(g["rho0_G"]), E=float(g["E"]), nu=float(g["nu"]))
+    data = corr_from(g, "corr")
+    args = (g["lam"], g["Phi"], g["lamb"], g["Qrb"], g["psir"])
+    dfdu0 = orc.add_eig_total_derivative(*args, hs.dAdu, None, np.zeros(hs.nvars), adj_corr_data=data, mode="buckling",
+                                         deriv_type="tensor")
+    assert relerr(dfdu0, g["dfdu0"]) < TOL
+    rhob = orc.add_eig_total_derivative(*args, hs.dAdx, hs.dBdx, np.zeros(hs.tab.nnodes), adj_corr_data=data,
+                                        mode="buckling", deriv_type="tensor")
+    assert relerr(rhob, g["rhob_eig"]) < TOL
+    rhob = rhob + hs.path_adjoint(dfdu0)
+    assert relerr(rhob, g["rhob"]) < TOL
+    flt = fe.NodeFilter(g["conn"], g["X"], r0=float(g["r0"]), dvmap=g["dvmap"], num_design_vars=int(g["num_design_vars"]))
+    xb = flt.apply_gradient(rhob, g["x"])
+    assert relerr(xb, g["xb"]) < TOL
+    assert abs(g["pert"] @ xb - float(g["ans"])) < TOL * abs(float(g["ans"]))
+    # the aggregate itself and its seeds (buckling.py:702-760)
+    Q = hs.full(g["Phi"])
+    node = int(g["node"])
+    h, _, _, _ = fe.eigenvector_aggregate(g["lam"], Q, node, float(g["agg_rho"]))
+    assert abs(h - float(g["h_agg"])) < 1e-13 * abs(float(g["h_agg"]))
+    Qb, lamb = fe.eigenvector_aggregate_seeds(g["lam"], Q, node, float(g["agg_rho"]))
+    assert relerr(Qb[g["reduced"]], g["Qrb"]) < 1e-13
+    assert np.abs(lamb - g["lamb"]).max() <= 1e-13 * max(np.abs(g["lamb"]).max(), 1e-300) + 1e-300
+    if solver == "basiclanczos":
+        ks, _, _ = fe.ks_buckling(g["BLF"], float(g["ks_rho"]))
+        assert abs(ks - float(g["ks"])) < 1e-13 * abs(float(g["ks"]))
+        assert relerr(flt.apply_gradient(hs.ks_gradient(g["BLF"], g["Phi"], float(g["ks_rho"])), g["x"]), g["ks_grad"]) < TOL
+        assert abs(g["f"] @ g["u"] - float(g["compliance"])) < 1e-13 * abs(float(g["compliance"]))
+        assert relerr(flt.apply_gradient(hs.compliance_gradient(), g["x"]), g["compliance_grad"]) < TOL

@@ -120,15 +120,30 @@ def case_g1(solver_type):
         adjoint_options={"lanczos_guess": True, "update_guess": False, "bs_target": 1},
         deriv_type="tensor",
     )
-    d = topo.test_eigenvector_aggregate_derivatives(mode="tanh", rho=100.0)
+    pert = np.random.uniform(size=topo.x.shape)  # the draw test_eigenvector_aggregate_derivatives would make itself
+    node = (8 + 1) * 16 + 16
+    d = topo.test_eigenvector_aggregate_derivatives(mode="tanh", rho=100.0, node=node, pert=pert)
     # test_* re-initialises at perturbed points; redo the base point for capture
     topo.initialize(store=True)
     topo.initialize_adjoint()
-    topo.add_eigenvector_aggregate_derivative(1.0, 100.0, (8 + 1) * 16 + 16, mode="tanh")
+    h_agg = topo.get_eigenvector_aggregate(100.0, node, mode="tanh")
+    topo.add_eigenvector_aggregate_derivative(1.0, 100.0, node, mode="tanh")
     Qrb = topo.Qrb.copy()
     lamb = topo.lamb.copy()
-    topo.finalize_adjoint()
+    # the two add_total_derivative calls of finalize_adjoint (buckling.py:930-972): d/du of the eigen part, then d/drho
+    captured = []
     s = topo.eig_solver
+    orig_add = s.add_total_derivative
+
+    def recording_add(*a, **kw):
+        out = orig_add(*a, **kw)
+        captured.append(np.array(out))
+        return out
+
+    s.add_total_derivative = recording_add
+    topo.finalize_adjoint()
+    s.add_total_derivative = orig_add
+    dfdu0, rhob_eig = captured
     f = {}
     f.update(csr_fields("K", topo.Kr))
     f.update(csr_fields("G", topo.Gr))
@@ -142,6 +157,25 @@ def case_g1(solver_type):
     )
     if "cs" in d:
         f.update(cs=np.float64(d["cs"]), cs_err=np.float64(d["cs_err"]))
+    # the harness around the eigd calls: mesh, design variables, filter, fundamental path, the chain rule's stages
+    f.update(csr_fields("F", topo.fltr.F))
+    f.update(
+        conn=topo.conn.astype(np.int32), X=topo.X, x=np.array(topo.x), rhoE=topo.rhoE, u=topo.u, f=topo.f,
+        reduced=np.asarray(topo.reduced, dtype=np.int64), dvmap=np.asarray(topo.fltr.dvmap, dtype=np.int64),
+        num_design_vars=np.int64(topo.fltr.num_design_vars), r0=np.float64(topo.fltr.r0),
+        p=np.float64(topo.p), rho0_K=np.float64(topo.rho0_K), rho0_G=np.float64(topo.rho0_G),
+        E=np.float64(topo.E), nu=np.float64(topo.nu),
+        pert=pert, node=np.int64(node), agg_rho=np.float64(100.0), h_agg=np.float64(h_agg),
+        dfdu0=dfdu0, rhob_eig=rhob_eig, rhob=topo.rhob, xb=topo.xb,
+    )
+    if solver_type == "BasicLanczos":
+        # the other functionals of the harness at the same point (buckling.py:634-700): KS of the buckling loads and
+        # the compliance, with their design gradients
+        f.update(
+            ks_rho=np.float64(30.0), ks=np.float64(topo.eval_ks_buckling(30.0)),
+            ks_grad=topo.eval_ks_buckling_derivative(30.0),
+            compliance=np.float64(topo.compliance()), compliance_grad=topo.compliance_derivative(),
+        )
     save("g1_buckling50_" + solver_type.lower(), **f)
 
 
@@ -174,6 +208,13 @@ def case_g2(solver_type):
     f.update(
         sigma=np.float64(topo.sigma), Q0b=Q0b, lamb0=lamb0, psi=topo.psi, rhoEb=topo.rhoEb,
         res_bortho=np.asarray(res), adjoint_residuals=np.array(topo.profile["adjoint residuals"]),
+    )
+    f.update(csr_fields("F", topo.fltr.F))
+    f.update(
+        conn=topo.conn.astype(np.int32), X=topo.X, x=np.array(topo.x), rhoE=topo.rhoE, xb=topo.xb,
+        dvmap=np.asarray(topo.fltr.dvmap, dtype=np.int64), num_design_vars=np.int64(topo.fltr.num_design_vars),
+        r0=np.float64(topo.fltr.r0), p=np.float64(topo.p), rho0_K=np.float64(topo.rho0_K),
+        density=np.float64(topo.density), E=np.float64(topo.E), nu=np.float64(topo.nu),
     )
     save("g2_natfreq32x16_" + solver_type.lower(), **f)
 
@@ -209,6 +250,14 @@ def case_g3(solver_type, epsilon, tag):
         vec=vec, epsilon=np.float64(epsilon), res_bortho=res, ortho_bortho=ortho,
         ans=np.float64(d["ans"]), cd=np.float64(d["cd"]), cd_err=np.float64(d["cd_err"]),
         conn=topo.conn.astype(np.int32), X=topo.X, rhoE=topo.rhoE,
+    )
+    f.update(csr_fields("F", topo.fltr.F))
+    f.update(
+        x=np.array(topo.x), xb=topo.xb, dvmap=np.asarray(topo.fltr.dvmap, dtype=np.int64),
+        num_design_vars=np.int64(topo.fltr.num_design_vars), r0=np.float64(topo.fltr.r0),
+        p=np.float64(topo.p), th_beta=np.float64(topo.beta), kappa=np.float64(topo.kappa),
+        density=np.float64(topo.density), heat_capacity=np.float64(topo.heat_capacity),
+        compliance=np.float64(topo.get_thermal_compliance(vec)),
     )
     save(f"g3_thermal32_{tag}_{solver_type.lower()}", **f)
 
@@ -363,6 +412,51 @@ def case_g6():
     save("g6_buckling50_complexstep", **f)
 
 
+# ---------------------------------------------------------------- G7 -------
+def case_g7():
+    """NodeFilter units (examples/node_filter.py:10-217): spatial and Helmholtz filters, with and without the tanh
+    projection and a symmetric design-variable map, forward and gradient, on a small non-square mesh."""
+    import_reference()
+    from node_filter import NodeFilter
+
+    nx, ny, Lx, Ly = 14, 9, 1.4, 0.8
+    x1, y1 = np.linspace(0, Lx, nx + 1), np.linspace(0, Ly, ny + 1)
+    nodes = np.arange((nx + 1) * (ny + 1)).reshape(nx + 1, ny + 1)
+    X = np.zeros(((nx + 1) * (ny + 1), 2))
+    X[nodes.ravel(), 0] = np.repeat(x1, ny + 1)
+    X[nodes.ravel(), 1] = np.tile(y1, nx + 1)
+    conn = np.zeros((nx * ny, 4), dtype=int)
+    for j in range(ny):
+        for i in range(nx):
+            conn[i + nx * j] = [nodes[i, j], nodes[i + 1, j], nodes[i + 1, j + 1], nodes[i, j + 1]]
+    dvmap = np.zeros((nx + 1, ny + 1), dtype=int)
+    index = 0
+    for i in range(nx // 2 + 1):                      # mirror symmetry left-right, as buckling.py:1327-1340
+        for j in range(ny + 1):
+            dvmap[i, j] = index
+            dvmap[nx - i, j] = index
+            index += 1
+    dvmap = dvmap.flatten()
+    dvmap[nodes[3, 4]] = -1                            # one node outside the design domain (x = 1 there)
+    rng = np.random.default_rng(21)
+    x = rng.uniform(0.05, 0.95, size=index)
+    g = rng.normal(size=X.shape[0])
+    r0 = 0.27
+    f = dict(conn=conn.astype(np.int32), X=X, dvmap=dvmap.astype(np.int64), num_design_vars=np.int64(index),
+             x=x, g=g, r0=np.float64(r0), beta=np.float64(8.0), eta=np.float64(0.4))
+    for ftype in ("spatial", "helmholtz"):
+        for proj in (False, True):
+            for use_map in (False, True):
+                kw = dict(dvmap=dvmap, num_design_vars=index) if use_map else {}
+                flt = NodeFilter(conn, X, r0=r0, ftype=ftype, beta=8.0, eta=0.4, projection=proj, **kw)
+                xin = x if use_map else rng.uniform(0.05, 0.95, size=X.shape[0])
+                tag = f"{ftype}_{'proj' if proj else 'lin'}_{'map' if use_map else 'nomap'}_"
+                f[tag + "x"] = xin
+                f[tag + "rho"] = flt.apply(xin.copy())
+                f[tag + "grad"] = flt.apply_gradient(g.copy(), xin.copy())
+    save("g7_node_filter", **f)
+
+
 CASES = {
     "g1_basic": lambda: case_g1("BasicLanczos"),
     "g1_iram": lambda: case_g1("IRAM"),
@@ -375,6 +469,7 @@ CASES = {
     "g4_iram": lambda: case_g4("IRAM"),
     "g5": case_g5,
     "g6": case_g6,
+    "g7": case_g7,
 }
 
 if __name__ == "__main__":
