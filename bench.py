@@ -12,13 +12,20 @@ problem (BASELINE.json configs[2]; SURVEY.md section 8d "C3").
 Untimed preamble per rank (reported in the JSON): synthetic K(rho), fundamental path u = K^-1 f,
 G(u), shift selection, factorisation of K + sigma G, the IRAM eigensolve.
 
-  python bench.py [--gpus 1] [--steps 3] [--warmup 1]
+  python bench.py [--gpus G] [--steps 3] [--warmup 1]
+      G > 1 without a launcher: this process starts G rank processes itself (before it touches the GPU; it never
+      does) and relays rank 0's JSON line.
   python -m torch.distributed.run --nproc-per-node G ... bench.py --gpus G ...
+      one rank per GPU from RANK / LOCAL_RANK / WORLD_SIZE; the collective is RCCL through the C ABI
+      (eigd_comm_init / eigd_allreduce_sum of include/eigd_hip.h), no PyTorch in the rank processes.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -53,6 +60,52 @@ def estimate_first_buckling_load(ctx, dK, dG, Kfac, n, iters=40):
     return 1.0 / mu
 
 
+def launch_ranks(nranks):
+    """
+    ``python bench.py --gpus N`` without a launcher: start N rank processes (fresh interpreters; this parent makes no
+    HIP call before or after), one per GPU, relay their stderr and rank 0's stdout, exit non-zero if any rank fails.
+    """
+    rdv = tempfile.mkdtemp(prefix="eigd_comm_")
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), EIGD_COMM_DIR=rdv,
+                   EIGD_DEVICE=str(r), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    try:
+        for fn in os.listdir(rdv):
+            os.unlink(os.path.join(rdv, fn))
+        os.rmdir(rdv)
+    except OSError:
+        pass
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def measured_traffic(entry, sources):
+    """
+    HBM bytes per launch from the committed PMC passes (profiles/r02_traffic.json, written by tools/pmc_report.py from
+    the rocprofv3 --pmc CSVs), valid only for the kernel sources they were taken with: a changed kernel file gives null.
+    """
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    try:
+        rec = json.load(open(path))[entry]
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC record"
+    for fn in sources:
+        sha = hashlib.sha256(open(os.path.join(ROOT, "eigd_amd", "csrc", fn), "rb").read()).hexdigest()[:16]
+        if rec.get("source_sha16", {}).get(fn) != sha:
+            return None, f"stale: {fn} changed since the PMC pass ({rec.get('files')})"
+    return rec["traffic_bytes_per_launch"], rec.get("files")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,7 +117,9 @@ def main():
     ap.add_argument("--m", type=int, default=65)
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--cpu-sample", choices=("full", "none"), default="full",
-                    help="CPU baseline: SuperLU factor of the same matrix + the oracle's sibk on two of the modes")
+                    help="CPU baseline: SuperLU factor of the same matrix + the oracle's laa + sibk on a sample of the modes")
+    ap.add_argument("--cpu-modes", type=int, default=4, help="modes in the CPU sample")
+    ap.add_argument("--numpy-steps", type=int, default=2, help="extra steps through the numpy-in / numpy-out call surface")
     ap.add_argument("--spmv-reps", type=int, default=200)
     ap.add_argument("--streams", type=int, default=None,
                     help="mode groups solved concurrently on separate HIP streams (default: EIGD_STREAMS or 1)")
@@ -74,25 +129,21 @@ def main():
     ap.add_argument("--emulate-rank", default=None, help="r/P: time the mode share of rank r of P on this GPU (development aid)")
     ap.add_argument("--trace", default=None, help="write the per-iteration host timeline of one extra step to this file")
     ap.add_argument("--no-fd-check", action="store_true", help="skip the directional finite-difference check of df/dx")
+    ap.add_argument("--force-launch", action="store_true",
+                    help="start the rank processes through the launcher even for --gpus 1 (test of the launcher)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_launch):
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    comm = None
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1:
-        # torch first: its bundled HIP runtime is the one the process then shares with libeigd_hip.so
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         os.environ["EIGD_DEVICE"] = str(local_rank)
-        from eigd_amd.comm import TorchDistComm
-
-        comm = TorchDistComm(device=torch.device("cuda", local_rank))
     if args.gpus != world:
         log(rank, f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    comm = None
     if args.emulate_rank and world == 1:
         # development aid: time the share of ONE rank of a P-rank job on this GPU (no collective; results are partial)
         class _OneOfMany:
@@ -116,6 +167,11 @@ def main():
     from eigd_amd.problems import BucklingColumn
 
     ctx = default_context()
+    if world > 1:
+        from eigd_amd.comm import RcclComm
+
+        comm = RcclComm(ctx, rank, world)           # RCCL over xGMI, one rank per GPU (collective call)
+        log(rank, f"RCCL communicator up: {world} ranks")
     N = args.modes
     timing = {}
 
@@ -182,10 +238,8 @@ def main():
     def fence():
         ctx.sync()
         if comm is not None and world > 1:
-            import torch
-
-            torch.cuda.synchronize()
             comm.barrier()
+            ctx.sync()
 
     for _ in range(args.warmup):
         step()
@@ -200,7 +254,7 @@ def main():
     elapsed = time.perf_counter() - t0
     log(rank, "step times (s):", [round(t, 3) for t in step_times])
     if comm is not None:
-        elapsed = comm.allreduce_max(elapsed)
+        elapsed = comm.allreduce_max(elapsed)       # the slowest rank's wall time
     adj_count = factor.count
     ms_per_step = 1e3 * elapsed / args.steps
     value = N * args.steps / elapsed
@@ -253,6 +307,24 @@ def main():
         pr.disable()
         with open(args.pyprofile, "w") as fh:
             pstats.Stats(pr, stream=fh).sort_stats("cumulative").print_stats(45)
+    # ------------------------------------------------------------------ the reference's call surface: numpy in, numpy out
+    # (the timed value keeps the operands resident in HBM; callers of the reference hand numpy arrays to solve_adjoint
+    # and add_total_derivative, which adds the H2D of Phib and the D2H / H2D of psi: reported next to the value)
+    numpy_api = None
+    if world == 1 and comm is None and args.numpy_steps > 0:
+        t0 = time.perf_counter()
+        for _ in range(args.numpy_steps):
+            psi_np, data_np = solver.solve_adjoint(Phib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1)
+            solver.add_total_derivative(lamb, Phib, psi_np, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data_np,
+                                        deriv_type="tensor")
+        ctx.sync()
+        t_np = (time.perf_counter() - t0) / args.numpy_steps
+        numpy_api = {"value": round(N / t_np, 3), "unit": "modes/s", "ms_per_step": round(1e3 * t_np, 3),
+                     "steps": args.numpy_steps,
+                     "note": "same step with numpy arrays in and out (H2D of Phib, D2H + H2D of psi; pageable host memory)"}
+        del psi_np
+        log(rank, f"numpy-in / numpy-out step: {1e3 * t_np:.1f} ms ({N / t_np:.1f} modes/s)")
+
     # ------------------------------------------------------------------ accuracy of the timed result
     res, ortho = solver.eval_adjoint_residual_norm(dPhib, dpsi, b_ortho=False) if world == 1 else (None, None)
     accuracy = {}
@@ -312,12 +384,12 @@ def main():
     sweep_ms = ctx.timer_stop_ms() / 10
     sweep_bytes = factor.factor.solve_bytes(N)
     default_c3 = (args.nx, args.ny, N, args.ordering) == (706, 706, 32, "geometric")
+    sweep_traffic, sweep_src = measured_traffic("sweep_k32_c3", ("factor.hip",)) if default_c3 else (None, "not the C3 default")
     achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
     roofline = {"kernel": "fwd_thin_kernel + fwd_level_kernel + bwd_thin_kernel + bwd_level_kernel (one sweep of the factor, "
                           "all tree levels)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": 6350000000 if default_c3 else None,
-                "traffic_source": "profiles/r01_pmc_fetch_sweep_coldot.csv + r01_pmc_write_sweep_coldot.csv",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": sweep_traffic, "traffic_source": sweep_src,
                 "bytes_per_launch": sweep_bytes, "us_per_launch": round(sweep_ms * 1e3, 1), "columns": N,
                 "nnzL": fstats["nnzL"]}
     # SpMV, the bit-exact CSR-stream kernel: K and G (same sparsity, 235 MB of traffic each) are applied alternately
@@ -336,10 +408,11 @@ def main():
     spmv_ms = ctx.timer_stop_ms() / (2 * (args.spmv_reps // 2))
     spmv_bytes = dK.spmv_bytes(1)
     spmv_rate = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+    spmv_traffic, spmv_src = (measured_traffic("spmv_c3", ("sparse.hip",)) if (args.nx, args.ny) == (706, 706)
+                              else (None, "not the C3 default"))
     spmv = {"kernel": "spmv_stream_kernel", "bound": "hbm", "achieved": round(spmv_rate, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(spmv_rate / HBM_PEAK_GBS, 4),
-            "traffic": 237996096 if (args.nx, args.ny) == (706, 706) else None,
-            "traffic_source": "profiles/r01_pmc_fetch_spmv_coldot.csv + r01_pmc_write_spmv_coldot.csv",
+            "traffic": spmv_traffic, "traffic_source": spmv_src,
             "bytes_per_launch": spmv_bytes, "us_per_launch": round(spmv_ms * 1e3, 2)}
 
     # ------------------------------------------------------------------ the same design point prepared on the device
@@ -375,7 +448,9 @@ def main():
     # ------------------------------------------------------------------ CPU baseline (oracle = port of the reference)
     cpu = None
     if args.cpu_sample != "none" and world == 1:
-        cpu = cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, dpsi, log)
+        cpu = cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, solver, dPhib, dpsi, data, dAdx, dBdx, ndv, log)
+        accuracy["dfdx_rel_err_gpu_vs_cpu"] = cpu.pop("dfdx_rel_err_gpu_vs_cpu")
+        accuracy["psi_rel_err_gpu_vs_cpu"] = cpu["psi_rel_err_gpu_vs_cpu"]
 
     out = {
         "metric": "adjoint_mode_derivatives_per_sec",
@@ -391,13 +466,14 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"buckling {n / 1e6:.1f}M-dof Q4 column ({args.nx}x{args.ny} elements), {N} modes, "
-                               f"IRAM m={args.m} + sibk rtol=1e-10 + tensor total derivative w.r.t. element densities",
+                               f"IRAM m={args.m} + sibk rtol={args.rtol:g} + tensor total derivative w.r.t. element densities",
                    "n_dof": int(n), "nnz": int(K.nnz), "modes": N, "m": args.m, "sigma": round(float(sigma), 6),
                    "ordering": args.ordering,
-                   "parallelism": f"modes sharded over {world} GPU(s), one df/dx all-reduce"},
+                   "parallelism": f"modes sharded over {world} GPU(s), one RCCL all-reduce of df/dx per step"},
         "roofline": roofline,
         "spmv": spmv,
         "cpu_baseline": cpu,
+        "numpy_api": numpy_api,
         "accuracy": accuracy,
         "preamble_s": {k: round(v, 3) for k, v in timing.items()},
         "factor_sweeps_per_step": int(adj_count),
@@ -406,87 +482,70 @@ def main():
     print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, dpsi, log):
+def cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, solver, dPhib, dpsi, data, dAdx, dBdx, ndv, log):
     """
-    The CPU oracle (numpy/scipy port of the reference algorithm: SuperLU + the same sibk) on the
-    same matrices, eigenpairs and right-hand sides, for two of the 32 modes (bounded sample).
+    The CPU oracle (numpy/scipy restatement of the reference: SuperLU + laa guess + sibk, oracle/eigd_oracle.py) on the
+    same matrices, eigenpairs, Lanczos data and right-hand sides, for a bounded sample of the modes spread over the
+    spectrum; then those modes' share of df/dx on both sides.  Repeated up to 3 times (best time kept) while a
+    repetition stays under 20 s, so the default run still finishes in minutes.
     """
     from oracle import eigd_oracle as orc
 
     n, N = Phib.shape
+    threads = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
     t0 = time.perf_counter()
     fac = orc.SpLuOperator((K + sigma * G).tocsc())
     t_fac = time.perf_counter() - t0
     log(0, f"cpu: SuperLU factorisation {t_fac:.1f}s")
-    # sibk on the first and the last mode (fastest and slowest to converge) with the full projector
-    BPhi = K @ Phi
-    ed = col.elem_dofs
-
-    def gather(v):
-        return np.where(ed >= 0, v[np.maximum(ed, 0)], 0.0)
-
-    Gm = -Phi.T @ Phib
-    G0 = np.diag(lam) @ Gm
-    t_adj = t_der = 0.0
-    errs = []
-    sample = [0, N // 2] if N > 1 else [0]
-    for i in sample:
+    ns = max(1, min(args.cpu_modes, N))
+    sample = sorted({int(round(q)) for q in np.linspace(0, N - 1, ns)})
+    V, Y, theta, indices = solver.V, np.asarray(solver.Y), np.asarray(solver.theta), np.asarray(solver.indices)
+    best = None
+    for rep in range(3):
         t0 = time.perf_counter()
-        psi_i = orc_sibk_one_mode(orc, Phib, G, K, lam, Phi, BPhi, fac, sigma, i, args.rtol)
-        t_adj += time.perf_counter() - t0
+        psi0 = orc.laa(Phib, K, fac, sigma, lam, V, Y, theta, indices, b_ortho=True, mode="buckling", cols=sample)
+        t_laa = time.perf_counter() - t0
         t0 = time.perf_counter()
-        # total derivative of that mode (numpy einsum version of the two element callbacks)
-        beta = 0.5 * Phi[:, i].dot(Phib[:, i])
-        wA = lam[i] * (lamb[i] * Phi[:, i] + psi_i)
-        wB = (lamb[i] - beta) * Phi[:, i] + psi_i
-        wAe, wBe, pe = gather(wA), gather(wB), gather(Phi[:, i])
-        d1 = col.dG_scale() * np.einsum("na,nab,nb->n", wAe, col.Ge_unit, pe)
-        d2 = col.dK_scale() * np.einsum("na,ab,nb->n", wBe, col.Ke0, pe)
-        _ = d1 + d2
-        t_der += time.perf_counter() - t0
-        # the GPU psi carries the correction along the other eigenvectors; remove it for the comparison
-        psi_gpu = dpsi.cols(i, i + 1).get()[:, 0]
-        corr = np.zeros(n)
-        for j in range(N):
-            if j != i:
-                corr += (G0[j, i] / (lam[j] - lam[i])) * Phi[:, j]
-        errs.append(float(np.linalg.norm((psi_gpu - corr) - psi_i) / np.linalg.norm(psi_i)))
-    log(0, f"cpu: {len(sample)} modes adjoint {t_adj:.1f}s derivative {t_der:.2f}s; GPU-vs-CPU psi rel-err {max(errs):.2e}")
-    return {"value": round(len(sample) / (t_adj + t_der), 5), "unit": "modes/s", "cores": 1, "kind": "port",
-            "sample": f"modes {sample} of {N} (lowest and middle mode) on the same 1M-dof matrices, eigenpairs and "
-                      f"right-hand sides; SuperLU factor {t_fac:.0f}s untimed, like the GPU's; adjoint {t_adj:.1f}s + "
-                      f"derivative {t_der:.2f}s",
-            "factor_s": round(t_fac, 1), "psi_rel_err_gpu_vs_cpu": max(errs)}
+        psi_c, data_c, info = orc.sibk(Phib, G, K, lam, Phi, mode="buckling", psi=psi0, sigma=sigma, factor=fac,
+                                       rtol=args.rtol, modes=sample)
+        t_sibk = time.perf_counter() - t0
+        # total derivative of the sampled modes: the reference's weight vectors (eigenvector_derivatives.py:118-134),
+        # numpy einsum version of the two element callbacks (examples/buckling.py:178-218, 321-340)
+        t0 = time.perf_counter()
+        WA, WB = orc.derivative_weights(lam, Phi, lamb, Phib, psi_c, data_c, "buckling")
+        ed = col.elem_dofs
 
+        def gather(M):
+            return np.where(ed[:, :, None] >= 0, M[np.maximum(ed, 0)], 0.0)
 
-def orc_sibk_one_mode(orc, Phib, A, B, lam, Phi, BPhi, fac, sigma, i, rtol, maxiter=50):
-    """oracle sibk (buckling mode) for column i only, projector over all N eigenvectors (ref 1198-1321, bs=1)"""
-    n, N = Phib.shape
-    rnorm0 = np.sqrt(np.max(np.sum(Phib**2, axis=0)))
-    proj = lambda x: x - BPhi @ (Phi.T @ x)  # noqa: E731
-    R = proj(-Phib[:, i].copy())            # psi0 = 0 (no Lanczos guess in the sample)
-    W = np.zeros((n, maxiter + 1))
-    Z = np.zeros((n, maxiter))
-    W[:, 0] = proj(R)
-    r00 = np.linalg.norm(W[:, 0])
-    W[:, 0] /= r00
-    H = np.zeros((maxiter + 1, maxiter))
-    for j in range(1, maxiter + 1):
-        kp = j - 1
-        Z[:, kp] = fac(W[:, kp])
-        w = proj(A @ Z[:, kp])
-        for k in range(j - 1, -1, -1):
-            H[k, kp] = w.dot(W[:, k])
-            w -= H[k, kp] * W[:, k]
-        w = proj(w)
-        H[j, kp] = np.linalg.norm(w)
-        W[:, j] = w / H[j, kp]
-        rv = np.zeros(j + 1)
-        rv[0] = r00
-        y, res = orc.solve_shifted_lstsq(-(lam[i] - sigma), H[: j + 1, :j], rv)
-        if res < rtol * rnorm0:
+        wAe, wBe, pe = gather(WA[:, sample]), gather(WB[:, sample]), gather(Phi[:, sample])
+        dfdx_c = (col.dG_scale() * np.einsum("nak,nab,nbk->n", wAe, col.Ge_unit, pe)
+                  + col.dK_scale() * np.einsum("nak,ab,nbk->n", wBe, col.Ke0, pe))
+        t_der = time.perf_counter() - t0
+        tot = t_laa + t_sibk + t_der
+        log(0, f"cpu: rep {rep}: {len(sample)} modes laa {t_laa:.1f}s sibk {t_sibk:.1f}s derivative {t_der:.2f}s "
+               f"(iterations {info})")
+        if best is None or tot < best[0]:
+            best = (tot, t_laa, t_sibk, t_der)
+        if tot > 20.0:
             break
-    return Z[:, :j] @ y
+    # the same modes' share on the GPU: psi of the timed step, device callbacks, restricted to the sample
+    import eigd_amd.adjoint as adj
+
+    dfdx_g = adj._total_derivative_device(solver._prob.Phi, dPhib, dpsi, lam, lamb, dAdx, dBdx, np.zeros(ndv), data,
+                                          "buckling", "tensor", np.asarray(sample))
+    err_df = float(np.linalg.norm(dfdx_g - dfdx_c) / np.linalg.norm(dfdx_c))
+    psi_g = dpsi.get()[:, sample]
+    err_psi = float(np.max(np.linalg.norm(psi_g - psi_c[:, sample], axis=0) / np.linalg.norm(psi_c[:, sample], axis=0)))
+    log(0, f"cpu: GPU-vs-CPU on modes {sample}: psi rel-err {err_psi:.2e}, df/dx rel-err {err_df:.2e}")
+    tot, t_laa, t_sibk, t_der = best
+    return {"value": round(len(sample) / tot, 5), "unit": "modes/s", "cores": 1, "host_cpus": os.cpu_count(),
+            "thread_env": threads, "kind": "port",
+            "sample": f"modes {sample} of {N} on the same 1M-dof matrices, eigenpairs, Lanczos basis and right-hand sides: "
+                      f"oracle laa guess {t_laa:.1f}s + sibk {t_sibk:.1f}s + derivative {t_der:.2f}s (best of up to 3 "
+                      f"repetitions); SuperLU factor {t_fac:.0f}s untimed, like the GPU's; SuperLU / scipy CSR kernels "
+                      f"are sequential whatever the thread settings",
+            "factor_s": round(t_fac, 1), "psi_rel_err_gpu_vs_cpu": err_psi, "dfdx_rel_err_gpu_vs_cpu": err_df}
 
 
 if __name__ == "__main__":

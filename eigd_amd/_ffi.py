@@ -95,6 +95,7 @@ _SIGNATURES = {
     "eigd_elem_bilinear": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_vp],
     "eigd_elem_linear_adjoint": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int,
                                  c_dbl, c_vp],
+    "eigd_design_map": [c_vp, c_i64, c_int, c_dbl, c_dbl, c_dbl, c_vp, c_vp, c_vp],
     "eigd_comm_unique_id": [c_vp],
     "eigd_comm_init": [c_vp, c_int, c_int, c_vp, P(c_vp)],
     "eigd_comm_destroy": [c_vp],

@@ -167,6 +167,38 @@ __global__ __launch_bounds__(kThreads) void elem_linear_adjoint_kernel(int nelem
   }
 }
 
+
+// Elementwise maps of the design-variable chain, one thread per entry:
+//   kind 0: out = x^p + c0                       SIMP penalisation rhoE^p + rho0 (examples/buckling.py:157-160)
+//   kind 1: out = p * x^(p-1)  [* g]             its derivative (buckling.py:207-208), optionally times g
+//   kind 2: out = (tanh(b e) + tanh(b (x - e))) / (tanh(b e) + tanh(b (1 - e)))      projection (node_filter.py:175-181)
+//   kind 3: out = g * (b / denom) / cosh(b (x - e))^2                                its derivative (node_filter.py:196-203)
+//   kind 4: out = c0 * x + c1                    linear interpolation (thermal.py:133, 198; mass densities)
+// p, c0 double as (b, e) for the projection.
+__global__ __launch_bounds__(kThreads) void design_map_kernel(int64_t n, int kind, double p, double c0, double c1,
+                                                             const double* __restrict__ x,
+                                                             const double* __restrict__ g, double* __restrict__ out) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const double xi = x[i];
+    double r;
+    if (kind == 0) {
+      r = pow(xi, p) + c0;
+    } else if (kind == 1) {
+      r = p * pow(xi, p - 1.0);
+      if (g) r *= g[i];
+    } else if (kind == 2) {
+      r = (tanh(p * c0) + tanh(p * (xi - c0))) / (tanh(p * c0) + tanh(p * (1.0 - c0)));
+    } else if (kind == 3) {
+      const double ch = cosh(p * (xi - c0));
+      r = (g ? g[i] : 1.0) * ((p / (tanh(p * c0) + tanh(p * (1.0 - c0)))) * 1.0 / (ch * ch));
+    } else {
+      r = c0 * xi + c1;
+    }
+    out[i] = r;
+  }
+}
+
 }  // namespace eigd
 
 using namespace eigd;
@@ -343,6 +375,16 @@ extern "C" int eigd_elem_linear_adjoint(eigd_ctx* ctx, int nelem, int nd, const 
       return EIGD_E_INTERNAL;
   }
 #undef EIGD_ELA_CASE
+  EIGD_LAUNCH_CHECK();
+  return EIGD_OK;
+}
+
+extern "C" int eigd_design_map(eigd_ctx* ctx, int64_t n, int kind, double p, double c0, double c1, const double* dx,
+                               const double* dg, double* dout) {
+  EIGD_REQUIRE(ctx && dx && dout, "null argument");
+  EIGD_REQUIRE(n > 0 && kind >= 0 && kind <= 4, "bad arguments n=%lld kind=%d", (long long)n, kind);
+  const int nb = static_cast<int>(std::min<int64_t>((n + kThreads - 1) / kThreads, 65536));
+  hipLaunchKernelGGL(design_map_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, n, kind, p, c0, c1, dx, dg, dout);
   EIGD_LAUNCH_CHECK();
   return EIGD_OK;
 }

@@ -474,9 +474,19 @@ class CSRMatrix:
         call("eigd_spmm_on", X.ctx.h, self.h, X.ptr, X.ld, Y.ptr, Y.ld, X.k, float(alpha), float(beta))  # on X's stream
         return Y
 
+    dtype = np.dtype(np.float64)
+
+    def matvec(self, x):
+        """numpy in, numpy out: lets scipy's aslinearoperator wrap a matrix that lives on the device"""
+        x = np.asarray(x, dtype=np.float64)
+        out = self.apply(self.ctx.from_host(x.reshape(self.ncols, -1))).get()
+        return out[:, 0] if x.ndim == 1 else out
+
+    matmat = matvec
+
     def update_values_device(self, vals):
         """new values (device block of nnz doubles, in this matrix's CSR order), same sparsity"""
-        if vals.n * vals.k != self.nnz:
+        if vals.n * vals.k < self.nnz:
             raise ValueError("value count does not match the matrix")
         call("eigd_csr_update_values_dev", self.h, vals.ptr)
 
@@ -660,28 +670,46 @@ class ElementBilinear:
         elem_dofs = np.ascontiguousarray(elem_dofs, dtype=np.int32)
         self.ctx = ctx
         self.nelem, self.nd = elem_dofs.shape
-        Me = np.ascontiguousarray(Me, dtype=np.float64)
-        self.per_elem = 1 if Me.ndim == 3 else 0
-        if Me.shape[-2:] != (self.nd, self.nd) or (self.per_elem and Me.shape[0] != self.nelem):
-            raise ValueError("element matrix shape does not match the dof list")
         self._dofs = _Buffer(ctx, elem_dofs.nbytes)
         call("eigd_h2d", ctx.h, c_vp(self._dofs.ptr), hptr(elem_dofs), elem_dofs.nbytes)
-        self._Me = _Buffer(ctx, Me.nbytes)
-        call("eigd_h2d", ctx.h, c_vp(self._Me.ptr), hptr(Me), Me.nbytes)
+        if isinstance(Me, DeviceBlock):  # per-element matrices made on the device (ElementLinearMatrices)
+            if Me.n * Me.k != self.nelem * self.nd * self.nd or Me.ld != Me.k:
+                raise ValueError("element matrix block does not match the dof list")
+            self.per_elem, self._Me = 1, Me
+        else:
+            Me = np.ascontiguousarray(Me, dtype=np.float64)
+            self.per_elem = 1 if Me.ndim == 3 else 0
+            if Me.shape[-2:] != (self.nd, self.nd) or (self.per_elem and Me.shape[0] != self.nelem):
+                raise ValueError("element matrix shape does not match the dof list")
+            self._Me = _Buffer(ctx, Me.nbytes)
+            call("eigd_h2d", ctx.h, c_vp(self._Me.ptr), hptr(Me), Me.nbytes)
         self._scale = None
-        if scale is not None:
+        if isinstance(scale, DeviceBlock):
+            if scale.n * scale.k != self.nelem:
+                raise ValueError("one scale factor per element expected")
+            self._scale = scale
+        elif scale is not None:
             scale = np.ascontiguousarray(scale, dtype=np.float64)
             self._scale = _Buffer(ctx, scale.nbytes)
             call("eigd_h2d", ctx.h, c_vp(self._scale.ptr), hptr(scale), scale.nbytes)
+
+    @classmethod
+    def from_device(cls, ctx, elem_dofs, Me, scale):
+        """element matrices (device block or numpy) and scale factors (device block) that already live on the device"""
+        return cls(ctx, elem_dofs, Me, scale)
+
+    @staticmethod
+    def _p(obj):
+        return obj.ptr if isinstance(obj, DeviceBlock) else c_vp(obj.ptr)
 
     def accumulate(self, W, V, out, alpha=1.0):
         """out (device, nelem x 1) += alpha * contraction"""
         if (W.n, W.k) != (V.n, V.k):
             raise ValueError("shape mismatch")
-        sp = c_vp(self._scale.ptr) if self._scale is not None else c_vp(None)
+        sp = self._p(self._scale) if self._scale is not None else c_vp(None)
         for c0 in range(0, W.k, 64):
             c1 = min(W.k, c0 + 64)
-            call("eigd_elem_bilinear", self.ctx.h, self.nelem, self.nd, c_vp(self._dofs.ptr), c_vp(self._Me.ptr),
+            call("eigd_elem_bilinear", self.ctx.h, self.nelem, self.nd, c_vp(self._dofs.ptr), self._p(self._Me),
                  self.per_elem, sp, W.cols(c0, c1).ptr, W.ld, V.cols(c0, c1).ptr, V.ld, c1 - c0, float(alpha), out.ptr)
         return out
 

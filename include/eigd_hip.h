@@ -228,6 +228,13 @@ int eigd_elem_linear_adjoint(eigd_ctx* ctx, int nelem, int nd, const int32_t* d_
                              const double* dQ, const double* dscale, const double* dW, int ldw, const double* dV,
                              int ldv, int k, double alpha, double* dOut);
 
+/* elementwise maps of the design-variable chain (examples/node_filter.py:175-203 projection and its
+ * derivative, examples/buckling.py:157-160, 207-208 SIMP penalisation and its derivative), dout[i] = map(dx[i]):
+ *   kind 0: x^p + c0     kind 1: p x^(p-1) (* dg[i] if dg)     kind 4: c0 x + c1
+ *   kind 2: tanh projection with beta = p, eta = c0            kind 3: its derivative times dg[i] */
+int eigd_design_map(eigd_ctx* ctx, int64_t n, int kind, double p, double c0, double c1, const double* dx,
+                    const double* dg, double* dout);
+
 /* ---- multi-GPU: the df/dx reduction over RCCL / xGMI ---------------------
  * The per-mode adjoint solves are sharded over the ranks (one process per GPU); each rank sums the total-derivative
  * contributions of its own modes (the loop over i of 93-134 / the column sum of 135-180) into a device vector, and

@@ -198,7 +198,10 @@ def generate_adjoint_correction(lam, Phi, psi, G=None, Phib=None, eig_atol=1e-5,
 # --------------------------------------------------------------------------
 # Lanczos adjoint approximation (ref 394-523)
 # --------------------------------------------------------------------------
-def laa(Phib, B, factor, sigma, lam, V, Y, theta, indices, D0=None, b_ortho=False, mode="normal"):
+def laa(Phib, B, factor, sigma, lam, V, Y, theta, indices, D0=None, b_ortho=False, mode="normal", cols=None):
+    """ref 394-523.  ``cols`` (not in the reference): evaluate only those modes' columns -- the coefficient matrix D is
+    built for all N modes as the reference does, the N-column product and factor solve of ref 519-521 are restricted
+    to the listed columns (bench.py times a bounded sample of the modes on the CPU); the result keeps shape (n, N)."""
     n = B.shape[1]
     m = len(theta)
     N = Phib.shape[1]
@@ -231,7 +234,12 @@ def laa(Phib, B, factor, sigma, lam, V, Y, theta, indices, D0=None, b_ortho=Fals
             D = C / (th_sel[None, :] - theta[:, None])
         D[indices[:N], np.arange(N)] = 0.0
     scale = 1.0 if mode == "normal" else sigma
-    return -factor(B @ V @ (Y @ (scale * (D / (lam - sigma)))))
+    Cf = Y @ (scale * (D / (lam - sigma)))
+    if cols is None:
+        return -factor(B @ V @ Cf)
+    out = np.zeros((n, N))
+    out[:, cols] = -factor(B @ (V @ Cf[:, cols]))
+    return out
 
 
 # --------------------------------------------------------------------------
@@ -459,9 +467,14 @@ def solve_shifted_lstsq(alpha, H, r):
 def sibk(
     Phib, A, B, lam, Phi, mode="normal", psi=None, sigma=None, factor=None,
     rtol=1e-10, atol=1e-30, eig_atol=1e-5, maxiter=50, bs_target=1,
-    update_guess=False, callback=None, nrestart=2,
+    update_guess=False, callback=None, nrestart=2, modes=None,
 ):
+    """ref 1052-1328.  ``modes`` (not in the reference; bs_target=1, update_guess=False only): solve only the listed
+    modes -- projector, G and the correction still use all N eigenvectors, the other columns of psi are left as given
+    (bench.py times a bounded sample of the modes on the CPU)."""
     n, N = _check_iter_args(Phib, A, B, lam, Phi, psi, mode)
+    if modes is not None and (bs_target != 1 or update_guess):
+        raise ValueError("modes= needs bs_target=1 and update_guess=False")
     if factor is None:
         factor, sigma = _default_factor(A, B, lam, sigma, mode)
     rnorm0 = np.sqrt(np.max(np.sum(Phib**2, axis=0)))
@@ -473,16 +486,28 @@ def sibk(
     K = B if mode == "normal" else A  # Krylov operator is P K factor (ref 1249-1252)
     sgn = 1.0 if mode == "normal" else -1.0  # ref 1265-1268
 
-    if mode == "normal":
-        R = -Phib - (A @ _psi - (B @ _psi) * lam)
+    if modes is None:
+        if mode == "normal":
+            R = -Phib - (A @ _psi - (B @ _psi) * lam)
+        else:
+            R = -Phib - (B @ _psi + (A @ _psi) * lam)
+        R = project(BPhi, Phi, R)
     else:
-        R = -Phib - (B @ _psi + (A @ _psi) * lam)
-    R = project(BPhi, Phi, R)
+        sel = np.asarray(modes)
+        R = np.zeros((n, N))
+        if mode == "normal":
+            Rs = -Phib[:, sel] - (A @ _psi[:, sel] - (B @ _psi[:, sel]) * lam[sel])
+        else:
+            Rs = -Phib[:, sel] - (B @ _psi[:, sel] + (A @ _psi[:, sel]) * lam[sel])
+        R[:, sel] = project(BPhi, Phi, Rs)
 
     info = []
     i = 0
     restart = 0
     while i < N:
+        if modes is not None and i not in modes:
+            i += 1
+            continue
         r = np.zeros((maxiter + bs_target, bs_target))
         bs = 0
         while i + bs < N and bs < bs_target:

@@ -385,16 +385,12 @@ import numpy as np
 sys.path.insert(0, os.environ["EIGD_ROOT"]); sys.path.insert(0, os.path.join(os.environ["EIGD_ROOT"], "tests"))
 import torch, torch.distributed as dist      # torch first: one HIP runtime for torch and libeigd_hip.so
 backend = os.environ["EIGD_TEST_BACKEND"]
-if backend == "nccl":
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-else:
-    dist.init_process_group("gloo")
+dist.init_process_group("gloo")
 os.environ["EIGD_DEVICE"] = "0"
 import eigd_amd as eg
 from eigd_amd.comm import TorchDistComm
 from conftest import csr_from, load_golden
-comm = TorchDistComm(device=torch.device("cuda", 0) if backend == "nccl" else "cpu")
+comm = TorchDistComm(device="cpu")
 g = load_golden("g4_laplace900_basiclanczos")
 K, M = csr_from(g, "K"), csr_from(g, "M")
 fac = eg.SpLuOperator((K + 0.1 * M).tocsc())
@@ -442,9 +438,78 @@ def test_two_rank_gpu_sharding_gloo(tmp_path):
     _run_ranks(tmp_path, 2, "gloo", 29531)
 
 
-def test_one_rank_rccl_allreduce_path(tmp_path):
-    """the bench's multi-GPU plumbing with RCCL (nccl backend) at world size 1: torch and libeigd_hip.so in one process"""
-    _run_ranks(tmp_path, 1, "nccl", 29532)
+def test_rccl_allreduce_through_the_c_abi(tmp_path):
+    """
+    eigd_comm_unique_id / eigd_comm_init / eigd_allreduce_sum / eigd_allreduce_max (include/eigd_hip.h) on the ranks this
+    box offers: librccl is bound at run time, a communicator is created from the 128-byte id exactly as the rank
+    processes of bench.py do (file rendezvous), the df/dx reduction runs in place on a device vector.  With one GPU
+    this is a world of one rank (RCCL refuses two ranks on the same device); the sum over more ranks is the same call.
+    """
+    import ctypes as C
+    import os
+
+    import eigd_amd as eg
+    from eigd_amd import _ffi
+    from eigd_amd.comm import RcclComm, exchange_unique_id
+    from eigd_amd.device import default_context
+
+    ctx = default_context()
+    buf = C.create_string_buffer(128)
+    _ffi.call("eigd_comm_unique_id", buf)                       # loads librccl, asks it for an id
+    assert any(b != 0 for b in buf.raw)
+    os.environ["EIGD_COMM_DIR"] = str(tmp_path)
+    try:
+        uid = exchange_unique_id(0, 1, lambda: buf.raw, tag="t")
+        assert uid == buf.raw and (tmp_path / "t.bin").read_bytes() == buf.raw
+        h = _ffi.c_vp()
+        _ffi.call("eigd_comm_init", ctx.h, 1, 0, uid, C.byref(h))   # a real ncclCommInitRank when nranks > 1
+        nr, rk = C.c_int(), C.c_int()
+        _ffi.call("eigd_comm_info", h, C.byref(nr), C.byref(rk))
+        assert (nr.value, rk.value) == (1, 0)
+        _ffi.lib().eigd_comm_destroy(h)
+        with pytest.raises(ValueError):
+            _ffi.call("eigd_comm_init", ctx.h, 2, 5, uid, C.byref(h))
+        comm = RcclComm(ctx, rank=0, size=1)
+    finally:
+        del os.environ["EIGD_COMM_DIR"]
+    x = np.random.default_rng(0).normal(size=1000)
+    d = ctx.from_host(x)
+    assert comm.allreduce_sum(d) is d and np.array_equal(d.get()[:, 0], x)
+    assert np.array_equal(comm.allreduce_sum(x), x) and comm.allreduce_max(3.5) == 3.5
+    comm.barrier()
+    # the sharded derivative with this communicator equals the unsharded one
+    g = load_golden("g4_laplace900_basiclanczos")
+    K, M = csr_from(g, "K"), csr_from(g, "M")
+    fac = eg.SpLuOperator((K + 0.1 * M).tocsc())
+    s = eg.BasicLanczos(N=6, m=60)
+    s.solve(K, M, fac, -0.1)
+    rng = np.random.default_rng(2)
+    Ca, Cb = rng.normal(size=(K.shape[0], 9)), rng.normal(size=(K.shape[0], 9))
+    psi, data = s.solve_adjoint(g["Phib"], method="sibk", rtol=1e-12)
+    ref = s.add_total_derivative(g["lamb"], g["Phib"], psi, _mock_cb(Ca), _mock_cb(Cb), np.zeros(9), adj_corr_data=data,
+                                 deriv_type="tensor")
+    psi_r, data_r = s.solve_adjoint(g["Phib"], method="sibk", rtol=1e-12, comm=comm)
+    out = s.add_total_derivative(g["lamb"], g["Phib"], psi_r, _mock_cb(Ca), _mock_cb(Cb), np.zeros(9), adj_corr_data=data_r,
+                                 deriv_type="tensor", comm=comm)
+    assert relerr(out, ref) < 1e-13
+    comm.close()
+
+
+def test_bench_launcher_starts_rank_processes(tmp_path):
+    """`python bench.py --gpus N` starts its own rank processes before touching the GPU and relays rank 0's line"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-launch", "--nx", "60", "--ny", "60",
+           "--modes", "4", "--m", "20", "--steps", "1", "--warmup", "0", "--cpu-sample", "none", "--no-fd-check",
+           "--numpy-steps", "0", "--spmv-reps", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["modes"] == 4
 
 
 def _fd_functional(lam, Phi, lamb, Phib, Phi_ref, mode):

@@ -126,3 +126,39 @@ def test_g1_buckling_chain_with_path_adjoint(solver):
         assert relerr(flt.apply_gradient(hs.ks_gradient(g["BLF"], g["Phi"], float(g["ks_rho"])), g["x"]), g["ks_grad"]) < TOL
         assert abs(g["f"] @ g["u"] - float(g["compliance"])) < 1e-13 * abs(float(g["compliance"]))
         assert relerr(flt.apply_gradient(hs.compliance_gradient(), g["x"]), g["compliance_grad"]) < TOL
+
+
+def test_g3_noise_floor_of_the_repeated_branch():
+    """
+    Conditioning of the reference's own formula on the epsilon = 1e-8 case: xi, eta divide the rounding error of
+    G = -Phi^T Phib by the gap (1e-7) of a numerically repeated pair.  Forming the same G with another summation order
+    (einsum instead of the BLAS product; both are correctly rounded dot products to a few ulp) moves the reference
+    algorithm's df/dx by more than 1e-9 relative -- the level at which GPU-vs-reference differences of this case are
+    judged (tests/test_gpu_derivatives.py::test_g3_thermal_repeated_branch_rhoEb).
+    """
+    g = load_golden("g3_thermal32_eps1e-8_basiclanczos")
+    tab = fe.Q4Tables(g["conn"], g["X"])
+    rhoE, p = g["rhoE"], float(g["p"])
+    kappa, beta, hc, dens = float(g["kappa"]), float(g["th_beta"]), float(g["heat_capacity"]), float(g["density"])
+    cbA = lambda w, v: fe.thermal_stiffness_deriv(tab, rhoE, p, kappa, beta, w, v)  # noqa: E731
+    cbB = lambda w, v: fe.thermal_mass_deriv(tab, hc, dens, beta, w, v)              # noqa: E731
+    ref_data = corr_from(g, "corr")
+    # undo the reference's correction along the eigenvectors to get back its converged psi, then redo it with each G
+    lam, Phi, Qb = g["lam"], g["Phi"], g["Qb"]
+    out = []
+    for G in (-(Phi.T @ Qb), -np.einsum("ki,kj->ij", Phi, Qb), -(Qb.T @ Phi).T):
+        psi = g["psi"].copy()
+        G_blas = -(Phi.T @ Qb)
+        undo = orc.generate_adjoint_correction(lam, Phi, np.zeros_like(psi), G=G_blas, mode="normal")
+        base = np.zeros_like(psi)
+        orc.generate_adjoint_correction(lam, Phi, base, G=G_blas, mode="normal")
+        psi -= base                                             # psi before the correction (distinct pairs only)
+        data = orc.generate_adjoint_correction(lam, Phi, psi, G=G, mode="normal")
+        assert {i: [t[0] for t in v] for i, v in data.items()} == {i: [t[0] for t in v] for i, v in ref_data.items()}
+        assert undo.keys() == data.keys()
+        out.append(orc.add_eig_total_derivative(lam, Phi, g["lamb"], Qb, psi, cbA, cbB, np.zeros(tab.nelems),
+                                                adj_corr_data=data, mode="normal", deriv_type="tensor"))
+    assert relerr(out[0], g["rhoEb"]) < 1e-10                    # the reference's own arithmetic reproduces its number
+    spread = max(relerr(out[1], out[0]), relerr(out[2], out[0]))
+    print(f"df/dx moves by {spread:.2e} under a change of summation order in G")
+    assert 1e-10 < spread < 1e-6
