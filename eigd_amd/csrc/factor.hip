@@ -1154,8 +1154,8 @@ __global__ __launch_bounds__(64) void bwd_wave_kernel(FrontArrays fa, const WgRe
 // wave needs is requested in one or two rounds, and 12 to 16 waves per CU are in flight.
 //
 // forward: wave = 16-row blocks rb, rb + 2, ... of [T; M21] (two waves per front).  K = own columns (NKS steps of 4).
-template <int KB, int NKS, int NSL>
-__global__ __launch_bounds__(128) void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
+template <int KB, int NKS, int NSL, int WPF>  // WPF: waves per front (1: the right-hand side block is loaded once per front)
+__global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
                                                        const double* __restrict__ F, const double* __restrict__ Tb,
                                                        const double* X, int ldx, double alpha, double* V,
                                                        double* __restrict__ Y, int kb) {
@@ -1199,14 +1199,17 @@ __global__ __launch_bounds__(128) void fwd_thin_kernel(FrontArrays fa, const WgR
 #pragma unroll
   for (int q = 0; q < 6; ++q)
     M[q] = (NSL > 0) ? *((mreg && 64 * q + lane < d) ? fa.cmask + vbase + 64 * q + lane : reinterpret_cast<const int*>(fa.zero)) : 0;
-  for (int rb = wave; rb < nrb; rb += 2) {
+  for (int rb = wave; rb < nrb; rb += WPF) {
     const int r = 16 * rb + li;  // the row this lane feeds as A operand
+    // a block of 16 own rows meets only zeros of T past its diagonal block (T is lower triangular): those K-steps
+    // read the zero word instead of streaming zeros from HBM (wave-uniform bound)
+    const int smax = (16 * rb + 16 <= ns) ? 4 * (rb + 1) : NKS;
     double a[NKS];
 #pragma unroll
     for (int s = 0; s < NKS; ++s) {
       const int o = 4 * s + lk;
       const double* p = (r < ns) ? Tf + static_cast<int64_t>(o) * w.ldt + r : Ff + static_cast<int64_t>(o) * d + r;
-      a[s] = *((o < ns && r < d) ? p : fa.zero);
+      a[s] = *((o < ns && r < d && s < smax) ? p : fa.zero);
     }
     // what the results meet: lane (reg, nb) <-> row 16 rb + lk + 4 reg, column 16 nb + li
     int di[4], mk[4];
@@ -1619,9 +1622,22 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
       const int nks = f->h_thin_fwd[l];
       if (!narrow && nwave > 0 && nks > 0) {  // thin fronts: one wave per block of rows, operands straight from memory
         const WgRec* recs = f->d_wave_wg + f->h_wave_ptr[l];
-#define EIGD_THIN_FWD(NKS, NSLV)                                                                                       \
-  hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV>), dim3(nwave), dim3(128), 0, st, fa, recs, sF, sT, dIn, ldin, alpha, \
-                     wV, wY, kb)
+        // waves per front: with one, the front's right-hand side block (and its carries) is loaded once instead of
+        // once per wave (measured on C3, 32 columns: 1.654 -> 1.606 ms per sweep; EIGD_THIN_WPF=2 restores two)
+        static const int thin_wpf = [] {
+          const char* v = std::getenv("EIGD_THIN_WPF");
+          return (v && *v) ? std::atoi(v) : 1;
+        }();
+        const bool one = thin_wpf != 2;
+#define EIGD_THIN_FWD(NKS, NSLV)                                                                                        \
+  do {                                                                                                                  \
+    if (one)                                                                                                            \
+      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1>), dim3(nwave), dim3(64), 0, st, fa, recs, sF, sT, dIn, ldin,  \
+                         alpha, wV, wY, kb);                                                                            \
+    else                                                                                                                \
+      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 2>), dim3(nwave), dim3(128), 0, st, fa, recs, sF, sT, dIn, ldin, \
+                         alpha, wV, wY, kb);                                                                            \
+  } while (0)
         if (leaf && nks == 4)
           EIGD_THIN_FWD(4, 0);
         else if (leaf && nks == 8)

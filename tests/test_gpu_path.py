@@ -82,7 +82,7 @@ def test_g1_buckling_basiclanczos_full_chain():
     psi, data = s.solve_adjoint(Qrb, method="sibk", rtol=1e-10, update_guess=False, bs_target=1,
                                 callback=res_hist.append)
     assert index_sets(data) == index_sets(corr_from(g, "corr"))
-    assert relerr(psi * sg, g["psir"]) < 1e-7
+    assert relerr(psi * sg, g["psir"]) < RTOL          # (measured 6e-14 .. 5e-11: tools/tol_probe.py)
     assert abs(factor.count - int(g["count_adjoint"])) <= 12  # applications per mode; reported, loosely gated
     assert len(res_hist) > 0
     res, ortho = s.eval_adjoint_residual_norm(Qrb, psi, b_ortho=False)
@@ -128,7 +128,7 @@ def test_g2_normal_mode_with_rigid_body_modes():
     _adopt_reference_lanczos(s, g)
     psi0, data = s.solve_adjoint(g["Q0b"], method="sibk", rtol=1e-10, update_guess=False, bs_target=1)
     assert index_sets(data) == index_sets(corr_from(g, "corr"))
-    assert relerr(psi0[:, 3:], g["psi"]) < 1e-7
+    assert relerr(psi0[:, 3:], g["psi"]) < RTOL
 
 
 @pytest.mark.parametrize("mode", ["normal", "buckling"])
@@ -141,7 +141,7 @@ def test_g4_method_matrix_basiclanczos(mode):
     s, factor, Phi_a, sg = _solve_basic(g, A, B, sigma, mode, prefix=p, N=6, m=60)
     assert s.m == int(g[p + "m"])
     _adopt_reference_lanczos(s, g, p)
-    for method, tol in (("laa", 1e-9), ("sibk", RTOL), ("pcpg", 1e-7), ("pgmres", RTOL), ("dl", RTOL)):
+    for method, tol in (("laa", 1e-9), ("sibk", RTOL), ("pcpg", RTOL), ("pgmres", RTOL), ("dl", RTOL)):
         if method != "laa" and g[p + method + "_res"].max() > 1e-6:
             continue  # not converged in the reference itself: nothing to pin
         kw = {"update_guess": False, "bs_target": 1} if method == "sibk" else {}
@@ -183,7 +183,7 @@ def test_iram_eigenpairs_lanczos_relation_and_adjoint(mode):
     assert np.linalg.norm(V.T @ (B @ V) - np.eye(s.m)) < 1e-10
     assert np.allclose(T, T.T)
     psi, data = s.solve_adjoint(g["Phib"] * sg, method="sibk", rtol=1e-12, update_guess=False, bs_target=1)
-    assert relerr(psi * sg, g[p + "sibk_psi"]) < 1e-7
+    assert relerr(psi * sg, g[p + "sibk_psi"]) < RTOL
     psi_l, _ = s.solve_adjoint(g["Phib"] * sg, method="laa")
     res, _ = s.eval_adjoint_residual_norm(g["Phib"] * sg, psi_l)
     assert np.all(np.isfinite(res))
@@ -203,7 +203,7 @@ def test_iram_g1_buckling_eigenvalues():
     Phi_a, sg = align_signs(Phi, g["Phi"])
     psi, data = s.solve_adjoint(g["Qrb"] * sg, method="sibk", rtol=1e-10, update_guess=False, bs_target=1)
     assert index_sets(data) == index_sets(corr_from(g, "corr"))
-    assert relerr(psi * sg, g["psir"]) < 1e-7
+    assert relerr(psi * sg, g["psir"]) < RTOL
 
 
 @pytest.mark.parametrize("tag", ["distinct", "repeated"])
