@@ -84,7 +84,7 @@ _SIGNATURES = {
     "eigd_assembler_free": [c_vp],
     "eigd_assembler_nnz": [c_vp, c_vp],
     "eigd_assembler_pattern": [c_vp, c_vp, c_vp],
-    "eigd_assemble": [c_vp, c_vp, c_int, c_vp, c_vp],
+    "eigd_assemble": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp],
     "eigd_elem_linear_matrices": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp],
     "eigd_colnorm2_dev": [c_vp, c_int, c_int, c_vp, c_int, c_vp],
     "eigd_colnorm2_fetch": [c_vp, c_vp, c_int],
@@ -92,7 +92,8 @@ _SIGNATURES = {
     "eigd_copy_block": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_gather_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
     "eigd_scatter_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
-    "eigd_elem_bilinear": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl, c_vp],
+    "eigd_elem_bilinear": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl,
+                           c_vp],
     "eigd_elem_linear_adjoint": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int,
                                  c_dbl, c_vp],
     "eigd_design_map": [c_vp, c_i64, c_int, c_dbl, c_dbl, c_dbl, c_vp, c_vp, c_vp],

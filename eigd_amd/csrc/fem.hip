@@ -20,9 +20,10 @@ namespace eigd {
 __device__ const double g_zero_fem = 0.0;
 __device__ const int32_t g_minus_one = -1;
 
-template <int KP>
+template <int KP, int ND>  // ND: dofs per element compiled in (8: the Q4 plane / thermal elements, 24: 6-dof shell facets)
 __global__ __launch_bounds__(kThreads) void elem_bilinear_kernel(int nelem, int nd, const int32_t* __restrict__ edofs,
                                                                 const double* __restrict__ Me, int per_elem,
+                                                                const int32_t* __restrict__ etype,
                                                                 const double* __restrict__ scale,
                                                                 const double* __restrict__ W, int ldw,
                                                                 const double* __restrict__ V, int ldv, int k,
@@ -31,25 +32,32 @@ __global__ __launch_bounds__(kThreads) void elem_bilinear_kernel(int nelem, int 
   const int c = threadIdx.x % KP;
   const int el = blockIdx.x * EPB + threadIdx.x / KP;
   const bool valid = (el < nelem) && (c < k);
-  // all element dofs first, then all sixteen gathers: two memory latencies per element instead of sixteen
+  // all element dofs first, then all the gathers: two memory latencies per element instead of one per dof
   // (masked lanes read a zero word through address select; a branch around a load serialises the loads)
-  double w[8], v[8];
-  int dofs[8];
+  double w[ND], v[ND];
+  int dofs[ND];
   const int32_t* ed = edofs + static_cast<int64_t>(valid ? el : 0) * nd;
 #pragma unroll
-  for (int a = 0; a < 8; ++a) dofs[a] = *((valid && a < nd) ? ed + a : &g_minus_one);
+  for (int a = 0; a < ND; ++a) dofs[a] = *((valid && a < nd) ? ed + a : &g_minus_one);
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
+  for (int a = 0; a < ND; ++a) {
     w[a] = *((dofs[a] >= 0) ? W + static_cast<int64_t>(dofs[a]) * ldw + c : &g_zero_fem);
     v[a] = *((dofs[a] >= 0) ? V + static_cast<int64_t>(dofs[a]) * ldv + c : &g_zero_fem);
   }
   double s = 0.0;
   if (valid) {
-    const double* M = Me + (per_elem ? static_cast<int64_t>(el) * nd * nd : 0);
-    for (int a = 0; a < nd; ++a) {
-      double t = 0.0;
-      for (int b = 0; b < nd; ++b) t += M[a * nd + b] * v[b];
-      s += w[a] * t;
+    // per_elem 0: one shared matrix; 1: a matrix per element; 2: a matrix per element TYPE (etype[e])
+    const int64_t which = (per_elem == 1) ? el : (per_elem == 2 ? etype[el] : 0);
+    const double* M = Me + which * nd * nd;
+#pragma unroll
+    for (int a = 0; a < ND; ++a) {
+      if (a < nd) {
+        double t = 0.0;
+#pragma unroll
+        for (int b = 0; b < ND; ++b)
+          if (b < nd) t += M[a * nd + b] * v[b];
+        s += w[a] * t;
+      }
     }
   }
 #pragma unroll
@@ -63,6 +71,7 @@ __global__ __launch_bounds__(kThreads) void elem_bilinear_kernel(int nelem, int 
 __global__ __launch_bounds__(kThreads) void assemble_gather_kernel(int64_t nnz, const int32_t* __restrict__ nz_ptr,
                                                                   const int32_t* __restrict__ nz_src, int nd2,
                                                                   const double* __restrict__ Me, int per_elem,
+                                                                  const int32_t* __restrict__ etype,
                                                                   const double* __restrict__ scale,
                                                                   double* __restrict__ vals) {
   for (int64_t z = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; z < nnz;
@@ -71,7 +80,8 @@ __global__ __launch_bounds__(kThreads) void assemble_gather_kernel(int64_t nnz, 
     for (int q = nz_ptr[z]; q < nz_ptr[z + 1]; ++q) {
       const int src = nz_src[q];
       const int e = src / nd2, ab = src - e * nd2;
-      const double m = Me[(per_elem ? static_cast<int64_t>(e) * nd2 : 0) + ab];
+      const int64_t which = (per_elem == 1) ? e : (per_elem == 2 ? etype[e] : 0);
+      const double m = Me[which * nd2 + ab];
       sum += (scale ? scale[e] : 1.0) * m;
     }
     vals[z] = sum;
@@ -235,7 +245,7 @@ extern "C" int eigd_assembler_free(eigd_assembler* a) {
 extern "C" int eigd_assembler_create(eigd_ctx* ctx, int n, int nelem, int nd, const int32_t* elem_dofs,
                                      eigd_assembler** out) {
   EIGD_REQUIRE(ctx && elem_dofs && out, "null argument");
-  EIGD_REQUIRE(n > 0 && nelem > 0 && nd >= 1 && nd <= 8, "bad shape n=%d nelem=%d nd=%d", n, nelem, nd);
+  EIGD_REQUIRE(n > 0 && nelem > 0 && nd >= 1 && nd <= 24, "bad shape n=%d nelem=%d nd=%d", n, nelem, nd);
   *out = nullptr;
   const int nd2 = nd * nd;
   EIGD_REQUIRE(static_cast<int64_t>(nelem) * nd2 < (int64_t(1) << 31), "too many element entries");
@@ -306,29 +316,36 @@ extern "C" int eigd_assembler_pattern(eigd_assembler* a, int32_t* hindptr, int32
   return EIGD_OK;
 }
 
-extern "C" int eigd_assemble(eigd_assembler* a, const double* dMe, int per_elem, const double* dscale, double* dvals) {
+extern "C" int eigd_assemble(eigd_assembler* a, const double* dMe, int per_elem, const int32_t* d_etype,
+                             const double* dscale, double* dvals) {
   EIGD_REQUIRE(a && dMe && dvals, "null argument");
+  EIGD_REQUIRE(per_elem >= 0 && per_elem <= 2 && (per_elem != 2 || d_etype), "per_elem = 2 needs the element types");
   if (a->nnz == 0) return EIGD_OK;
   const int nb = static_cast<int>(std::min<int64_t>((a->nnz + kThreads - 1) / kThreads, 65536));
   hipLaunchKernelGGL(assemble_gather_kernel, dim3(nb), dim3(kThreads), 0, a->ctx->stream, a->nnz, a->d_nz_ptr, a->d_nz_src,
-                     a->nd * a->nd, dMe, per_elem, dscale, dvals);
+                     a->nd * a->nd, dMe, per_elem, d_etype, dscale, dvals);
   EIGD_LAUNCH_CHECK();
   return EIGD_OK;
 }
 
 extern "C" int eigd_elem_bilinear(eigd_ctx* ctx, int nelem, int nd, const int32_t* d_edofs, const double* dMe,
-                                  int per_elem, const double* dscale, const double* dW, int ldw, const double* dV,
-                                  int ldv, int k, double alpha, double* dOut) {
+                                  int per_elem, const int32_t* d_etype, const double* dscale, const double* dW, int ldw,
+                                  const double* dV, int ldv, int k, double alpha, double* dOut) {
   EIGD_REQUIRE(ctx && d_edofs && dMe && dW && dV && dOut, "null argument");
-  EIGD_REQUIRE(nelem > 0 && nd >= 1 && nd <= 8 && k >= 1 && k <= kMaxK && ldw >= k && ldv >= k,
+  EIGD_REQUIRE(nelem > 0 && nd >= 1 && nd <= 24 && k >= 1 && k <= kMaxK && ldw >= k && ldv >= k,
                "bad shape nelem=%d nd=%d k=%d", nelem, nd, k);
+  EIGD_REQUIRE(per_elem >= 0 && per_elem <= 2 && (per_elem != 2 || d_etype), "per_elem = 2 needs the element types");
   const int kp = next_pow2(k);
   const int epb = kThreads / kp;
   const dim3 grid((nelem + epb - 1) / epb);
 #define EIGD_EB_CASE(KP)                                                                                             \
   case KP:                                                                                                           \
-    hipLaunchKernelGGL(elem_bilinear_kernel<KP>, grid, dim3(kThreads), 0, ctx->stream, nelem, nd, d_edofs, dMe,      \
-                       per_elem, dscale, dW, ldw, dV, ldv, k, alpha, dOut);                                          \
+    if (nd <= 8)                                                                                                     \
+      hipLaunchKernelGGL((elem_bilinear_kernel<KP, 8>), grid, dim3(kThreads), 0, ctx->stream, nelem, nd, d_edofs, dMe, \
+                         per_elem, d_etype, dscale, dW, ldw, dV, ldv, k, alpha, dOut);                               \
+    else                                                                                                             \
+      hipLaunchKernelGGL((elem_bilinear_kernel<KP, 24>), grid, dim3(kThreads), 0, ctx->stream, nelem, nd, d_edofs, dMe, \
+                         per_elem, d_etype, dscale, dW, ldw, dV, ldv, k, alpha, dOut);                               \
     break;
   switch (kp) {
     EIGD_EB_CASE(1)

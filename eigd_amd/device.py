@@ -666,13 +666,25 @@ class ElementBilinear:
 
     device = True
 
-    def __init__(self, ctx, elem_dofs, Me, scale=None):
+    def __init__(self, ctx, elem_dofs, Me, scale=None, etype=None):
         elem_dofs = np.ascontiguousarray(elem_dofs, dtype=np.int32)
         self.ctx = ctx
         self.nelem, self.nd = elem_dofs.shape
         self._dofs = _Buffer(ctx, elem_dofs.nbytes)
         call("eigd_h2d", ctx.h, c_vp(self._dofs.ptr), hptr(elem_dofs), elem_dofs.nbytes)
-        if isinstance(Me, DeviceBlock):  # per-element matrices made on the device (ElementLinearMatrices)
+        self._etype = None
+        if etype is not None:  # Me holds one matrix per element TYPE, etype[e] selects
+            etype = np.ascontiguousarray(etype, dtype=np.int32)
+            Me = np.ascontiguousarray(Me, dtype=np.float64)
+            if etype.shape != (self.nelem,) or Me.ndim != 3 or Me.shape[1:] != (self.nd, self.nd) or (
+                    self.nelem and (etype.min() < 0 or etype.max() >= Me.shape[0])):
+                raise ValueError("element types do not match the matrices")
+            self._etype = _Buffer(ctx, etype.nbytes)
+            call("eigd_h2d", ctx.h, c_vp(self._etype.ptr), hptr(etype), etype.nbytes)
+            self.per_elem = 2
+            self._Me = _Buffer(ctx, Me.nbytes)
+            call("eigd_h2d", ctx.h, c_vp(self._Me.ptr), hptr(Me), Me.nbytes)
+        elif isinstance(Me, DeviceBlock):  # per-element matrices made on the device (ElementLinearMatrices)
             if Me.n * Me.k != self.nelem * self.nd * self.nd or Me.ld != Me.k:
                 raise ValueError("element matrix block does not match the dof list")
             self.per_elem, self._Me = 1, Me
@@ -710,7 +722,7 @@ class ElementBilinear:
         for c0 in range(0, W.k, 64):
             c1 = min(W.k, c0 + 64)
             call("eigd_elem_bilinear", self.ctx.h, self.nelem, self.nd, c_vp(self._dofs.ptr), self._p(self._Me),
-                 self.per_elem, sp, W.cols(c0, c1).ptr, W.ld, V.cols(c0, c1).ptr, V.ld, c1 - c0, float(alpha), out.ptr)
+                 self.per_elem, c_vp(self._etype.ptr) if self._etype is not None else c_vp(None), sp, W.cols(c0, c1).ptr, W.ld, V.cols(c0, c1).ptr, V.ld, c1 - c0, float(alpha), out.ptr)
         return out
 
     def __call__(self, W, V):
@@ -721,6 +733,41 @@ class ElementBilinear:
         out = self.ctx.zeros(self.nelem, 1)
         self.accumulate(W, V, out)
         return out.get()[:, 0]
+
+
+class GroupedElementDerivative:
+    """
+    Device callback for design variables that scale GROUPS of elements (wall thicknesses of panels, examples/crm.py
+    style): ``cb(W, V)[g] = sum_{e in g} sum_parts part(W, V)[e]`` with ElementBilinear parts; ``accumulate`` adds into a
+    device vector of ngroups entries (fixed summation order: a CSR product with the group incidence matrix).
+    """
+
+    device = True
+
+    def __init__(self, ctx, parts, group_of_element, ngroups):
+        from scipy import sparse
+
+        self.ctx, self.parts = ctx, list(parts)
+        group_of_element = np.asarray(group_of_element, dtype=np.int64)
+        self.nel = len(group_of_element)
+        if any(p.nelem != self.nel for p in self.parts):
+            raise ValueError("parts and groups disagree on the number of elements")
+        self.nout = self.nelem = int(ngroups)
+        self._map = CSRMatrix(ctx, sparse.csr_matrix((np.ones(self.nel), (group_of_element, np.arange(self.nel))),
+                                                     shape=(self.nout, self.nel)))
+
+    def accumulate(self, W, V, out, alpha=1.0):
+        tmp = self.ctx.zeros(self.nel, 1)
+        for part in self.parts:
+            part.accumulate(W, V, tmp)
+        self._map.apply(tmp, out, alpha=float(alpha), beta=1.0)
+        return out
+
+    def __call__(self, W, V):
+        if not isinstance(W, DeviceBlock):
+            W = self.ctx.from_host(np.asarray(W, dtype=np.float64).reshape(np.shape(W)[0], -1))
+            V = self.ctx.from_host(np.asarray(V, dtype=np.float64).reshape(np.shape(V)[0], -1))
+        return self.accumulate(W, V, self.ctx.zeros(self.nout, 1)).get()[:, 0]
 
 
 class ElementAssembler:
@@ -762,18 +809,20 @@ class ElementAssembler:
         call("eigd_assembler_pattern", self.h, hptr(ip), hptr(ix))
         return sparse.csr_matrix((np.zeros(self.nnz), ix[: self.nnz], ip), shape=(self.n, self.n))
 
-    def _upload(self, key, arr):
+    def _upload(self, key, arr, dtype=np.float64):
         """element matrices / scale factors are uploaded once per distinct host array"""
         ent = self._cache.get(key)
         if ent is None or ent[0] is not arr:
-            a = np.ascontiguousarray(arr, dtype=np.float64)
+            a = np.ascontiguousarray(arr, dtype=dtype)
             buf = _Buffer(self.ctx, max(a.nbytes, 8))
             call("eigd_h2d", self.ctx.h, c_vp(buf.ptr), hptr(a), a.nbytes)
             ent = (arr, buf)
+            if len(self._cache) >= 8:  # a handful of distinct operands per assembler (K, G, their parts): drop the oldest
+                self._cache.pop(next(iter(self._cache)))
             self._cache[key] = ent
         return ent[1]
 
-    def assemble(self, Me, scale=None, out=None):
+    def assemble(self, Me, scale=None, out=None, etype=None):
         """
         CSR values (device block nnz x 1) of sum_e scale[e] P_e^T Me P_e; Me: (nd, nd) shared or (nelem, nd, nd) numpy
         array, or a device block of nelem * nd * nd doubles (per-element matrices made on the device)
@@ -784,11 +833,18 @@ class ElementAssembler:
             sp = scale.ptr if isinstance(scale, DeviceBlock) else (
                 c_vp(None) if scale is None else c_vp(self._upload("scale", scale).ptr))
             vals = out if out is not None else self.ctx.empty(max(self.nnz, 1), 1)
-            call("eigd_assemble", self.h, Me.ptr, 1, sp, vals.ptr)
+            call("eigd_assemble", self.h, Me.ptr, 1, c_vp(None), sp, vals.ptr)
             return vals
         Me = np.asarray(Me, dtype=np.float64)
         per_elem = 1 if Me.ndim == 3 else 0
-        if Me.shape[-2:] != (self.nd, self.nd) or (per_elem and Me.shape[0] != self.nelem):
+        tp = c_vp(None)
+        if etype is not None:  # one matrix per element type
+            et = np.asarray(etype)
+            if Me.ndim != 3 or et.shape != (self.nelem,) or et.min() < 0 or et.max() >= Me.shape[0]:
+                raise ValueError("element types do not match the matrices")
+            per_elem = 2
+            tp = c_vp(self._upload("etype", etype, np.int32).ptr)
+        if Me.shape[-2:] != (self.nd, self.nd) or (per_elem == 1 and Me.shape[0] != self.nelem):
             raise ValueError("element matrix shape does not match the dof list")
         if isinstance(scale, DeviceBlock):
             sp = scale.ptr
@@ -799,7 +855,7 @@ class ElementAssembler:
                 raise ValueError("one scale factor per element expected")
             sp = c_vp(self._upload("scale", scale).ptr)
         vals = out if out is not None else self.ctx.empty(max(self.nnz, 1), 1)
-        call("eigd_assemble", self.h, c_vp(self._upload("Me", Me).ptr), per_elem, sp, vals.ptr)
+        call("eigd_assemble", self.h, c_vp(self._upload(("Me", id(Me)), Me).ptr), per_elem, tp, sp, vals.ptr)
         return vals
 
     def values_to_host(self, vals):

@@ -263,3 +263,196 @@ class ThermalPlate:
 
     def dof_coords(self):
         return self.mesh.X
+
+
+class ShellBox:
+    """
+    Stand-in for the reference's CRM wingbox configuration (BASELINE configs[4]; examples/crm.py needs TACS and a mesh
+    file that are not available, SURVEY.md 8d "C5"): a thin-walled box beam of flat-shell Q4 facets on a closed
+    3-D surface grid, 6 dof / node (3 translations, 3 rotations), clamped at the root.
+
+      K(t) = sum_e t_e (K_membrane + K_shear + K_drill)_e + t_e^3 (K_bending)_e        (Mindlin facet in its panel frame)
+      G(t) = sum_e t_e sigma_e (G_xx)_e       geometric stiffness of a prescribed bending pre-stress: the upper skin in
+                                              compression, growing towards the root (an up-bending wing)
+      (K + lam G) phi = 0,   design variables: one wall thickness per (panel, spanwise segment) group.
+
+    Four element types (upper skin, right spar, lower skin, left spar) differ by the rotation of the panel frame; the
+    device kernels take the type matrices and ``etype`` (no per-element matrices).  Everything here is vectorised numpy
+    set-up; assembly, factorisation, eigensolve, adjoint and derivative run on the device.
+    """
+
+    def __init__(self, nx, nw, nh, h=0.0125, t0=0.02, nseg=4, E=1.0, nu=0.3, sigma0=1e-4, seed=0, drill=0.1,
+                 shear_full=0.05):
+        self.nx, self.nw, self.nh, self.h, self.nseg = nx, nw, nh, h, nseg
+        nc = 2 * (nw + nh)
+        self.nc = nc
+        self.nnodes = (nx + 1) * nc
+        self.nelems = nx * nc
+        self.L, self.Wd, self.Hd = nx * h, nw * h, nh * h
+        # perimeter: upper skin (y: 0 -> W at z = H), right spar (z: H -> 0 at y = W), lower skin, left spar
+        s = np.arange(nc)
+        y = np.where(s < nw, s * h, np.where(s < nw + nh, self.Wd, np.where(s < 2 * nw + nh, (2 * nw + nh - s) * h, 0.0)))
+        z = np.where(s < nw, self.Hd, np.where(s < nw + nh, (nw + nh - s) * h,
+                                                np.where(s < 2 * nw + nh, 0.0, (s - 2 * nw - nh) * h)))
+        ii, jj = np.meshgrid(np.arange(nx + 1), s, indexing="ij")
+        self.X = np.stack([ii.ravel() * h, y[jj.ravel()], z[jj.ravel()]], axis=1)
+        ei, ej = np.meshgrid(np.arange(nx), s, indexing="ij")
+        ei, ej = ei.ravel(), ej.ravel()
+        node = lambda i, j: i * nc + (j % nc)  # noqa: E731
+        self.conn = np.stack([node(ei, ej), node(ei + 1, ej), node(ei + 1, ej + 1), node(ei, ej + 1)], axis=1)
+        self.etype = np.where(ej < nw, 0, np.where(ej < nw + nh, 1, np.where(ej < 2 * nw + nh, 2, 3))).astype(np.int32)
+        self.group = (self.etype * nseg + np.minimum(ei * nseg // nx, nseg - 1)).astype(np.int64)
+        self.ngroups = 4 * nseg
+        rng = np.random.default_rng(seed)
+        self.t = t0 * rng.uniform(0.8, 1.2, size=self.ngroups)
+        # pre-stress of the reference load at the element centres: -sigma0 on the upper skin at the root
+        zc = 0.25 * self.X[self.conn, 2].sum(axis=1)
+        xc = 0.25 * self.X[self.conn, 0].sum(axis=1)
+        self.sigma_e = -sigma0 * (1.0 - xc / self.L) * (zc - 0.5 * self.Hd) / (0.5 * self.Hd)
+        # dofs: 6 per node, root section clamped
+        nv = 6 * self.nnodes
+        fixed = np.zeros(nv, dtype=bool)
+        fixed[: 6 * nc] = True
+        self.free_map = np.where(fixed, -1, np.cumsum(~fixed) - 1)
+        self.reduced = np.flatnonzero(~fixed)
+        self.n = len(self.reduced)
+        full = (6 * self.conn[:, :, None] + np.arange(6)[None, None, :]).reshape(self.nelems, 24)
+        self.elem_dofs = self.free_map[full].astype(np.int32)
+        self._element_types(E, nu, drill, shear_full)
+
+    def _element_types(self, E, nu, drill, shear_full):
+        hx = hs = self.h
+        C0 = plane_stress_C0(E, nu)
+        Gs = (5.0 / 6.0) * E / (2.0 * (1.0 + nu))
+        Kl = np.zeros((24, 24))   # thickness-linear part: membrane + transverse shear + drilling
+        Kc = np.zeros((24, 24))   # thickness-cubic part: bending
+        Gx = np.zeros((24, 24))   # unit axial membrane stress acting on the three translations
+        iu, iv, iw, irx, iry, irz = (6 * np.arange(4) + c for c in range(6))
+
+        def shape(xi, eta):
+            N = 0.25 * np.array([(1 - xi) * (1 - eta), (1 + xi) * (1 - eta), (1 + xi) * (1 + eta), (1 - xi) * (1 + eta)])
+            Nx = 0.25 * np.array([-(1 - eta), (1 - eta), (1 + eta), -(1 + eta)]) * (2.0 / hx)
+            Ny = 0.25 * np.array([-(1 - xi), -(1 + xi), (1 + xi), (1 - xi)]) * (2.0 / hs)
+            return N, Nx, Ny
+
+        def shear_B(N, Nx, Ny):  # gamma = [w,x + theta_y ; w,y - theta_x]
+            Bs = np.zeros((2, 24))
+            Bs[0, iw], Bs[0, iry] = Nx, N
+            Bs[1, iw], Bs[1, irx] = Ny, -N
+            return Bs
+
+        detJ = 0.25 * hx * hs
+        for eta in GAUSS:
+            for xi in GAUSS:
+                N, Nx, Ny = shape(xi, eta)
+                Bm = np.zeros((3, 24))
+                Bm[0, iu], Bm[1, iv], Bm[2, iu], Bm[2, iv] = Nx, Ny, Ny, Nx
+                Kl += detJ * Bm.T @ C0 @ Bm
+                Bb = np.zeros((3, 24))  # curvatures of beta_x = theta_y, beta_y = -theta_x
+                Bb[0, iry], Bb[1, irx], Bb[2, iry], Bb[2, irx] = Nx, -Ny, Ny, -Nx
+                Kc += detJ * Bb.T @ (C0 / 12.0) @ Bb
+                Bs = shear_B(N, Nx, Ny)
+                Kl += shear_full * detJ * Gs * Bs.T @ Bs
+                for idx in (iu, iv, iw):
+                    Gx[np.ix_(idx, idx)] += detJ * np.outer(Nx, Nx)
+        N, Nx, Ny = shape(0.0, 0.0)                      # transverse shear: one-point rule (no locking)
+        Bs = shear_B(N, Nx, Ny)
+        Kl += (1.0 - shear_full) * (4.0 * detJ) * Gs * Bs.T @ Bs
+        Kl[irz, irz] += drill * E * hx * hs / 4.0        # drilling rotations: a small penalty keeps K definite
+        frames = [np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]]), np.array([[1.0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]]),
+                  np.array([[1.0, 0, 0], [0, -1.0, 0], [0, 0, -1.0]]), np.array([[1.0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]])]
+        self.K_lin, self.K_cub, self.G_xx = [], [], []
+        for T in frames:                                  # local = T global, for translations and rotations alike
+            R = np.kron(np.eye(8), T)
+            self.K_lin.append(R.T @ Kl @ R)
+            self.K_cub.append(R.T @ Kc @ R)
+            self.G_xx.append(R.T @ Gx @ R)
+        self.K_lin, self.K_cub, self.G_xx = (np.array(a) for a in (self.K_lin, self.K_cub, self.G_xx))
+
+    # ---- per-element factors of a thickness vector ---------------------------------------------------------
+    def scales(self, t=None):
+        te = (self.t if t is None else np.asarray(t))[self.group]
+        return te, te**3, te * self.sigma_e
+
+    def dof_coords(self):
+        return np.repeat(self.X, 6, axis=0)[self.reduced]
+
+    def assemble_host(self, t=None):
+        """K, G as scipy CSR (COO assembly on the host: for the small test sizes)"""
+        s1, s3, sg = self.scales(t)
+        Ke = s1[:, None, None] * self.K_lin[self.etype] + s3[:, None, None] * self.K_cub[self.etype]
+        Ge = sg[:, None, None] * self.G_xx[self.etype]
+        ed = self.elem_dofs.astype(np.int64)
+        rows = np.repeat(ed, 24, axis=1).ravel()
+        cols = np.tile(ed, (1, 24)).ravel()
+        keep = (rows >= 0) & (cols >= 0)
+        out = []
+        for Me in (Ke, Ge):
+            A = sparse.coo_matrix((Me.ravel()[keep], (rows[keep], cols[keep])), shape=(self.n, self.n)).tocsr()
+            A.sum_duplicates()
+            A.sort_indices()
+            out.append(A)
+        return out
+
+    def group_map(self):
+        """ngroups x nelems incidence matrix: sums element quantities into the design groups"""
+        return sparse.csr_matrix((np.ones(self.nelems), (self.group, np.arange(self.nelems))),
+                                 shape=(self.ngroups, self.nelems))
+
+
+class ShellBoxOnDevice:
+    """
+    The ShellBox design point on the device: typed element assembly of K(t), G(t) (eigd_assemble with one matrix per
+    element type), the shifted factor K + sigma G, and the derivative callbacks d(w^T K v)/dt_g, d(w^T G v)/dt_g as
+    element kernels summed into the thickness groups.
+    """
+
+    def __init__(self, box, ctx=None):
+        from .device import CSRMatrix, ElementAssembler, default_context
+        from .operators import SpLuOperator
+
+        self.box, self.ctx = box, (ctx if ctx is not None else default_context())
+        ctx = self.ctx
+        self.asm = ElementAssembler(ctx, box.elem_dofs, box.n)
+        pat = self.asm.pattern()
+        ones = sparse.csr_matrix((np.ones(pat.nnz), pat.indices, pat.indptr), shape=pat.shape) \
+            + sparse.identity(box.n, format="csr") * (10.0 * 24 * 9)
+        ones.sort_indices()
+        if ones.nnz != pat.nnz:
+            raise ValueError("every dof needs a diagonal entry in the assembled pattern")
+        self.factor = SpLuOperator(ones, ctx=ctx, check_symmetry=False, coords=box.dof_coords())
+        self.dK, self.dG, self._shifted = CSRMatrix(ctx, ones), CSRMatrix(ctx, ones), CSRMatrix(ctx, ones)
+        self.sigma = None
+
+    def assemble(self, t=None):
+        """K(t), G(t) values on the device (and in self.dK / self.dG)"""
+        box, ctx = self.box, self.ctx
+        s1, s3, sg = box.scales(t)
+        vK = self.asm.assemble(box.K_lin, s1, etype=box.etype)
+        vK3 = self.asm.assemble(box.K_cub, s3, etype=box.etype)
+        vK.assign_lincomb([(1.0, vK), (1.0, vK3)])
+        vG = self.asm.assemble(box.G_xx, sg, etype=box.etype)
+        self.dK.update_values_device(vK)
+        self.dG.update_values_device(vG)
+        self.vK, self.vG = vK, vG
+        return vK, vG
+
+    def refactor(self, sigma):
+        """numeric factorisation of K + sigma G from the device values; returns the number of negative pivots"""
+        vS = self.ctx.empty(self.vK.n, 1).assign_lincomb([(1.0, self.vK), (float(sigma), self.vG)])
+        self._shifted.update_values_device(vS)
+        self.factor.refactor_device(vS, indefinite_matrix=self._shifted)
+        self.sigma = float(sigma)
+        return self.factor.negative_pivots
+
+    def callbacks(self, t=None):
+        """(dAdx, dBdx) = d(w^T G v)/dt_g, d(w^T K v)/dt_g as device callbacks (A = G, B = K: buckling mode)"""
+        from .device import ElementBilinear, GroupedElementDerivative
+
+        box, ctx = self.box, self.ctx
+        te = (box.t if t is None else np.asarray(t))[box.group]
+        dK = [ElementBilinear(ctx, box.elem_dofs, box.K_lin, etype=box.etype),
+              ElementBilinear(ctx, box.elem_dofs, box.K_cub, scale=3.0 * te**2, etype=box.etype)]
+        dG = [ElementBilinear(ctx, box.elem_dofs, box.G_xx, scale=box.sigma_e, etype=box.etype)]
+        return (GroupedElementDerivative(ctx, dG, box.group, box.ngroups),
+                GroupedElementDerivative(ctx, dK, box.group, box.ngroups))

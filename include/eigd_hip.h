@@ -193,11 +193,12 @@ int eigd_scatter_cols(eigd_ctx* ctx, int n, int ksrc, const double* dSrc, int ld
  * out[e] += alpha * scale[e] * sum_c w_e(:,c)^T M_e v_e(:,c): the d/d(rho_e) contractions the
  * reference's harness callbacks evaluate with numpy einsums (examples/buckling.py:178-218,
  * 283-340; natural_frequency.py:162-203, 238-284; thermal.py:150-190, 216-246) and that
- * add_eig_total_derivative calls (33-182).  d_edofs: nelem x nd dof list (-1 = constrained),
- * dMe: nelem x nd x nd (per_elem != 0) or one shared nd x nd matrix, nd <= 8.             */
+ * add_eig_total_derivative calls (33-182).  d_edofs: nelem x nd dof list (-1 = constrained), nd <= 24 (6-dof shell
+ * facets: the CRM-like configuration, examples/crm.py:295-376).  dMe: one shared nd x nd matrix (per_elem = 0),
+ * nelem matrices (per_elem = 1), or one matrix per element TYPE selected by d_etype[e] (per_elem = 2). */
 int eigd_elem_bilinear(eigd_ctx* ctx, int nelem, int nd, const int32_t* d_edofs, const double* dMe, int per_elem,
-                       const double* dscale, const double* dW, int ldw, const double* dV, int ldv, int k, double alpha,
-                       double* dOut);
+                       const int32_t* d_etype, const double* dscale, const double* dW, int ldw, const double* dV, int ldv,
+                       int k, double alpha, double* dOut);
 
 /* ---- element assembly on the device ------------------------------------
  * The COO -> CSR assembly loops of the harnesses (examples/buckling.py:152-176, 220-255;
@@ -211,8 +212,10 @@ int eigd_assembler_create(eigd_ctx* ctx, int n, int nelem, int nd, const int32_t
 int eigd_assembler_free(eigd_assembler* a);
 int eigd_assembler_nnz(eigd_assembler* a, int64_t* nnz);
 int eigd_assembler_pattern(eigd_assembler* a, int32_t* hindptr /* n + 1 */, int32_t* hindices /* nnz */);
-/* dMe: nelem x nd x nd (per_elem != 0) or one shared nd x nd matrix; dscale: nelem or NULL; dvals: nnz (device) */
-int eigd_assemble(eigd_assembler* a, const double* dMe, int per_elem, const double* dscale, double* dvals);
+/* dMe: one shared nd x nd matrix (per_elem = 0), nelem of them (1), or one per element type d_etype[e] (2);
+ * dscale: nelem or NULL; dvals: nnz (device); nd <= 24 */
+int eigd_assemble(eigd_assembler* a, const double* dMe, int per_elem, const int32_t* d_etype, const double* dscale,
+                  double* dvals);
 /* element matrices linear in the element's dof values, Me[e] = sum_m (L[m] . u_e) Q[m]: the stress (geometric)
  * stiffness of the linear pre-buckling state (examples/buckling.py:220-255) with L = C0 B at the Gauss points and
  * Q = detJ * (dN dN^T terms).  d_edofs: nelem x nd dofs of the FULL vector du; dL: nterms x nd; dQ: nterms x nd x nd;

@@ -1,0 +1,201 @@
+"""
+BASELINE configs[4] (the reference's CRM wingbox, examples/crm.py:212-259, 295-376 -- TACS and its mesh are not available, so a
+build-defined stand-in, SURVEY.md 8d "C5"): thin-walled box beam of 6-dof flat-shell facets, (K_e + lam K_g) phi = 0,
+64 modes, full df/dx against finite differences over every design variable (wall-thickness groups).
+
+  small size : device assembly (typed 24-dof elements) against the host assembly, eigenvalues / psi / df/dx against
+               the CPU oracle (SuperLU + Lanczos + sibk + numpy element sums) on the same matrices, FD over all groups
+  full size  : ~2.0 M dof, 64 modes -- size-independent properties: eigen- and adjoint residuals, K-orthonormality,
+               mode sharding, df/dx against central differences over ALL design variables
+"""
+import time
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import align_signs, index_sets, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _find_shift(dev, blf_guess):
+    """a shift below the first buckling load: K + sigma G positive definite (inertia from the factorisation)"""
+    sigma = 0.6 * blf_guess
+    for _ in range(40):
+        if dev.refactor(sigma) == 0:
+            return sigma
+        sigma *= 0.5
+    raise AssertionError("no positive definite shift found")
+
+
+def _first_load_estimate(dev, iters=30):
+    """power iteration on K^-1 (-G) with the factor of K (sigma = 0)"""
+    ctx, n = dev.ctx, dev.box.n
+    assert dev.refactor(0.0) == 0
+    x = ctx.from_host(np.random.default_rng(3).uniform(-1, 1, size=n))
+    t = ctx.empty(n, 1)
+    mu = 0.0
+    for _ in range(iters):
+        dev.dG.apply(x, t, alpha=-1.0)
+        num = float(x.coldot(t)[0])
+        dev.dK.apply(x, t)
+        mu = num / float(x.coldot(t)[0])
+        dev.dG.apply(x, t, alpha=-1.0)
+        dev.factor.solve_device(t)
+        x.assign_lincomb([(1.0 / float(t.colnorms()[0]), t)])
+    return 1.0 / mu
+
+
+def _functional(lam, Phi, w, Phib, Phi_ref):
+    sg = np.sign(np.einsum("ij,ij->j", Phi, Phi_ref))
+    return float(w @ np.log(lam) + np.einsum("ij,ij->", Phib, Phi * sg))
+
+
+def test_shell_box_small_against_cpu_oracle():
+    import eigd_amd as eg
+    from eigd_amd.problems import ShellBox, ShellBoxOnDevice
+    from oracle import eigd_oracle as orc
+
+    box = ShellBox(40, 12, 4, nseg=3, seed=1)
+    dev = ShellBoxOnDevice(box)
+    ctx = dev.ctx
+    vK, vG = dev.assemble()
+    K, G = box.assemble_host()
+    pat = dev.asm.pattern()
+    assert np.array_equal(pat.indptr, K.indptr) and np.array_equal(pat.indices, K.indices)
+    assert np.abs(dev.asm.values_to_host(vK) - K.data).max() < 1e-13 * np.abs(K.data).max()
+    Gp = (G + 0.0 * K).tocsr()            # G on K's pattern
+    Gp.sort_indices()
+    assert np.abs(dev.asm.values_to_host(vG) - Gp.data).max() < 1e-13 * np.abs(G.data).max()
+    sigma = _find_shift(dev, _first_load_estimate(dev))
+    N = 8
+    s = eg.IRAM(N=N, m=40, mode="buckling", ctx=ctx)
+    lam, Phi = s.solve(dev.dG, dev.dK, dev.factor, sigma)
+    fo = orc.SpLuOperator((K + sigma * G).tocsc())
+    so = orc.BasicLanczos(N=N, m=120, tol=1e-13, mode="buckling")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lam_o, Phi_o = so.solve(G, K, fo, sigma)
+    assert relerr(lam, lam_o) < 1e-8
+    assert np.abs(Phi.T @ (K @ Phi) - np.eye(N)).max() < 1e-9
+    # adjoint + derivative on the SAME eigenvectors on both sides
+    rng = np.random.default_rng(5)
+    Phib, w = rng.uniform(-1, 1, size=(box.n, N)), rng.uniform(0.5, 1.5, size=N)
+    psi_d, data_d = s.solve_adjoint(Phib, method="sibk", rtol=1e-12, update_guess=False, bs_target=1)
+    psi_o, data_o, _ = orc.sibk(Phib, G, K, lam, Phi, mode="buckling", sigma=sigma, factor=fo, rtol=1e-12)
+    assert index_sets(data_d) == index_sets(data_o)
+    assert relerr(psi_d, psi_o) < 1e-8
+    dAdx, dBdx = dev.callbacks()
+    dfdx = s.add_total_derivative(w, Phib, psi_d, dAdx, dBdx, np.zeros(box.ngroups), adj_corr_data=data_d, deriv_type="tensor")
+    ed, te = box.elem_dofs, box.t[box.group]
+    gm = box.group_map()
+
+    def gather(M):
+        M = M.reshape(M.shape[0], -1)
+        return np.where(ed[:, :, None] >= 0, M[np.maximum(ed, 0)], 0.0)
+
+    def cbK(W, V):   # d(w^T K v)/dt_g = sum_{e in g} w_e^T (K_lin + 3 t^2 K_cub) v_e    (numpy statement of the callback)
+        we, ve = gather(W), gather(V)
+        Ke = box.K_lin[box.etype] + (3.0 * te**2)[:, None, None] * box.K_cub[box.etype]
+        return gm @ np.einsum("nak,nab,nbk->n", we, Ke, ve)
+
+    def cbG(W, V):
+        we, ve = gather(W), gather(V)
+        return gm @ (box.sigma_e * np.einsum("nak,nab,nbk->n", we, box.G_xx[box.etype], ve))
+
+    dfdx_o = orc.add_eig_total_derivative(lam, Phi, w, Phib, psi_o, cbG, cbK, np.zeros(box.ngroups), adj_corr_data=data_o,
+                                          mode="buckling", deriv_type="tensor")
+    assert relerr(dfdx, dfdx_o) < 1e-8
+    for dt in ("vector",):
+        assert relerr(s.add_total_derivative(w, Phib, psi_d, dAdx, dBdx, np.zeros(box.ngroups), adj_corr_data=data_d,
+                                             deriv_type=dt), dfdx_o) < 1e-8
+    # full gradient against central differences, one design variable at a time
+    t0 = box.t.copy()
+    fd = np.zeros(box.ngroups)
+    for g in range(box.ngroups):
+        f = []
+        for sgn in (1.0, -1.0):
+            t = t0.copy()
+            t[g] += sgn * 1e-6 * t0[g]
+            dev.assemble(t)
+            assert dev.refactor(sigma) == 0
+            s2 = eg.IRAM(N=N, m=40, mode="buckling", ctx=ctx)
+            l2, P2 = s2.solve(dev.dG, dev.dK, dev.factor, sigma)
+            f.append(_functional(l2, P2, w, Phib, Phi))
+        fd[g] = (f[0] - f[1]) / (2e-6 * t0[g])
+    assert relerr(dfdx, fd) < 2e-6, (dfdx, fd)
+
+
+def test_c5_full_size_properties():
+    """~2.0 M dof, 64 modes (BASELINE configs[4]); everything on the device, the checks are size independent"""
+    import eigd_amd as eg
+    from eigd_amd.problems import ShellBox, ShellBoxOnDevice
+
+    t_start = time.perf_counter()
+    box = ShellBox(832, 160, 40, nseg=2, seed=0)
+    assert box.n == 1996800 and box.ngroups == 8
+    dev = ShellBoxOnDevice(box)
+    ctx = dev.ctx
+    dev.assemble()
+    sigma = _find_shift(dev, _first_load_estimate(dev, iters=20))
+    stats = dev.factor.factor.stats()
+    print(f"C5: n = {box.n}, nnz(K) = {dev.dK.nnz}, nnz(L) = {stats['nnzL']}, set-up {time.perf_counter() - t_start:.1f} s")
+    N = 64
+    s = eg.IRAM(N=N, m=129, mode="buckling", ctx=ctx)
+    t0 = time.perf_counter()
+    lam, Phi = s.solve(dev.dG, dev.dK, dev.factor, sigma)
+    t_eig = time.perf_counter() - t0
+    assert np.all(np.diff(lam) >= 0) and lam[0] > sigma
+    dPhi = s._prob.Phi
+    KP, GP = dev.dK.apply(dPhi).get(), dev.dG.apply(dPhi).get()
+    R = KP + GP * lam                                                       # (K + lam G) phi = 0
+    assert np.linalg.norm(R, axis=0).max() < 1e-8 * np.linalg.norm(KP, axis=0).max()
+    assert np.abs(Phi.T @ KP - np.eye(N)).max() < 1e-9
+    rng = np.random.default_rng(1)
+    Phib, w = rng.uniform(-1, 1, size=(box.n, N)), rng.uniform(0.5, 1.5, size=N)
+    dPhib = ctx.from_host(Phib)
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        dpsi, data = s.solve_adjoint(dPhib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1)
+    dAdx, dBdx = dev.callbacks()
+    dfdx = s.add_total_derivative(w, dPhib, dpsi, dAdx, dBdx, np.zeros(box.ngroups), adj_corr_data=data, deriv_type="tensor")
+    ctx.sync()
+    t_adj = time.perf_counter() - t0
+    print(f"C5: eigensolve {t_eig:.2f} s, adjoint + derivative of {N} modes {t_adj:.2f} s ({N / t_adj:.1f} modes/s)")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res, ortho = s.eval_adjoint_residual_norm(dPhib, dpsi, b_ortho=True)
+    assert res.max() < 1e-7 * np.linalg.norm(Phib, axis=0).max()
+
+    class OneOfFour:  # rank 3 of 4 without the other processes: its columns are the columns of the full solve
+        rank, size = 3, 4
+
+        def allreduce_sum(self, a):
+            return a
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        psi_r, _ = s.solve_adjoint(dPhib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, comm=OneOfFour())
+    a, b = psi_r.get()[:, 3::4], dpsi.get()[:, 3::4]
+    assert relerr(a, b) < 1e-8
+    del a, b, psi_r
+    # the whole gradient against central differences (every design variable: 2 x ngroups eigensolves at full size)
+    t_base = box.t.copy()
+    fd = np.zeros(box.ngroups)
+    h = 1e-5
+    for g in range(box.ngroups):
+        f = []
+        for sgn in (1.0, -1.0):
+            t = t_base.copy()
+            t[g] += sgn * h * t_base[g]
+            dev.assemble(t)
+            assert dev.refactor(sigma) == 0
+            s2 = eg.IRAM(N=N, m=129, mode="buckling", ctx=ctx)
+            l2, P2 = s2.solve(dev.dG, dev.dK, dev.factor, sigma)
+            f.append(_functional(l2, P2, w, Phib, Phi))
+        fd[g] = (f[0] - f[1]) / (2 * h * t_base[g])
+    print(f"C5: df/dx vs central differences over all {box.ngroups} design variables: rel-err {relerr(dfdx, fd):.2e}; "
+          f"total {time.perf_counter() - t_start:.0f} s")
+    assert relerr(dfdx, fd) < 1e-5, (dfdx, fd)
