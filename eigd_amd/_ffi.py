@@ -36,6 +36,7 @@ _SIGNATURES = {
     "eigd_ctx_create": [c_int, P(c_vp)],
     "eigd_ctx_fork": [c_vp, P(c_vp)],
     "eigd_ctx_destroy": [c_vp],
+    "eigd_ctx_make_current": [c_vp],
     "eigd_sync": [c_vp],
     "eigd_malloc": [c_vp, c_sz, P(c_vp)],
     "eigd_free": [c_vp, c_vp],

@@ -623,6 +623,7 @@ def _run_groups(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist, s
     def work(g):
         try:
             ctxg = prob.ctx.fork(g)
+            ctxg.make_current()   # a fresh host thread: HIP's current device is per thread
             pg = prob.on(ctxg)
             R0 = ctxg.empty(Rc.n, len(parts[g])).copy_from(Rg[g])
             out[g] = _sibk_round(pg, R0, lam_p[parts[g]], sigma, rnorm0, rtol, atol, maxiter,

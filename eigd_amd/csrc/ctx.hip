@@ -97,6 +97,12 @@ int eigd_ctx_destroy(eigd_ctx* ctx) {
   return EIGD_OK;
 }
 
+int eigd_ctx_make_current(eigd_ctx* ctx) {
+  EIGD_REQUIRE(ctx, "ctx is null");
+  EIGD_HIP(hipSetDevice(ctx->device));  // HIP's current device is per host thread: a new thread starts on device 0
+  return EIGD_OK;
+}
+
 int eigd_sync(eigd_ctx* ctx) {
   EIGD_REQUIRE(ctx, "ctx is null");
   EIGD_HIP(hipStreamSynchronize(ctx->stream));

@@ -60,6 +60,8 @@ struct FrontArrays {
   const double* zero;   // one 0.0 and ...
   const int* neg1;      // ... one -1 in device memory: masked-off lanes of the sweeps load from here (address select)
   int W;                // instead of branching around the load, which would serialise the loads of a tile
+  int tri;              // 1: the diagonal blocks of T are lower triangular (Cholesky / sign-tracked path); 0: dense 64 x 64
+                        // diagonal blocks (Bunch-Kaufman path: pivoting inside the panel), the sweeps skip no part of them
 };
 
 constexpr int kPlaneCols = 4 + 8 + 16 + 32;  // one set of carry planes per sweep width
@@ -164,6 +166,193 @@ __global__ __launch_bounds__(kThreads) void potrf_inv_kernel(FrontArrays fa, con
     const int j = idx / w, i = idx - j * w;
     if (i >= j) Fd[static_cast<int64_t>(j) * d + i] = S[j * TLD + i];
     Ig[j * W + i] = Iv[j * TLD + i];
+  }
+}
+
+
+// Indefinite shifts (sigma inside the spectrum; examples/crm.py:26, 221 -- SuperLU pivots there, reference 13): the same
+// panel step with Bunch-Kaufman pivoting INSIDE the W x W diagonal block.  P A_pp P^T = L D L^T with 1 x 1 and 2 x 2
+// pivots (alpha = (1 + sqrt 17) / 8, the bounded-growth rule of LAPACK's dsytf2); every 2 x 2 block is diagonalised,
+// D = Q diag(e) Q^T, so that A_pp = M S M^T with M = P^T L Q |e|^(1/2) and S = diag(sign e).  M is a dense block, but
+// the rest of the factorisation and the sweeps only ever use inv(M) (trsm as a product, T = inv(M11) explicit), so
+// nothing else changes: the permutation never leaves this kernel and the symbolic structure stays what it was.
+// Pivots are not delayed to the parent front: a front whose own block is singular by itself still fails.
+__global__ __launch_bounds__(kThreads) void ldlt_bk_inv_kernel(FrontArrays fa, const int* __restrict__ fronts, int step,
+                                                              double* __restrict__ F, double* __restrict__ Inv,
+                                                              int* __restrict__ flag) {
+  __shared__ double A[TW * TLD];   // full symmetric working block, column-major: A[j * TLD + i]; columns < k hold L
+  __shared__ double X[TW * TLD];   // inv(M), column c at X[c * TLD + .]
+  __shared__ double wk[2 * TW];    // the two multiplier columns of a 2 x 2 step
+  __shared__ int perm[TW], kind[TW];  // kind[k]: 1 = 1 x 1 pivot, 2 = first row of a 2 x 2 pivot, 0 = its second row
+  __shared__ int s_kp, s_kstep, s_bad;
+  const int f = fronts[blockIdx.x];
+  const int W = fa.W;
+  const int ns = fa.ns[f];
+  const int64_t d = ns + fa.bs[f];
+  const int j0 = step * W;
+  const int w = min(W, ns - j0);
+  double* Fd = F + fa.foff[f] + static_cast<int64_t>(j0) * d + j0;
+  const int tid = threadIdx.x;
+  const double alpha = 0.6403882032022076;  // (1 + sqrt(17)) / 8
+  for (int idx = tid; idx < w * w; idx += kThreads) {
+    const int j = idx / w, i = idx - j * w;
+    A[j * TLD + i] = (i >= j) ? Fd[static_cast<int64_t>(j) * d + i] : Fd[static_cast<int64_t>(i) * d + j];
+  }
+  if (tid < w) perm[tid] = tid;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  int k = 0;
+  while (k < w) {
+    if (tid == 0) {  // pivot choice (dsytf2, lower): at most two scans of w entries
+      const double absakk = fabs(A[k * TLD + k]);
+      int imax = k;
+      double colmax = 0.0;
+      for (int i = k + 1; i < w; ++i) {
+        const double v = fabs(A[k * TLD + i]);
+        if (v > colmax) { colmax = v; imax = i; }
+      }
+      int kp = k, kstep = 1;
+      const double big = fmax(absakk, colmax);
+      if (!(big > 0.0) || !(big < 1.0e300)) {
+        s_bad = 1;  // the whole column is zero / not finite: singular to working precision
+      } else if (absakk < alpha * colmax) {
+        double rowmax = 0.0;
+        for (int j = k; j < w; ++j)
+          if (j != imax) rowmax = fmax(rowmax, fabs(A[j * TLD + imax]));
+        if (absakk >= alpha * colmax * (colmax / rowmax)) {
+          kp = k;
+        } else if (fabs(A[imax * TLD + imax]) >= alpha * rowmax) {
+          kp = imax;
+        } else {
+          kp = imax;
+          kstep = 2;
+        }
+      }
+      s_kp = kp;
+      s_kstep = kstep;
+    }
+    __syncthreads();
+    if (s_bad) break;
+    const int kstep = s_kstep, kp = s_kp;
+    const int kk = k + kstep - 1;  // the position the chosen row moves to
+    if (kp != kk) {  // symmetric interchange kk <-> kp: rows (all columns, L included), then columns
+      for (int j = tid; j < w; j += kThreads) {
+        const double t = A[j * TLD + kk];
+        A[j * TLD + kk] = A[j * TLD + kp];
+        A[j * TLD + kp] = t;
+      }
+      __syncthreads();
+      for (int i = tid; i < w; i += kThreads) {
+        const double t = A[kk * TLD + i];
+        A[kk * TLD + i] = A[kp * TLD + i];
+        A[kp * TLD + i] = t;
+      }
+      if (tid == 0) {
+        const int t = perm[kk];
+        perm[kk] = perm[kp];
+        perm[kp] = t;
+      }
+      __syncthreads();
+    }
+    if (kstep == 1) {
+      const double dk = A[k * TLD + k];
+      const int m = w - k - 1;
+      for (int idx = tid; idx < m * m; idx += kThreads) {  // trailing block, both triangles
+        const int cc = idx / m, ii = idx - cc * m;
+        A[(k + 1 + cc) * TLD + k + 1 + ii] -= A[k * TLD + k + 1 + ii] * A[k * TLD + k + 1 + cc] / dk;
+      }
+      __syncthreads();
+      for (int i = k + 1 + tid; i < w; i += kThreads) A[k * TLD + i] /= dk;  // the multipliers
+      if (tid == 0) kind[k] = 1;
+    } else {
+      const double a = A[k * TLD + k], b = A[k * TLD + k + 1], c = A[(k + 1) * TLD + k + 1];
+      const double det = a * c - b * b;
+      const int m = w - k - 2;
+      for (int i = tid; i < m; i += kThreads) {  // [w1 w2] = [a_i,k  a_i,k+1] inv(D)
+        const double x = A[k * TLD + k + 2 + i], y = A[(k + 1) * TLD + k + 2 + i];
+        wk[i] = (x * c - y * b) / det;
+        wk[TW + i] = (y * a - x * b) / det;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < m * m; idx += kThreads) {
+        const int cc = idx / m, ii = idx - cc * m;
+        A[(k + 2 + cc) * TLD + k + 2 + ii] -= wk[ii] * A[k * TLD + k + 2 + cc] + wk[TW + ii] * A[(k + 1) * TLD + k + 2 + cc];
+      }
+      __syncthreads();
+      for (int i = tid; i < m; i += kThreads) {
+        A[k * TLD + k + 2 + i] = wk[i];
+        A[(k + 1) * TLD + k + 2 + i] = wk[TW + i];
+      }
+      if (tid == 0) {
+        kind[k] = 2;
+        kind[k + 1] = 0;
+      }
+    }
+    __syncthreads();
+    k += kstep;
+  }
+  if (s_bad) {
+    if (tid == 0) atomicCAS(flag, 0, f + 1);
+    // leave something finite behind: the caller reports the failure, later launches of this numeric phase must not fault
+    for (int idx = tid; idx < w * w; idx += kThreads) {
+      const int j = idx / w, i = idx - j * w;
+      A[j * TLD + i] = (i == j) ? 1.0 : 0.0;
+    }
+    if (tid < w) {
+      perm[tid] = tid;
+      kind[tid] = 1;
+    }
+    __syncthreads();
+  }
+  // inv(M) = |e|^(-1/2) Q^T inv(L) P, one column per lane: x = P e_c, forward substitution with the unit lower L
+  // (the sub-diagonal entry inside a 2 x 2 block belongs to D, not to L), then the block-diagonal scaling
+  if (tid < w) {
+    const int c = tid;
+    double* x = X + c * TLD;
+    for (int i = 0; i < w; ++i) {
+      double sum = (perm[i] == c) ? 1.0 : 0.0;
+      const int jend = (kind[i] == 0) ? i - 1 : i;
+      for (int j = 0; j < jend; ++j) sum -= A[j * TLD + i] * x[j];
+      x[i] = sum;
+    }
+    for (int i = 0; i < w; ++i) {
+      if (kind[i] == 1) {
+        x[i] /= sqrt(fabs(A[i * TLD + i]));
+      } else if (kind[i] == 2) {
+        const double a = A[i * TLD + i], b = A[i * TLD + i + 1], cc = A[(i + 1) * TLD + i + 1];
+        // eigen-decomposition of [[a, b], [b, cc]]: rotation by theta with tan(2 theta) = 2 b / (a - cc)
+        const double th = 0.5 * atan2(2.0 * b, a - cc);
+        const double cs = cos(th), sn = sin(th);
+        const double e1 = a * cs * cs + 2.0 * b * cs * sn + cc * sn * sn;
+        const double e2 = a * sn * sn - 2.0 * b * cs * sn + cc * cs * cs;
+        const double x0 = x[i], x1 = x[i + 1];
+        x[i] = (cs * x0 + sn * x1) / sqrt(fabs(e1));
+        x[i + 1] = (-sn * x0 + cs * x1) / sqrt(fabs(e2));
+      }
+    }
+  }
+  // signs of S, inertia
+  if (tid < w) {
+    double sgv = 1.0;
+    if (kind[tid] == 1) {
+      sgv = (A[tid * TLD + tid] < 0.0) ? -1.0 : 1.0;
+    } else {
+      const int i = (kind[tid] == 2) ? tid : tid - 1;
+      const double a = A[i * TLD + i], b = A[i * TLD + i + 1], cc = A[(i + 1) * TLD + i + 1];
+      const double th = 0.5 * atan2(2.0 * b, a - cc);
+      const double cs = cos(th), sn = sin(th);
+      const double e = (kind[tid] == 2) ? a * cs * cs + 2.0 * b * cs * sn + cc * sn * sn
+                                        : a * sn * sn - 2.0 * b * cs * sn + cc * cs * cs;
+      sgv = (e < 0.0) ? -1.0 : 1.0;
+    }
+    fa.sgn[fa.c0[f] + j0 + tid] = sgv;
+    if (sgv < 0.0) atomicAdd(flag + 1, 1);
+  }
+  __syncthreads();
+  double* Ig = Inv + fa.ioff[f] + static_cast<int64_t>(step) * W * W;
+  for (int idx = tid; idx < w * w; idx += kThreads) {
+    const int j = idx / w, i = idx - j * w;
+    Ig[j * W + i] = X[j * TLD + i];
   }
 }
 
@@ -306,7 +495,8 @@ __global__ __launch_bounds__(kThreads) void trinv_kernel(FrontArrays fa, const i
   for (int idx = tid; idx < W * W; idx += kThreads) {
     const int c = idx / W, i = idx - c * W;
     if (i < wj && c < wj)
-      Tf[static_cast<int64_t>(j0 + c) * ns + j0 + i] = (i >= c) ? If[static_cast<int64_t>(j) * W * W + c * W + i] : 0.0;
+      Tf[static_cast<int64_t>(j0 + c) * ns + j0 + i] = If[static_cast<int64_t>(j) * W * W + c * W + i];  // (zeros above the
+    // diagonal on the Cholesky path, a dense block on the Bunch-Kaufman path)
   }
   __threadfence();
   __syncthreads();
@@ -347,7 +537,7 @@ __global__ __launch_bounds__(kThreads) void trinv_kernel(FrontArrays fa, const i
       for (int q = 0; q < 4; ++q) Bs[(r0 + p) * TLD + c0 + q] = acc[p][q];
     for (int idx = tid; idx < W * TW; idx += kThreads) {
       const int kk = idx / TW, r = idx - kk * TW;
-      As[kk * TLD + r] = (kk < wi && r < wi && r >= kk) ? If[static_cast<int64_t>(i) * W * W + kk * W + r] : 0.0;  // inv(L_ii)(r, kk)
+      As[kk * TLD + r] = (kk < wi && r < wi) ? If[static_cast<int64_t>(i) * W * W + kk * W + r] : 0.0;  // inv(L_ii)(r, kk)
     }
     __syncthreads();
     double out[4][4];
@@ -1203,7 +1393,7 @@ __global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, cons
     const int r = 16 * rb + li;  // the row this lane feeds as A operand
     // a block of 16 own rows meets only zeros of T past its diagonal block (T is lower triangular): those K-steps
     // read the zero word instead of streaming zeros from HBM (wave-uniform bound)
-    const int smax = (16 * rb + 16 <= ns) ? 4 * (rb + 1) : NKS;
+    const int smax = (fa.tri && 16 * rb + 16 <= ns) ? 4 * (rb + 1) : NKS;
     double a[NKS];
 #pragma unroll
     for (int s = 0; s < NKS; ++s) {
@@ -1312,7 +1502,7 @@ __global__ __launch_bounds__(64) void bwd_thin_kernel(FrontArrays fa, const WgRe
       for (int ob = 0; ob < NOB; ++ob) {
         const int o = 16 * ob + li;
         // (rows of T above the diagonal block of these 16 columns hold zeros: wave-uniform test, not fetched)
-        a[s][ob] = *((k < d && o < ns && !(4 * CH * ch + 4 * s + 3 < 16 * ob)) ? Fp + static_cast<int64_t>(k) * ns + o : fa.zero);
+        a[s][ob] = *((k < d && o < ns && !(fa.tri && 4 * CH * ch + 4 * s + 3 < 16 * ob)) ? Fp + static_cast<int64_t>(k) * ns + o : fa.zero);
       }
       const int e = k - ns;  // border entry
       const int r0 = __shfl(I[0], e & 63), r1 = __shfl(I[1], e & 63), r2 = __shfl(I[2], e & 63), r3 = __shfl(I[3], e & 63);
@@ -1441,6 +1631,7 @@ struct eigd_factor {
   int* d_cmask = nullptr;
   double *d_data = nullptr, *d_F = nullptr, *d_Inv = nullptr, *d_V = nullptr, *d_Y = nullptr, *d_sgn = nullptr;
   int n_negative = 0;
+  bool pivoted = false;  // the last numeric phase ran the Bunch-Kaufman panel kernel (dense diagonal blocks in T)
   int* d_flag = nullptr;
   size_t bytes = 0;
   std::vector<int> ea_split;  // per (level, slot): grid.y of the extend-add launches
@@ -1467,6 +1658,7 @@ struct eigd_factor {
     a.zero = d_aux;
     a.neg1 = reinterpret_cast<const int*>(d_aux + 1);
     a.W = sym->W;
+    a.tri = pivoted ? 0 : 1;
     return a;
   }
 };
@@ -1482,11 +1674,13 @@ int upload(eigd_factor* f, T** dptr, const std::vector<T>& h) {
   return EIGD_OK;
 }
 
-int numeric(eigd_factor* f, const double* data, bool on_device = false) {
+int numeric(eigd_factor* f, const double* data, bool on_device = false, bool pivot = false) {
   const Symbolic& s = *f->sym;
   hipStream_t st = f->ctx->stream;
-  EIGD_HIP(hipMemcpyAsync(f->d_data, data, sizeof(double) * f->data_len,
-                          on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  f->pivoted = pivot;
+  if (data != nullptr)  // (the pivoting pass re-reads the values the first pass brought in)
+    EIGD_HIP(hipMemcpyAsync(f->d_data, data, sizeof(double) * f->data_len,
+                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   EIGD_HIP(hipMemsetAsync(f->d_F, 0, sizeof(double) * s.front_doubles, st));
   EIGD_HIP(hipMemsetAsync(f->d_flag, 0, 2 * sizeof(int), st));
   {
@@ -1512,8 +1706,12 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false) {
       const int64_t po = s.ls_pref_ptr[rec];
       const int nchunks = s.pref_chunks[po + na];
       const int ntiles = s.pref_tiles[po + na];
-      hipLaunchKernelGGL(potrf_inv_kernel, dim3(na), dim3(kThreads), 0, st, fa, fronts, step, f->d_F, f->d_Inv,
-                         f->d_flag);
+      if (pivot)
+        hipLaunchKernelGGL(ldlt_bk_inv_kernel, dim3(na), dim3(kThreads), 0, st, fa, fronts, step, f->d_F, f->d_Inv,
+                           f->d_flag);
+      else
+        hipLaunchKernelGGL(potrf_inv_kernel, dim3(na), dim3(kThreads), 0, st, fa, fronts, step, f->d_F, f->d_Inv,
+                           f->d_flag);
       EIGD_LAUNCH_CHECK();
       if (nchunks > 0) {
         hipLaunchKernelGGL(trsm_kernel, dim3(nchunks), dim3(kThreads), 0, st, fa, fronts, na, step,
@@ -1548,6 +1746,10 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false) {
   EIGD_HIP(hipMemcpyAsync(flag, f->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   EIGD_HIP(hipStreamSynchronize(st));
   f->n_negative = flag[1];
+  // Not positive definite (negative or unusable pivots on the Cholesky path): the shift lies inside the spectrum.
+  // Factor again with Bunch-Kaufman pivoting inside the panels -- the positive definite shifts of the reference's
+  // examples never come here and keep the plain (bitwise unchanged) Cholesky path.
+  if (!pivot && (flag[0] != 0 || flag[1] != 0)) return numeric(f, nullptr, true, true);
   if (flag[0] != 0) {
     set_error("zero or non-finite pivot in front %d: the (shifted) matrix is singular to working precision -- move the "
               "shift away from an eigenvalue",

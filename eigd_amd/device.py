@@ -35,6 +35,10 @@ class Context:
             kids[index] = Context(self.device, _parent=self)
         return kids[index]
 
+    def make_current(self):
+        """bind the calling host thread to this context's device (worker threads start on device 0)"""
+        call("eigd_ctx_make_current", self.h)
+
     def sync(self):
         call("eigd_sync", self.h)
 

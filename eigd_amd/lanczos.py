@@ -696,6 +696,11 @@ class IRAM(_AdjointAPI):
         self.Phi = dPhi.get()
         self._phi_token = self.Phi
         self.eig_res = np.abs(beta_m * self.Y[m - 1, sel])
+        if np.any(self.eig_res > 1e-6 * np.maximum(np.abs(self.theta[sel]), 1.0)):
+            # the restarts converge the Ritz values of largest magnitude; the reference then selects by eigenvalue order
+            # (1960-1965): with a shift on the wrong side of the wanted eigenvalues these are different pairs
+            warnings.warn("IRAM: the selected Ritz pairs are not the converged ones (largest residual "
+                          f"{self.eig_res.max():.1e}): the shift is not next to the wanted eigenvalues")
         self._m = m
         self._nV = m
         self._V_host = None

@@ -20,10 +20,12 @@ class SpLuOperator(LinearOperator):
     ``(n,)`` and ``(n, k)`` numpy arrays).  ``mat`` must be symmetric.  The factorisation is
     ``P mat P^T = L S L^T`` with ``S = diag(+-1)``: plain Cholesky for the positive definite
     shifts of the reference's examples (K - sigma M below the spectrum, K + sigma G below the
-    first buckling load), a sign-tracked LDL^T without pivoting for a shift inside the spectrum
-    (``negative_pivots`` = number of eigenvalues of the pencil below the shift); in that case every
-    application is followed by one step of iterative refinement.  A zero / non-finite pivot raises
-    ``NotPositiveDefiniteError`` (a ``numpy.linalg.LinAlgError``): the shift sits on an eigenvalue.
+    first buckling load); for a shift inside the spectrum (the reference's CRM example, sigma = omega_0^2) the numeric
+    phase is repeated with Bunch-Kaufman pivoting (1 x 1 and 2 x 2 pivots, interchanges inside the 64-column panel of
+    a front, so the symbolic structure is kept; ``negative_pivots`` = number of eigenvalues of the pencil below the
+    shift) and every application is followed by one step of iterative refinement.  A panel block that is singular
+    to working precision raises ``NotPositiveDefiniteError`` (a ``numpy.linalg.LinAlgError``): the shift sits on an
+    eigenvalue (pivots are not delayed to the parent front).
     """
 
     def __init__(self, mat, ctx=None, symbolic=None, leaf_size=0, panel_width=0, check_symmetry=True, coords=None):
@@ -63,9 +65,12 @@ class SpLuOperator(LinearOperator):
 
     def _refine(self, B, X, alpha):
         """X <- X + alpha * mat^{-1} (B - mat X / alpha) ... one step of iterative refinement on device blocks"""
-        R = self._mat_dev.apply(X)                       # mat X   (X = alpha * approx(mat^{-1} B))
+        # everything on X's context: with concurrent mode groups (streams > 1) X lives on a forked context whose
+        # stream and sweep lane must carry the whole refinement step
+        R = X.ctx.empty(X.n, X.k)
+        self._mat_dev.apply(X, R)                        # mat X   (X = alpha * approx(mat^{-1} B))
         R.assign_lincomb([(alpha, B), (-1.0, R)])        # alpha B - mat X
-        self.factor.solve_inplace(R, 1.0)
+        self.factor.solve_to(R, R, 1.0)
         X.assign_lincomb([(1.0, X), (1.0, R)])
         return X
 

@@ -53,6 +53,9 @@ int eigd_ctx_create(int device, eigd_ctx** out);
  * lock-step solvers run on forked contexts so that their launch chains overlap */
 int eigd_ctx_fork(eigd_ctx* parent, eigd_ctx** out);
 int eigd_ctx_destroy(eigd_ctx* ctx);
+/* make the context's device the calling host thread's current HIP device (call once at the start of every worker
+ * thread that drives a context: allocations and launches of that thread then land on the right GPU) */
+int eigd_ctx_make_current(eigd_ctx* ctx);
 int eigd_sync(eigd_ctx* ctx);
 int eigd_malloc(eigd_ctx* ctx, size_t bytes, void** dptr);
 int eigd_free(eigd_ctx* ctx, void* dptr);

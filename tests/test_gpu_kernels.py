@@ -515,3 +515,75 @@ def test_stress_stiffness_on_the_device_matches_the_host_formula(ctx):
     P = asm.pattern()
     Gd = sparse.csr_matrix((vals, P.indices, P.indptr), shape=P.shape)
     assert abs(Gd - G).max() <= 1e-13 * abs(G).max()
+
+
+def test_bunch_kaufman_pivoting_inside_the_fronts(ctx):
+    """
+    Interior shifts on which the unpivoted L S L^T breaks down (reference: SuperLU pivots, eigenvector_derivatives.py:11-23;
+    examples/crm.py:26, 221 shifts into the spectrum).  (a) the first pivot of the elimination order is EXACTLY zero:
+    sigma = K_pp / M_pp for the first eliminated dof p; (b) shifts that make leading principal minors nearly singular
+    (sigma = a Ritz value of a leading block); each against SuperLU, inertia against the dense spectrum.
+    """
+    import eigd_amd as eg
+    from eigd_amd.device import Symbolic
+
+    K = grid_matrix(21, 17, 2, seed=5)
+    n = K.shape[0]
+    rng = np.random.default_rng(3)
+    M = sparse.diags(rng.uniform(0.5, 1.5, size=n)).tocsr()
+    Md = M.diagonal()
+    perm = Symbolic(K).array("perm")
+    Kd = K.toarray()
+    lam_all = np.linalg.eigvalsh(np.diag(Md ** -0.5) @ Kd @ np.diag(Md ** -0.5))
+    B = rng.normal(size=(n, 6))
+    shifts = [K[perm[0], perm[0]] / Md[perm[0]]]                       # (a): a_11 = 0 exactly after the shift
+    for q in (3, 7, 19):                                               # (b): leading q x q block of the order singular
+        idx = perm[:q]
+        ev = np.linalg.eigvalsh(np.diag(Md[idx] ** -0.5) @ Kd[np.ix_(idx, idx)] @ np.diag(Md[idx] ** -0.5))
+        shifts.append(ev[q // 2])
+    for sigma in shifts:
+        mat = (K - sigma * M).tocsr()
+        op = eg.SpLuOperator(mat.tocsc(), ctx=ctx)
+        assert op.negative_pivots == int(np.count_nonzero(lam_all < sigma)), sigma     # inertia (Sylvester)
+        X = op(B)
+        Xr = splu(mat.tocsc()).solve(B)
+        assert np.linalg.norm(mat @ X - B) / np.linalg.norm(B) < 1e-10, sigma
+        assert relerr(X, Xr) < 1e-8, sigma
+        # the factor alone (no refinement step) is already accurate: the pivoting, not the refinement, does the work
+        Xf = op.factor.solve_inplace(ctx.from_host(B)).get()
+        assert np.linalg.norm(mat @ Xf - B) / np.linalg.norm(B) < 1e-8, sigma
+    # a positive definite matrix never takes the pivoting path: same bits as before
+    opd = eg.SpLuOperator((K + 0.3 * M).tocsc(), ctx=ctx)
+    assert opd.negative_pivots == 0 and relerr(opd(B), splu((K + 0.3 * M).tocsc()).solve(B)) < 1e-12
+
+
+def test_interior_shift_eigenpairs_and_adjoint_with_streams(ctx):
+    """
+    shift-invert Lanczos around an interior shift with the pivoted factor: eigenpairs on both sides of the shift, and
+    the lock-step adjoint solve with concurrent mode groups (streams = 3: refinement step and sweep lane per stream)
+    against the single-stream run
+    """
+    import warnings
+
+    import eigd_amd as eg
+
+    K = grid_matrix(30, 26, 1, seed=2)
+    n = K.shape[0]
+    M = sparse.diags(np.random.default_rng(1).uniform(0.5, 1.5, size=n)).tocsr()
+    lam_all = np.linalg.eigvalsh(np.diag(M.diagonal() ** -0.5) @ K.toarray() @ np.diag(M.diagonal() ** -0.5))
+    sigma = 0.5 * (lam_all[9] + lam_all[10])
+    fac = eg.SpLuOperator((K - sigma * M).tocsc(), ctx=ctx)
+    assert fac.negative_pivots == 10
+    s = eg.BasicLanczos(N=6, m=80, tol=1e-12, ctx=ctx)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lam, Phi = s.solve(K, M, fac, sigma)
+    assert np.all(np.abs(np.sort(lam) - np.sort(lam_all[np.argsort(np.abs(lam_all - sigma))[:6]])) < 1e-8 * np.abs(lam_all).max())
+    R = K @ Phi - (M @ Phi) * lam
+    assert np.linalg.norm(R, axis=0).max() < 1e-8 * np.abs(K).max()
+    Phib = np.random.default_rng(4).uniform(-1, 1, size=(n, 6))
+    psi1, data1 = s.solve_adjoint(Phib, method="sibk", rtol=1e-11, streams=1)
+    psi3, data3 = s.solve_adjoint(Phib, method="sibk", rtol=1e-11, streams=3)
+    assert relerr(psi3, psi1) < 1e-9
+    res, _ = s.eval_adjoint_residual_norm(Phib, psi3, b_ortho=True)
+    assert res.max() < 1e-8 * np.linalg.norm(Phib, axis=0).max()

@@ -19,32 +19,33 @@ from conftest import align_signs, index_sets, relerr
 pytestmark = pytest.mark.gpu
 
 
-def _find_shift(dev, blf_guess):
-    """a shift below the first buckling load: K + sigma G positive definite (inertia from the factorisation)"""
-    sigma = 0.6 * blf_guess
-    for _ in range(40):
+def _find_shift(dev, start=1.0, refine=3):
+    """
+    A positive shift below the first positive buckling load, from the inertia the factorisation reports (K + sigma G is
+    positive definite exactly for sigma below it): double until negative pivots appear, then bisect a few times.  The
+    pre-stress has a tension side too (negative loads of similar size): a power iteration on K^-1 G would not tell the
+    two apart, and a shift on the wrong side makes every solver (the reference's included) return the unconverged
+    interior Ritz values.
+    """
+    good, bad = 0.0, None
+    sigma = start
+    for _ in range(60):
         if dev.refactor(sigma) == 0:
-            return sigma
-        sigma *= 0.5
-    raise AssertionError("no positive definite shift found")
-
-
-def _first_load_estimate(dev, iters=30):
-    """power iteration on K^-1 (-G) with the factor of K (sigma = 0)"""
-    ctx, n = dev.ctx, dev.box.n
-    assert dev.refactor(0.0) == 0
-    x = ctx.from_host(np.random.default_rng(3).uniform(-1, 1, size=n))
-    t = ctx.empty(n, 1)
-    mu = 0.0
-    for _ in range(iters):
-        dev.dG.apply(x, t, alpha=-1.0)
-        num = float(x.coldot(t)[0])
-        dev.dK.apply(x, t)
-        mu = num / float(x.coldot(t)[0])
-        dev.dG.apply(x, t, alpha=-1.0)
-        dev.factor.solve_device(t)
-        x.assign_lincomb([(1.0 / float(t.colnorms()[0]), t)])
-    return 1.0 / mu
+            good = sigma
+            sigma *= 2.0
+        else:
+            bad = sigma
+            break
+    assert bad is not None and good > 0.0
+    for _ in range(refine):
+        mid = 0.5 * (good + bad)
+        if dev.refactor(mid) == 0:
+            good = mid
+        else:
+            bad = mid
+    sigma = 0.9 * good
+    assert dev.refactor(sigma) == 0
+    return sigma
 
 
 def _functional(lam, Phi, w, Phib, Phi_ref):
@@ -65,10 +66,11 @@ def test_shell_box_small_against_cpu_oracle():
     pat = dev.asm.pattern()
     assert np.array_equal(pat.indptr, K.indptr) and np.array_equal(pat.indices, K.indices)
     assert np.abs(dev.asm.values_to_host(vK) - K.data).max() < 1e-13 * np.abs(K.data).max()
-    Gp = (G + 0.0 * K).tocsr()            # G on K's pattern
-    Gp.sort_indices()
-    assert np.abs(dev.asm.values_to_host(vG) - Gp.data).max() < 1e-13 * np.abs(G.data).max()
-    sigma = _find_shift(dev, _first_load_estimate(dev))
+    from scipy import sparse
+
+    Gd = sparse.csr_matrix((dev.asm.values_to_host(vG), pat.indices, pat.indptr), shape=pat.shape)   # G on K's pattern
+    assert abs(Gd - G).max() < 1e-13 * np.abs(G.data).max()
+    sigma = _find_shift(dev)
     N = 8
     s = eg.IRAM(N=N, m=40, mode="buckling", ctx=ctx)
     lam, Phi = s.solve(dev.dG, dev.dK, dev.factor, sigma)
@@ -138,7 +140,7 @@ def test_c5_full_size_properties():
     dev = ShellBoxOnDevice(box)
     ctx = dev.ctx
     dev.assemble()
-    sigma = _find_shift(dev, _first_load_estimate(dev, iters=20))
+    sigma = _find_shift(dev, start=0.25)
     stats = dev.factor.factor.stats()
     print(f"C5: n = {box.n}, nnz(K) = {dev.dK.nnz}, nnz(L) = {stats['nnzL']}, set-up {time.perf_counter() - t_start:.1f} s")
     N = 64
