@@ -12,6 +12,25 @@ from scipy.sparse.linalg import LinearOperator
 from .device import CSRMatrix, Factor, default_context
 
 
+def _with_structural_diagonal(csr):
+    """
+    The symbolic analysis needs every diagonal entry stored.  A shift that annihilates one exactly (sigma = K_pp / M_pp:
+    scipy's subtraction then drops the entry) is a legitimate interior shift: the entry is put back as an explicit zero.
+    """
+    n = csr.shape[0]
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(csr.indptr))
+    have = np.zeros(n, dtype=bool)
+    have[rows[rows == csr.indices]] = True
+    if have.all():
+        return csr
+    miss = np.flatnonzero(~have)
+    coo = csr.tocoo()
+    out = sparse.csr_matrix((np.concatenate([coo.data, np.zeros(len(miss))]),
+                             (np.concatenate([coo.row, miss]), np.concatenate([coo.col, miss]))), shape=csr.shape)
+    out.sort_indices()
+    return out
+
+
 class SpLuOperator(LinearOperator):
     """
     Shift-invert operator ``x -> mat^{-1} x`` factored and applied on the MI355X.
@@ -50,6 +69,7 @@ class SpLuOperator(LinearOperator):
             mat = sparse.csr_matrix((cm.data.real.copy(), cm.indices, cm.indptr), shape=cm.shape)
         csr = mat.tocsr().astype(np.float64)  # for a symmetric matrix CSC and CSR coincide
         csr.sort_indices()
+        csr = _with_structural_diagonal(csr)
         if check_symmetry:
             x = np.random.default_rng(0).uniform(-1.0, 1.0, size=csr.shape[0])
             d = csr @ x - csr.T @ x
