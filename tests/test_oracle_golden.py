@@ -248,3 +248,26 @@ def test_error_behaviour():
     with pytest.raises(ValueError):
         orc.IRAM(mode="nope")
     assert orc.IRAM(N=4).m == 20 and orc.IRAM(N=30, m=40).m == 61
+
+
+def test_oracle_sample_hooks_reproduce_the_full_run():
+    """bench.py times a few modes on the CPU through sibk(modes=...) / laa(cols=...): same columns as the full run"""
+    g = load_golden("g4_laplace900_basiclanczos")
+    K, M = csr_from(g, "K"), csr_from(g, "M")
+    p = "buckling_"
+    A, B = (-0.005 * M).tocsr(), K
+    sigma = float(g[p + "sigma"])
+    fac = orc.SpLuOperator((B + sigma * A).tocsc())
+    lam, Phi, Phib = g[p + "lam"], g[p + "Phi"], g["Phib"]
+    args = (Phib, B, fac, sigma, lam, g[p + "V"], g[p + "Y"], g[p + "theta"], g[p + "indices"])
+    full0 = orc.laa(*args, b_ortho=True, mode="buckling")
+    part0 = orc.laa(*args, b_ortho=True, mode="buckling", cols=[1, 4])
+    assert relerr(part0[:, [1, 4]], full0[:, [1, 4]]) < 1e-12 and not part0[:, [0, 2, 3, 5]].any()
+    full, data, _ = orc.sibk(Phib, A, B, lam, Phi, mode="buckling", psi=full0.copy(), sigma=sigma, factor=fac, rtol=1e-12)
+    for i in (1, 4):
+        one, data1, info = orc.sibk(Phib, A, B, lam, Phi, mode="buckling", psi=part0.copy(), sigma=sigma, factor=fac,
+                                    rtol=1e-12, modes=[i])
+        assert len(info) == 1 and index_sets(data1) == index_sets(data)
+        assert relerr(one[:, i], full[:, i]) < 1e-12
+    with pytest.raises(ValueError):
+        orc.sibk(Phib, A, B, lam, Phi, mode="buckling", sigma=sigma, factor=fac, modes=[0], bs_target=2)
