@@ -494,7 +494,13 @@ def _active_range(done):
     return int(live[0]), int(live[-1]) + 1
 
 
-def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
+def _compact_default():
+    import os
+
+    return os.environ.get("EIGD_COMPACT", "1") != "0"
+
+
+def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist, compact=None):
     """
     One attempt of the bs_target=1 solver for all columns of R0 at once.
     Returns (update block dpsi, converged flags, info list).
@@ -502,9 +508,16 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     The modes advance in lock step; every operator application acts on the contiguous column
     range that still holds unfinished modes (the range shrinks as the low modes converge), so
     late iterations do not pay for finished columns.
+
+    Column compaction: the Krylov histories are row-major n x k slabs, so once most modes have finished a pass over the
+    remaining columns still drags whole 128-byte lines of the finished ones through HBM (8 live bytes per line at the
+    end).  Whenever the live modes have dropped to half the slab width, their columns of W, Z and of the block in flight
+    are gathered into stacks of that width and the iteration goes on there: every later Gram-Schmidt pass, sweep,
+    SpMM and projection streams live data only.  Pure data movement: each column's arithmetic is unchanged.
     """
     ctx, mode = prob.ctx, prob.mode
     k = R0.k
+    compact = _compact_default() if compact is None else compact
     Kop = prob.opB if mode == "normal" else prob.opA  # Krylov operator P K factor (ref 1249-1252)
     sgn = 1.0 if mode == "normal" else -1.0            # ref 1265-1268
     info = [None] * k
@@ -531,6 +544,7 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     H = np.zeros((k, maxiter + 1, maxiter))
     Ycoef = np.zeros((maxiter, k))
     T = ctx.empty(prob.n, k)
+    cols = np.arange(k)          # original column of every column of the current stacks
     jlast = 0
 
     def enqueue_operator(kp, lo, hi, nlive):
@@ -544,11 +558,12 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     def small_solves(j, lo, hi, h, hn):
         """host side of step j: Hessenberg least squares and convergence tests of the live modes (ref 1262-1321)"""
         kp = j - 1
-        for c in range(lo, hi):
+        for cl in range(lo, hi):
+            c = cols[cl]
             if done[c]:
                 continue
-            H[c, :j, kp] = h[:, c - lo]
-            H[c, j, kp] = hn[c - lo]
+            H[c, :j, kp] = h[:, cl - lo]
+            H[c, j, kp] = hn[cl - lo]
             rvec = np.zeros(j + 1)
             rvec[0] = r00[c]
             y, res = solve_shifted_lstsq(sgn * (lam_c[c] - sigma), H[c, : j + 1, :j], rvec)  # ref 1262-1270
@@ -561,10 +576,22 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
                 Ycoef[:j, c] = y
                 done[c] = True
 
+    def flush_finished(nslabs):
+        """psi += Z y for the finished columns of the current stacks (ref 1277 / 1313), scattered to their places"""
+        fin = np.flatnonzero(done[cols])
+        if len(fin) == 0 or nslabs == 0:
+            return
+        upd = ctx.zeros(prob.n, len(cols))
+        Z.axpy_into(upd, Ycoef[:nslabs][:, cols], alpha=1.0)
+        if len(cols) == k and len(fin) == k:
+            dpsi.copy_from(upd)
+        else:
+            upd.gather_cols(fin).scatter_cols_into(dpsi, cols[fin])
+
     # Software pipeline: the device work of step j+1 (sweep, SpMM, projection) is enqueued BEFORE the host does
     # the least-squares problems of step j, so the small dense solves overlap the triangular sweep.  A mode that
     # turns out to have converged at step j rides along for one extra step (its coefficients there are zero).
-    lo, hi = _active_range(done)
+    lo, hi = _active_range(done[cols])
     Ta = enqueue_operator(0, lo, hi, int(np.count_nonzero(~done)))
     for j in range(1, maxiter + 1):
         h = _cgs2(W, Ta, j, c0=lo)                       # ref 1254-1256 (Gram-Schmidt vs all previous W)
@@ -573,7 +600,7 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
         cur = (lo, hi)
         nxt = None
         if j < maxiter:
-            W[j].cols(lo, hi).assign_scaled_inverse(Ta, hn2, done[lo:hi])  # ref 1260 ... where the next basis vector
+            W[j].cols(lo, hi).assign_scaled_inverse(Ta, hn2, done[cols[lo:hi]])  # ref 1260 ... where the next basis vector
             nxt = enqueue_operator(j, lo, hi, 0)         # is formed; the host reads them behind the sweep in flight
         hn = np.sqrt(ctx.fetch_colnorm2(cur[1] - cur[0]))
         small_solves(j, cur[0], cur[1], h, hn)
@@ -583,15 +610,33 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
             with prob.fac.factor._count_lock:
                 prob.fac.factor.count += int(np.count_nonzero(~done))
         if nxt is not None:
+            live = np.flatnonzero(~done[cols])
+            if compact and len(cols) > 1 and 2 * len(live) <= len(cols):
+                # narrower stacks for the live modes: W[0..j], Z[0..j] (Z[j] and the block in flight are enqueued:
+                # stream order makes them visible to the gathers)
+                flush_finished(j)                        # finished columns leave with their share of the update
+                kc = len(live)
+                kw = 1 << max(kc - 1, 0).bit_length()     # stack widths 16, 8, 4, 2, 1: stable shapes for the workspace cache
+                Wn = ctx.workspace_stack(f"krylov_W/{kw}", maxiter + 1, prob.n, kw)
+                Zn = ctx.workspace_stack(f"krylov_Z/{kw}", maxiter, prob.n, kw)
+                Tn = ctx.empty(prob.n, kw)
+                for s_ in range(j + 1):
+                    W[s_].gather_cols_into(Wn[s_].cols(0, kc), live)
+                    Z[s_].gather_cols_into(Zn[s_].cols(0, kc), live)
+                T.gather_cols_into(Tn.cols(0, kc), live)
+                W, Z, T, cols = Wn, Zn, Tn, cols[live]
+                lo, hi = 0, kc
+                Ta = T.cols(0, kc)
+                continue
             # the step in flight keeps the range it was launched with; narrower ranges apply from the step after.
             # Columns that finished meanwhile are zeroed when the next basis vector is formed (scale above).
-            nlo, nhi = _active_range(done)
+            nlo, nhi = _active_range(done[cols])
             if (nlo, nhi) != (lo, hi):
                 Ta = nxt.cols(nlo - lo, nhi - lo)
                 lo, hi = nlo, nhi
             else:
                 Ta = nxt
-    Z.axpy_into(dpsi, Ycoef[:jlast], alpha=1.0)          # ref 1277 / 1313: psi += Z y
+    flush_finished(jlast)                                # ref 1277 / 1313: psi += Z y
     return dpsi, converged, info
 
 

@@ -337,6 +337,18 @@ class DeviceBlock:
                  out.cols(c0, c1).ptr, out.ld)
         return out
 
+    def gather_cols_into(self, dst, cols):
+        """dst[:, j] = self[:, cols[j]] into an existing block (a slab of a narrower Krylov stack)"""
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        if (dst.n, dst.k) != (self.n, len(cols)):
+            raise ValueError("shape mismatch in column gather")
+        for c0 in range(0, len(cols), 64):
+            c1 = min(len(cols), c0 + 64)
+            sub = np.ascontiguousarray(cols[c0:c1])
+            call("eigd_gather_cols", self.ctx.h, self.n, c1 - c0, self.ptr, self.ld, hptr(sub),
+                 dst.cols(c0, c1).ptr, dst.ld)
+        return dst
+
     def scatter_cols_into(self, dst, cols):
         cols = np.ascontiguousarray(cols, dtype=np.int32)
         for c0 in range(0, len(cols), 64):
