@@ -497,7 +497,9 @@ def _active_range(done):
 def _compact_default():
     import os
 
-    return os.environ.get("EIGD_COMPACT", "1") != "0"
+    # off by default: measured on C3 (32 modes) the gathers of a repack cost what the narrower passes save (136 ms per
+    # step either way): late iterations are bound by the k-independent part (sweep latency, projections), not by bytes
+    return os.environ.get("EIGD_COMPACT", "0") == "1"
 
 
 def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist, compact=None):
@@ -509,11 +511,11 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist, compa
     range that still holds unfinished modes (the range shrinks as the low modes converge), so
     late iterations do not pay for finished columns.
 
-    Column compaction: the Krylov histories are row-major n x k slabs, so once most modes have finished a pass over the
-    remaining columns still drags whole 128-byte lines of the finished ones through HBM (8 live bytes per line at the
-    end).  Whenever the live modes have dropped to half the slab width, their columns of W, Z and of the block in flight
-    are gathered into stacks of that width and the iteration goes on there: every later Gram-Schmidt pass, sweep,
-    SpMM and projection streams live data only.  Pure data movement: each column's arithmetic is unchanged.
+    Column compaction (``compact`` / EIGD_COMPACT=1, off by default): the Krylov histories are row-major n x k slabs, so
+    once most modes have finished a pass over the remaining columns still drags whole 128-byte lines of the finished
+    ones through HBM.  With compaction, whenever the live modes have dropped to half the slab width their columns of W,
+    Z and of the block in flight are gathered into stacks of that width and the iteration goes on there.  Pure data
+    movement: each column's arithmetic is unchanged (tested); measured gain at C3: none (see _compact_default).
     """
     ctx, mode = prob.ctx, prob.mode
     k = R0.k

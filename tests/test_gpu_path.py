@@ -901,3 +901,31 @@ def test_c3_full_size_properties():
     col.rhoE = rho0
     fd = (f[0] - f[1]) / (2.0 * h)
     assert abs(float(dfdx @ p) - fd) < 1e-5 * abs(fd)
+
+
+def test_column_compaction_of_the_krylov_stacks_changes_no_column():
+    """EIGD_COMPACT=1: the live columns move to narrower stacks once half have finished -- same psi, data, histories"""
+    import eigd_amd as eg
+    import eigd_amd.adjoint as adj
+
+    g = load_golden("g4_laplace900_basiclanczos")
+    K, M = csr_from(g, "K"), csr_from(g, "M")
+    fac = eg.SpLuOperator((K + 0.1 * M).tocsc())
+    s = eg.BasicLanczos(N=6, m=60)
+    s.solve(K, M, fac, -0.1)
+    out = {}
+    orig = adj._compact_default
+    try:
+        for flag in (False, True):
+            adj._compact_default = lambda flag=flag: flag
+            hist = []
+            fac.count = 0
+            psi, data = s.solve_adjoint(g["Phib"], method="sibk", rtol=1e-12, lanczos_guess=False, callback=hist.append)
+            out[flag] = (psi, data, hist, fac.count)
+    finally:
+        adj._compact_default = orig
+    assert relerr(out[True][0], out[False][0]) < 1e-12
+    assert index_sets(out[True][1]) == index_sets(out[False][1])
+    assert len(out[True][2]) == len(out[False][2]) and np.allclose(out[True][2], out[False][2], rtol=1e-6, atol=1e-14)
+    assert out[True][3] == out[False][3]
+    assert relerr(out[True][0], g["normal_sibk_psi"]) < 1e-8
