@@ -1186,8 +1186,8 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-template <int KB, int NSL>
-__global__ __launch_bounds__(128) void fwd_wave_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
+template <int KB, int NSL, int WPF>  // WPF: waves per front (each loads the front's right-hand side block)
+__global__ __launch_bounds__(64 * WPF) void fwd_wave_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
                                                        const double* __restrict__ F, const double* __restrict__ Tb,
                                                        const double* X, int ldx, double alpha, double* V,
                                                        double* __restrict__ Y, int kb) {
@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(128) void fwd_wave_kernel(FrontArrays fa, const WgR
     }
   }
   double* Vout = V + static_cast<int64_t>(w.slot) * vslot;
-  for (int rt = w.s0 + wave; rt < w.s1; rt += 2) {
+  for (int rt = w.s0 + wave; rt < w.s1; rt += WPF) {
     const bool own = rt < 1;
     const int row0 = own ? 0 : ns + (rt - 1) * TW;
     const int rows = min(TW, (own ? ns : d) - row0);
@@ -1344,7 +1344,9 @@ __global__ __launch_bounds__(64) void bwd_wave_kernel(FrontArrays fa, const WgRe
 // wave needs is requested in one or two rounds, and 12 to 16 waves per CU are in flight.
 //
 // forward: wave = 16-row blocks rb, rb + 2, ... of [T; M21] (two waves per front).  K = own columns (NKS steps of 4).
-template <int KB, int NKS, int NSL, int WPF>  // WPF: waves per front (1: the right-hand side block is loaded once per front)
+// WPF: waves per front (1: the right-hand side block is loaded once per front); TRI: T has lower triangular diagonal
+// blocks (Cholesky path) -- false on the Bunch-Kaufman path, whose diagonal blocks are dense
+template <int KB, int NKS, int NSL, int WPF, bool TRI>
 __global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
                                                        const double* __restrict__ F, const double* __restrict__ Tb,
                                                        const double* X, int ldx, double alpha, double* V,
@@ -1393,7 +1395,7 @@ __global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, cons
     const int r = 16 * rb + li;  // the row this lane feeds as A operand
     // a block of 16 own rows meets only zeros of T past its diagonal block (T is lower triangular): those K-steps
     // read the zero word instead of streaming zeros from HBM (wave-uniform bound)
-    const int smax = (fa.tri && 16 * rb + 16 <= ns) ? 4 * (rb + 1) : NKS;
+    const int smax = (TRI && 16 * rb + 16 <= ns) ? 4 * (rb + 1) : NKS;
     double a[NKS];
 #pragma unroll
     for (int s = 0; s < NKS; ++s) {
@@ -1464,7 +1466,7 @@ __global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, cons
 // front in chunks of 4 CH, from the transposed copy Ft (row r of [T; M21] at r * ns: a K-step reads whole rows).  The
 // border rows of the caller's block are found through bout, which the wave holds lane by lane (bs <= 320) and reads
 // with ds_bpermute: no dependent index round per chunk.
-template <int KB, int NOB, int CH>
+template <int KB, int NOB, int CH, bool TRI>
 __global__ __launch_bounds__(64) void bwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
                                                       const double* __restrict__ Ft, const double* __restrict__ Y,
                                                       double* Out, int ldo, int kb) {
@@ -1502,7 +1504,7 @@ __global__ __launch_bounds__(64) void bwd_thin_kernel(FrontArrays fa, const WgRe
       for (int ob = 0; ob < NOB; ++ob) {
         const int o = 16 * ob + li;
         // (rows of T above the diagonal block of these 16 columns hold zeros: wave-uniform test, not fetched)
-        a[s][ob] = *((k < d && o < ns && !(fa.tri && 4 * CH * ch + 4 * s + 3 < 16 * ob)) ? Fp + static_cast<int64_t>(k) * ns + o : fa.zero);
+        a[s][ob] = *((k < d && o < ns && !(TRI && 4 * CH * ch + 4 * s + 3 < 16 * ob)) ? Fp + static_cast<int64_t>(k) * ns + o : fa.zero);
       }
       const int e = k - ns;  // border entry
       const int r0 = __shfl(I[0], e & 63), r1 = __shfl(I[1], e & 63), r2 = __shfl(I[2], e & 63), r3 = __shfl(I[3], e & 63);
@@ -1807,15 +1809,26 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     bool narrow = false;
     if (KPT <= wave_max_kpt) {
       if (nwave > 0) {  // narrow sweep: one wave per tile of the single-tile fronts
+        static const int wave_wpf = [] {
+          const char* v = std::getenv("EIGD_WAVE_WPF");
+          return (v && *v) ? std::atoi(v) : 2;
+        }();
+#define EIGD_WAVE_FWD(NSLV)                                                                                           \
+  do {                                                                                                                \
+    if (wave_wpf == 1)                                                                                                \
+      hipLaunchKernelGGL((fwd_wave_kernel<KB, NSLV, 1>), dim3(nwave), dim3(64), 0, st, fa,                            \
+                         f->d_wave_wg + f->h_wave_ptr[l], sF, sT, dIn, ldin, alpha, wV, wY, kb);                      \
+    else                                                                                                              \
+      hipLaunchKernelGGL((fwd_wave_kernel<KB, NSLV, 2>), dim3(nwave), dim3(128), 0, st, fa,                           \
+                         f->d_wave_wg + f->h_wave_ptr[l], sF, sT, dIn, ldin, alpha, wV, wY, kb);                      \
+  } while (0)
         if (leaf)
-          hipLaunchKernelGGL((fwd_wave_kernel<KB, 0>), dim3(nwave), dim3(128), 0, st, fa, f->d_wave_wg + f->h_wave_ptr[l],
-                             sF, sT, dIn, ldin, alpha, wV, wY, kb);
+          EIGD_WAVE_FWD(0);
         else if (two)
-          hipLaunchKernelGGL((fwd_wave_kernel<KB, 2>), dim3(nwave), dim3(128), 0, st, fa, f->d_wave_wg + f->h_wave_ptr[l],
-                             sF, sT, dIn, ldin, alpha, wV, wY, kb);
+          EIGD_WAVE_FWD(2);
         else
-          hipLaunchKernelGGL((fwd_wave_kernel<KB, kMaxS + 1>), dim3(nwave), dim3(128), 0, st, fa,
-                             f->d_wave_wg + f->h_wave_ptr[l], sF, sT, dIn, ldin, alpha, wV, wY, kb);
+          EIGD_WAVE_FWD(kMaxS + 1);
+#undef EIGD_WAVE_FWD
         EIGD_LAUNCH_CHECK();
         narrow = true;
       }
@@ -1833,12 +1846,15 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
         const bool one = thin_wpf != 2;
 #define EIGD_THIN_FWD(NKS, NSLV)                                                                                        \
   do {                                                                                                                  \
-    if (one)                                                                                                            \
-      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1>), dim3(nwave), dim3(64), 0, st, fa, recs, sF, sT, dIn, ldin,  \
-                         alpha, wV, wY, kb);                                                                            \
+    if (!fa.tri)                                                                                                        \
+      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, false>), dim3(nwave), dim3(64), 0, st, fa, recs, sF, sT, dIn, \
+                         ldin, alpha, wV, wY, kb);                                                                      \
+    else if (one)                                                                                                       \
+      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, true>), dim3(nwave), dim3(64), 0, st, fa, recs, sF, sT, dIn,  \
+                         ldin, alpha, wV, wY, kb);                                                                      \
     else                                                                                                                \
-      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 2>), dim3(nwave), dim3(128), 0, st, fa, recs, sF, sT, dIn, ldin, \
-                         alpha, wV, wY, kb);                                                                            \
+      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 2, true>), dim3(nwave), dim3(128), 0, st, fa, recs, sF, sT, dIn, \
+                         ldin, alpha, wV, wY, kb);                                                                      \
   } while (0)
         if (leaf && nks == 4)
           EIGD_THIN_FWD(4, 0);
@@ -1916,12 +1932,22 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
       if constexpr (KPT >= 4) {
         const WgRec* recs = f->d_wave_wg + f->h_wave_ptr[l];
         const int nks = f->h_thin_bwd[l];
+#define EIGD_THIN_BWD(NOB, CHV)                                                                                   \
+  do {                                                                                                            \
+    if (fa.tri)                                                                                                   \
+      hipLaunchKernelGGL((bwd_thin_kernel<KB, NOB, CHV, true>), dim3(nwave), dim3(64), 0, st, fa, recs, f->d_Ft, wY, \
+                         dX, ldx, kb);                                                                            \
+    else                                                                                                          \
+      hipLaunchKernelGGL((bwd_thin_kernel<KB, NOB, CHV, false>), dim3(nwave), dim3(64), 0, st, fa, recs, f->d_Ft, \
+                         wY, dX, ldx, kb);                                                                        \
+  } while (0)
         if (nks == 4)
-          hipLaunchKernelGGL((bwd_thin_kernel<KB, 1, 8>), dim3(nwave), dim3(64), 0, st, fa, recs, f->d_Ft, wY, dX, ldx, kb);
+          EIGD_THIN_BWD(1, 8);
         else if (nks == 8)
-          hipLaunchKernelGGL((bwd_thin_kernel<KB, 2, 8>), dim3(nwave), dim3(64), 0, st, fa, recs, f->d_Ft, wY, dX, ldx, kb);
+          EIGD_THIN_BWD(2, 8);
         else
-          hipLaunchKernelGGL((bwd_thin_kernel<KB, 4, 4>), dim3(nwave), dim3(64), 0, st, fa, recs, f->d_Ft, wY, dX, ldx, kb);
+          EIGD_THIN_BWD(4, 4);
+#undef EIGD_THIN_BWD
         EIGD_LAUNCH_CHECK();
       }
     } else if (nsb > 0) {  // single-column-tile fronts: LDS tiles as tall as the level needs
