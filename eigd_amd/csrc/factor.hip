@@ -838,11 +838,12 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
       const int idx = threadIdx.x + e * kThreads;
       const int c = idx & (T::KB - 1);
       const bool ok = c < kb && xi[e] >= 0;
-      double v = alpha * *(ok ? X + static_cast<int64_t>(xi[e]) * ldx + c : fa.zero);
+      const double xv = alpha * *(ok ? X + static_cast<int64_t>(xi[e]) * ldx + c : fa.zero);
       const double* cp = V + (vbase + ct * TW + idx / T::KB) * T::KB + c;
-#pragma unroll
+      double v = 0.0;  // the children's carries first, in plane order, then the right-hand side: alpha x + (p0 + p1 + ..)
+#pragma unroll         // -- the association every forward kernel (and the in-LDS sums of the subtree kernels) uses
       for (int s = 0; s < NSL; ++s) v += *((ok && s < nslot) ? cp + s * vslot : fa.zero);
-      bv[e] = v;
+      bv[e] = xv + v;
     }
   };
   // tile (row tile rt, column tile ct) of [T; M21]: element (r, j) at base + j*ld + r
@@ -989,11 +990,12 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
         const int idx = threadIdx.x + e * kThreads;
         const int c = idx & (T::KB - 1);
         const bool ok = c < kb && xi[e] >= 0;
-        double v = alpha * *(ok ? X + static_cast<int64_t>(xi[e]) * ldx + c : fa.zero);
+        const double xv = alpha * *(ok ? X + static_cast<int64_t>(xi[e]) * ldx + c : fa.zero);
         const double* cp = V + (vbase + idx / T::KB) * T::KB + c;
+        double v = 0.0;
 #pragma unroll
         for (int s = 0; s < NSL; ++s) v += *((ok && s < nslot) ? cp + s * vslot : fa.zero);
-        vh[e - h] = v;
+        vh[e - h] = xv + v;
       }
 #pragma unroll
       for (int e = h; e < h + HB; ++e) {
@@ -1206,10 +1208,11 @@ __global__ __launch_bounds__(64 * WPF) void fwd_wave_kernel(FrontArrays fa, cons
 #pragma unroll
     for (int c = 0; c < KB; ++c) {
       const bool okc = ok && c < kb;
-      double v = alpha * *(okc ? X + static_cast<int64_t>(xi) * ldx + c : fa.zero);
+      const double xv = alpha * *(okc ? X + static_cast<int64_t>(xi) * ldx + c : fa.zero);
+      double v = 0.0;
 #pragma unroll
       for (int s = 0; s < NSL; ++s) v += *((okc && s < nslot) ? cp + s * vslot + c : fa.zero);
-      b[c] = v;
+      b[c] = xv + v;
     }
   }
   double* Vout = V + static_cast<int64_t>(w.slot) * vslot;
@@ -1373,11 +1376,12 @@ __global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, cons
       for (int nb = 0; nb < NB; ++nb) {
         const int o = 4 * s + lk, n = 16 * nb + li;
         const bool ok = xi[s] >= 0 && n < kb;
-        double v = alpha * *(ok ? X + static_cast<int64_t>(xi[s]) * ldx + n : fa.zero);
+        const double xv = alpha * *(ok ? X + static_cast<int64_t>(xi[s]) * ldx + n : fa.zero);
         const double* cp = V + (vbase + o) * KB + n;
+        double v = 0.0;
 #pragma unroll
         for (int sl = 0; sl < NSL; ++sl) v += *((ok && ((mo[s] >> sl) & 1)) ? cp + sl * vslot : fa.zero);
-        b[s][nb] = v;
+        b[s][nb] = xv + v;
       }
   }
   double* Vout = V + static_cast<int64_t>(w.slot) * vslot;
@@ -1539,6 +1543,150 @@ __global__ __launch_bounds__(64) void bwd_thin_kernel(FrontArrays fa, const WgRe
       }
 }
 
+
+// ------------------------------------------------------------------ fused bottom subtrees (forward)
+// The levels next to the leaves hold most of the factor AND most of the carry traffic: a front's carry is written to
+// a plane in HBM by its level's launch and read back by the parent's launch one level up.  A fused subtree keeps
+// those carries on the chip: ONE workgroup walks a whole bottom subtree (its fronts level by level, a barrier
+// between levels); a front adds its carry into the parent's accumulator in LDS (ds_add_f64: every parent row receives
+// at most one value from each of its at most two children, and an addition of two numbers does not depend on the
+// order), the parent reads its right-hand side and its border carries from there.  Only the subtree root writes a
+// carry to HBM (into its plane, as before).  Per front the arithmetic is that of fwd_thin_kernel -- MFMA operands
+// straight from global memory, v1 = alpha x + (p0 + p1) -- so the result is bitwise the one of the level-by-level path.
+struct SubFront {
+  WgRec w;     // the front's numbers, as in the per-level records
+  int acc;     // first row of this front's accumulator in the workgroup's LDS block; -1: no children
+  int pacc;    // first row of the parent's accumulator; -1: the subtree root (its carry goes to the global plane)
+  int nks;     // K-steps of 4 own columns the front needs: 4, 8 or 16
+  int w0, wpf; // the waves [w0, w0 + wpf) of the workgroup share this front's blocks of 16 rows
+  int phase;   // level inside the subtree
+  int pad0, pad1;
+};
+struct SubTree {
+  int first, count, rows, nphase;  // its SubFront records (phases ascending), accumulator rows, number of phases
+};
+
+constexpr int kSubWaves = 4;
+
+template <int KB, int NKS>
+__device__ __forceinline__ void subtree_front_fwd(const FrontArrays& fa, const SubFront& sf, int sub,
+                                                  const double* __restrict__ F, const double* __restrict__ Tb,
+                                                  const double* X, int ldx, double alpha, double* V,
+                                                  double* __restrict__ Y, int kb, double* acc) {
+  constexpr int NB = KB / 16;
+  const WgRec& w = sf.w;
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ns = w.ns, d = ns + w.bs;
+  const int64_t vslot = fa.vrows * KB, vbase = w.voff;
+  const bool kids = sf.acc >= 0;
+  const double* accf = acc + static_cast<int64_t>(kids ? sf.acc : 0) * KB;
+  // v1 = alpha * X[own rows] + (the children's carries, summed in LDS), as B operands
+  double b[NKS][NB];
+  {
+    int xi[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) xi[s] = *((4 * s + lk < ns) ? fa.v_src + vbase + 4 * s + lk : fa.neg1);
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int o = 4 * s + lk, n = 16 * nb + li;
+        const bool ok = xi[s] >= 0 && n < kb;
+        const double xv = alpha * *(ok ? X + static_cast<int64_t>(xi[s]) * ldx + n : fa.zero);
+        const double cv = (kids && ok) ? accf[o * KB + n] : 0.0;
+        b[s][nb] = xv + cv;
+      }
+  }
+  double* Vout = V + static_cast<int64_t>(w.slot) * vslot;
+  const double* Tf = Tb + w.toff;
+  const double* Ff = F + w.foff;
+  const int nrb = (d + 15) >> 4;
+  for (int rb = sub; rb < nrb; rb += sf.wpf) {
+    const int r = 16 * rb + li;
+    const int smax = (fa.tri && 16 * rb + 16 <= ns) ? 4 * (rb + 1) : NKS;
+    double a[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      const int o = 4 * s + lk;
+      const double* p = (r < ns) ? Tf + static_cast<int64_t>(o) * w.ldt + r : Ff + static_cast<int64_t>(o) * d + r;
+      a[s] = *((o < ns && r < d && s < smax) ? p : fa.zero);
+    }
+    int di[4];
+    double sg[4], cg[4][NB];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int ro = 16 * rb + lk + 4 * reg;
+      const bool border = ro >= ns && ro < d;
+      di[reg] = *(border ? fa.rel + w.bptr + (ro - ns) : fa.neg1);
+      sg[reg] = *((ro < ns) ? fa.sgn + w.c0 + ro : fa.zero);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = 16 * nb + li;
+        cg[reg][nb] = (kids && border && n < kb) ? accf[ro * KB + n] : 0.0;
+      }
+    }
+    double4_t c[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) c[nb] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) c[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s][nb], c[nb], 0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one wait, then the stores back to back
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int ro = 16 * rb + lk + 4 * reg;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = 16 * nb + li;
+        if (ro < ns) {
+          if (n < kb) Y[(vbase + ro) * kb + n] = sg[reg] * c[nb][reg];
+        } else if (di[reg] >= 0 && n < kb) {
+          const double val = cg[reg][nb] - c[nb][reg];
+          if (sf.pacc >= 0)
+            __hip_atomic_fetch_add(acc + (static_cast<int64_t>(sf.pacc) + di[reg]) * KB + n, val, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+          else
+            Vout[(w.pvoff + di[reg]) * KB + n] = val;
+        }
+      }
+    }
+  }
+}
+
+template <int KB>
+__global__ __launch_bounds__(64 * kSubWaves) void fwd_subtree_kernel(FrontArrays fa, const SubTree* __restrict__ trees,
+                                                                     const SubFront* __restrict__ fronts,
+                                                                     const double* __restrict__ F,
+                                                                     const double* __restrict__ Tb, const double* X,
+                                                                     int ldx, double alpha, double* V,
+                                                                     double* __restrict__ Y, int kb) {
+  extern __shared__ double sub_acc[];
+  const SubTree st = trees[blockIdx.x];
+  for (int i = threadIdx.x; i < st.rows * KB; i += 64 * kSubWaves) sub_acc[i] = 0.0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  int q = st.first;
+  const int qend = st.first + st.count;
+  for (int ph = 0; ph < st.nphase; ++ph) {
+    while (q < qend && fronts[q].phase == ph) {
+      const int w0 = fronts[q].w0, wpf = fronts[q].wpf;
+      if (wave >= w0 && wave < w0 + wpf) {
+        const SubFront sf = fronts[q];
+        if (sf.nks == 4)
+          subtree_front_fwd<KB, 4>(fa, sf, wave - w0, F, Tb, X, ldx, alpha, V, Y, kb, sub_acc);
+        else if (sf.nks == 8)
+          subtree_front_fwd<KB, 8>(fa, sf, wave - w0, F, Tb, X, ldx, alpha, V, Y, kb, sub_acc);
+        else
+          subtree_front_fwd<KB, 16>(fa, sf, wave - w0, F, Tb, X, ldx, alpha, V, Y, kb, sub_acc);
+      }
+      ++q;
+    }
+    __syncthreads();
+  }
+}
+
 // Ft(r, o) = [T; M21](r, o), row-major d x ns per front: 64 x 64 tiles through LDS
 __global__ __launch_bounds__(kThreads) void transpose_front_kernel(FrontArrays fa, const int* __restrict__ tr_pref,
                                                                   int nfronts, const int64_t* __restrict__ ftoff,
@@ -1618,6 +1766,11 @@ struct eigd_factor {
   // narrow sweeps (k <= 8): one record per single-tile front and level, the transposed copy of [T; M21]
   WgRec* d_wave_wg = nullptr;
   std::vector<int> h_wave_ptr;
+  // fused bottom subtrees (sweeps of 16 / 32 columns): their fronts sit at the END of each level's wave records
+  SubTree* d_sub_trees = nullptr;
+  SubFront* d_sub_fronts = nullptr;
+  int n_subtrees = 0, sub_rows_max = 0;
+  std::vector<int> h_wave_free;  // per level: leading records of fronts outside the fused subtrees
   int64_t* d_ftoff = nullptr;
   int* d_tr_pref = nullptr;
   double* d_Ft = nullptr;
@@ -1792,6 +1945,21 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
   auto lds_bytes = [](int kd) { return static_cast<unsigned>(sizeof(double) * (kd + 1) * (TLD + Tile<KPT>::BLD)); };
   const double* sF = f->d_Pk ? f->d_Pk : f->d_F;  // the panels [T; M21]: packed copy, or in place (F and T)
   const double* sT = f->d_Pk ? f->d_Pk : f->d_T;
+  // fused bottom subtrees (16 / 32 columns): one launch for all their levels; the per-level launches below then
+  // only see the fronts outside them (a prefix of each level's wave records)
+  static const bool fuse_fwd = [] {
+    const char* v = std::getenv("EIGD_FUSE_FWD");
+    return (v && *v) ? std::atoi(v) != 0 : true;
+  }();
+  const bool fused_f = KPT >= 4 && fuse_fwd && f->n_subtrees > 0;
+  if constexpr (KPT >= 4) {
+    if (fused_f) {
+      hipLaunchKernelGGL((fwd_subtree_kernel<KB>), dim3(f->n_subtrees), dim3(64 * kSubWaves),
+                         sizeof(double) * f->sub_rows_max * KB, st, fa, f->d_sub_trees, f->d_sub_fronts, sF, sT, dIn, ldin,
+                         alpha, wV, wY, kb);
+      EIGD_LAUNCH_CHECK();
+    }
+  }
   // ---- forward: leaves -> root.  Y receives S z, the border rows of V the carries.
   for (int l = 0; l < s.nlevels; ++l) {
     const int nov = f->ov_lvl_ptr[l + 1] - f->ov_lvl_ptr[l];
@@ -1835,8 +2003,11 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     }
     if constexpr (KPT >= 4) {
       const int nks = f->h_thin_fwd[l];
+      if (!narrow && nwave > 0 && nks > 0 && fused_f && f->h_wave_free[l] == 0) narrow = true;  // the whole level is fused
       if (!narrow && nwave > 0 && nks > 0) {  // thin fronts: one wave per block of rows, operands straight from memory
         const WgRec* recs = f->d_wave_wg + f->h_wave_ptr[l];
+        const int nwave_all = nwave;
+        const int nwave = fused_f ? f->h_wave_free[l] : nwave_all;  // (shadows: the launches below take the unfused prefix)
         // waves per front: with one, the front's right-hand side block (and its carries) is loaded once instead of
         // once per wave (measured on C3, 32 columns: 1.654 -> 1.606 ms per sweep; EIGD_THIN_WPF=2 restores two)
         static const int thin_wpf = [] {
@@ -2061,7 +2232,7 @@ int eigd_factor_free(eigd_factor* f) {
                   f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_ov_dst,   f->d_ov_ptr, f->d_ov_src,
                   f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux,      f->d_bout,  f->d_tickets,
                   f->d_P,         f->d_wave_wg,     f->d_ftoff,      f->d_tr_pref,  f->d_Ft,
-                  f->d_pkoff,     f->d_Pk};
+                  f->d_pkoff,     f->d_Pk,          f->d_sub_trees,  f->d_sub_fronts};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;
@@ -2323,6 +2494,114 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   f->n_tickets = std::max(1, n_tickets);
   f->n_tri = tri_pref[nf];
   f->n_m21 = m_pref[nf];
+
+  // ---- fused bottom subtrees (see fwd_subtree_kernel).  Roots are chosen top-down: the highest fronts whose whole
+  // subtree consists of single-column-tile fronts on levels the wave-per-block kernels serve, with at most two
+  // children each, and whose accumulators (one block of own + border rows per front that has children) fit the LDS budget.
+  std::vector<SubTree> sub_trees;
+  std::vector<SubFront> sub_fronts;
+  std::vector<int> h_wave_free(static_cast<size_t>(s.nlevels), 0);
+  int sub_rows_max = 0;
+  {
+    // OFF by default (EIGD_FUSE=1 turns it on): measured on the 1 M-dof benchmark the fused launch takes 665 us where
+    // the three level launches it replaces take 410 us (32 columns; 1.88 against 1.58 ms per sweep) -- 65 KB of
+    // accumulators per workgroup leave two workgroups per CU, and every level of the subtree adds a barrier and a round
+    // of dependent loads (record -> indices -> operands) that the wave-per-block kernels overlap across 12 waves per
+    // CU.  The bytes saved (15 % of a sweep) do not pay for that; kept as a tested option for narrower accumulators.
+    const int fuse_levels = env_int("EIGD_FUSE", 0) != 0 ? env_int("EIGD_FUSE_LEVELS", 2) : -1;
+    const int fuse_rows = std::min(255, env_int("EIGD_FUSE_ROWS", 255));  // 255 rows x 32 columns x 8 B < 64 KiB
+    std::vector<std::vector<int>> kidsof(static_cast<size_t>(nf));
+    for (int c = 0; c < nf; ++c)
+      if (s.f_parent[c] >= 0 && s.f_bs[c] > 0) kidsof[s.f_parent[c]].push_back(c);
+    // rows[q]: accumulator rows of the subtree below q if every front in it qualifies, -1 otherwise (postorder: children first)
+    std::vector<int> rows(static_cast<size_t>(nf), -1);
+    for (int q = 0; q < nf; ++q) {
+      const int l = s.f_level[q];
+      bool ok = s.f_ns[q] <= TW && s.f_ns[q] > 0 && l <= fuse_levels && f->h_thin_fwd[l] > 0 && f->h_thin_bwd[l] > 0 &&
+                kidsof[q].size() <= 2 && child_no[q] < kMaxS;
+      int r = kidsof[q].empty() ? 0 : s.f_ns[q] + s.f_bs[q];
+      for (int c : kidsof[q]) {
+        if (rows[c] < 0) ok = false;
+        else r += rows[c];
+      }
+      // a child that is not a carry child (no border) hangs below q in the tree only formally: nothing to check
+      rows[q] = (ok && r <= fuse_rows) ? r : -1;
+    }
+    std::vector<char> fused(static_cast<size_t>(nf), 0);
+    for (int q = nf - 1; q >= 0; --q) {
+      if (fused[q] || rows[q] <= 0) continue;  // (rows == 0: a leaf on its own -- nothing to fuse)
+      // collect the subtree, levels ascending
+      std::vector<int> members, stack{q};
+      while (!stack.empty()) {
+        const int x = stack.back();
+        stack.pop_back();
+        members.push_back(x);
+        fused[x] = 1;
+        for (int c : kidsof[x]) stack.push_back(c);
+      }
+      std::stable_sort(members.begin(), members.end(), [&](int a, int b) {
+        return s.f_level[a] != s.f_level[b] ? s.f_level[a] < s.f_level[b] : a < b;
+      });
+      std::vector<int> accoff(members.size(), -1);
+      int off = 0;
+      for (size_t i = 0; i < members.size(); ++i)
+        if (!kidsof[members[i]].empty()) {
+          accoff[i] = off;
+          off += s.f_ns[members[i]] + s.f_bs[members[i]];
+        }
+      auto acc_of = [&](int fr) {
+        for (size_t i = 0; i < members.size(); ++i)
+          if (members[i] == fr) return accoff[i];
+        return -1;
+      };
+      SubTree st;
+      st.first = static_cast<int>(sub_fronts.size());
+      st.count = static_cast<int>(members.size());
+      st.rows = off;
+      int phase = -1, lastlvl = -1;
+      size_t i = 0;
+      while (i < members.size()) {
+        size_t j = i;
+        while (j < members.size() && s.f_level[members[j]] == s.f_level[members[i]]) ++j;
+        ++phase;
+        lastlvl = s.f_level[members[i]];
+        const int nfp = static_cast<int>(j - i);
+        const int wpf = nfp >= kSubWaves ? 1 : kSubWaves / nfp;
+        for (size_t t = i; t < j; ++t) {
+          const int fr = members[t];
+          SubFront sf;
+          front_numbers(sf.w, fr);
+          sf.w.tile = 0;
+          sf.w.s0 = sf.w.s1 = 0;
+          sf.w.slab = sf.w.cnt = 0;
+          sf.w.G = 1;
+          sf.w.flags = 1 | (kidsof[fr].empty() ? 0 : 2);
+          sf.acc = accoff[t];
+          sf.pacc = (fr == q) ? -1 : acc_of(s.f_parent[fr]);
+          sf.nks = (s.f_ns[fr] <= 16) ? 4 : (s.f_ns[fr] <= 32) ? 8 : 16;
+          sf.wpf = wpf;
+          sf.w0 = nfp >= kSubWaves ? static_cast<int>((t - i) % kSubWaves) : static_cast<int>(t - i) * wpf;
+          sf.phase = phase;
+          sf.pad0 = sf.pad1 = 0;
+          sub_fronts.push_back(sf);
+        }
+        i = j;
+      }
+      (void)lastlvl;
+      st.nphase = phase + 1;
+      sub_rows_max = std::max(sub_rows_max, st.rows);
+      sub_trees.push_back(st);
+    }
+    // the fused fronts go to the end of their level's wave records: the per-level launches then take a prefix
+    for (int l = 0; l < s.nlevels; ++l) {
+      auto b = wave_wg.begin() + h_wave_ptr[l], e = wave_wg.begin() + h_wave_ptr[l + 1];
+      auto mid = std::stable_partition(b, e, [&](const WgRec& w) { return !fused[w.f]; });
+      h_wave_free[l] = static_cast<int>(mid - b);
+    }
+  }
+  f->h_wave_free = h_wave_free;
+  f->n_subtrees = static_cast<int>(sub_trees.size());
+  f->sub_rows_max = sub_rows_max;
   int rc = EIGD_OK;
 #define UP(dst, vec)                          \
   if (rc == EIGD_OK) rc = upload(f, &f->dst, vec);
@@ -2341,6 +2620,8 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   UP(d_fwd_wg, fwd_wg)
   UP(d_bwd_wg, bwd_wg)
   UP(d_wave_wg, wave_wg)
+  UP(d_sub_trees, sub_trees)
+  UP(d_sub_fronts, sub_fronts)
   UP(d_ftoff, ftoff)
   if (packed) {
     UP(d_pkoff, pkoff)

@@ -588,3 +588,38 @@ def test_interior_shift_eigenpairs_and_adjoint_with_streams(ctx):
     assert relerr(psi3, psi1) < 1e-9
     res, _ = s.eval_adjoint_residual_norm(Phib, psi3, b_ortho=True)
     assert res.max() < 1e-8 * np.linalg.norm(Phib, axis=0).max()
+
+
+def test_fused_bottom_subtrees_give_the_same_bits(ctx):
+    """EIGD_FUSE=1 (forward sweep of the bottom subtrees in one launch, carries summed in LDS): bitwise the level-by-level result"""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = textwrap.dedent("""
+        import sys, hashlib
+        import numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from test_symbolic_cpu import grid_matrix
+        from eigd_amd.device import Factor, default_context
+        ctx = default_context()
+        A = grid_matrix(150, 140, 2, 4)
+        F = Factor(ctx, A)
+        rng = np.random.default_rng(0)
+        h = hashlib.sha256()
+        for k in (16, 32, 21):
+            B = rng.normal(size=(A.shape[0], k))
+            X = F.solve_inplace(ctx.from_host(B)).get()
+            assert np.linalg.norm(A @ X - B) / np.linalg.norm(B) < 1e-11
+            h.update(X.tobytes())
+        print(h.hexdigest())
+    """) % (root, os.path.join(root, "tests"))
+    out = {}
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, EIGD_FUSE=flag), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[flag] = r.stdout.strip().splitlines()[-1]
+    assert out["0"] == out["1"]
