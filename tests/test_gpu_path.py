@@ -826,8 +826,8 @@ def test_g6_complex_step_point_on_the_device():
 
 def test_c3_full_size_properties():
     """
-    The benchmark configuration itself (BASELINE configs[2]: 706 x 706 Q4 column, 998 284 dof) with 8 modes, through
-    size-independent properties: eigen-residuals and K-orthonormality, adjoint residuals, linearity of the adjoint
+    The benchmark configuration itself (BASELINE configs[2]: 706 x 706 Q4 column, 998 284 dof, 32 modes, IRAM m = 65),
+    through size-independent properties: eigen-residuals and K-orthonormality, adjoint residuals, linearity of the adjoint
     solve in the right-hand side, mode sharding (a rank's columns are the columns of the full solve) and the
     total derivative against a central difference of the eigenvalue part.
     """
@@ -847,8 +847,8 @@ def test_c3_full_size_properties():
     fac = eg.SpLuOperator((K + sigma * G).tocsr(), ctx=ctx, symbolic=Kfac.symbolic, check_symmetry=False)
     assert fac.negative_pivots == 0
     del Kfac
-    N = 8
-    s = eg.IRAM(N=N, m=33, mode="buckling", ctx=ctx)
+    N = 32
+    s = eg.IRAM(N=N, m=65, mode="buckling", ctx=ctx)
     lam, Phi = s.solve(G, K, fac, sigma)
     assert 1.5 < lam[0] < 2.2 and np.all(np.diff(lam) > 0)
     R = K @ Phi + (G @ Phi) * lam                                          # (K + lam G) phi = 0
@@ -895,7 +895,7 @@ def test_c3_full_size_properties():
         K2 = col.stiffness()                                               # frozen pre-buckling stresses, as dAdx
         G2, _ = _assemble(col.mesh, (col.rhoE**col.p + col.rho0_G)[:, None, None] * col.Ge_unit, 2, col.free_map)
         fac.refactor((K2 + sigma * G2).tocsr())
-        s2 = eg.IRAM(N=N, m=33, mode="buckling", ctx=ctx)
+        s2 = eg.IRAM(N=N, m=65, mode="buckling", ctx=ctx)
         lam2, _ = s2.solve(G2, K2, fac, sigma)
         f.append(float(np.dot(w, np.log(lam2))))
     col.rhoE = rho0
