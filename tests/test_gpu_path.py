@@ -608,16 +608,17 @@ def test_total_derivative_matches_central_difference(kind):
     assert abs(ans - fd) <= 2e-6 * max(abs(fd), 1e-12), (ans, fd)
 
 
-def test_c2_like_natural_frequency_properties_at_scale():
+def test_c2_natural_frequency_properties_at_full_size():
     """
-    Natural-frequency configuration (BASELINE configs[1] shape, 160 x 160 elements = 51 842 dof here to keep the
-    suite short): size-independent properties of the whole path -- eigen-residuals, B-orthonormality, the three
-    rigid-body modes, adjoint residuals and orthogonality, and IRAM / BasicLanczos agreement.
+    Natural-frequency configuration at its stated size (BASELINE configs[1]: 316 x 316 elements = 200 978 dof, 10 + 3
+    rigid modes, m = 60): size-independent properties of the whole path -- eigen-residuals, B-orthonormality, the
+    three rigid-body modes, adjoint residuals and orthogonality, and IRAM / BasicLanczos agreement.
     """
     import eigd_amd as eg
     from eigd_amd.problems import FreePlate
 
-    prob = FreePlate(160, 160, seed=1)
+    prob = FreePlate(316, 316, seed=1)
+    assert prob.n == 200978
     K, M = prob.stiffness(), prob.mass()
     sigma, N = -10.0, 13
     fac = eg.SpLuOperator((K - sigma * M).tocsc(), coords=prob.dof_coords())
@@ -646,12 +647,15 @@ def test_c2_like_natural_frequency_properties_at_scale():
     assert set(data.keys()) <= {0, 1, 2}                                   # only the rigid-body cluster is repeated
 
 
-def test_c4_like_thermal_repeated_eigenvalues_at_scale():
-    """square thermal plate (exactly repeated pairs by symmetry): index sets and adjoint orthogonality, 40 401 dof"""
+def test_c4_thermal_repeated_eigenvalues_at_full_size():
+    """BASELINE configs[3] at its stated size: square thermal plate, 706 x 706 elements = 499 849 dof (exactly repeated
+    pairs by symmetry; the 8 lowest of the configuration's 20 modes, m = 90: exactly repeated eigenvalues are only split
+    by rounding in a single-vector Lanczos, in the reference as here): index sets, adjoint residuals, orthogonality"""
     import eigd_amd as eg
     from eigd_amd.problems import ThermalPlate
 
-    prob = ThermalPlate(200, epsilon=0.0)
+    prob = ThermalPlate(706, epsilon=0.0)
+    assert prob.n == 499849
     K, M = prob.stiffness(), prob.mass()
     sigma, N = -0.1, 8
     fac = eg.SpLuOperator((K - sigma * M).tocsc(), coords=prob.dof_coords())
