@@ -202,6 +202,46 @@ def ks_buckling(BLF, ks_rho=160.0):
     return float(c + np.log(np.sum(e)) / ks_rho), e / np.sum(e), mu
 
 
+def min_frequency_ks(lam, Q, node_sets, ks_param=1.0, fixed_mass=1.0):
+    """
+    The reference's minimum-frequency functional (examples/natural_frequency.py:742-807, MinFreqOpt): KS minimum over
+    the natural frequencies of the structure carrying a point mass ``fixed_mass`` at each node set in turn -- per set a
+    reduced N x N problem diag(omega^2) q = w^2 (I + m c^T c) q with c = mean eigenvector displacement over the set
+    (530-550).  N-sized host arithmetic, as in the reference.  Returns (ks, Qb, lamb): the value and the adjoint seeds
+    that solve_adjoint / add_total_derivative take (527-532, 552-562).  ``Q``: (n, N) eigenvectors of the non-rigid modes.
+    """
+    from scipy.linalg import eigh
+
+    lam = np.asarray(lam, dtype=float)
+    Q = np.asarray(Q)
+    omega, N = np.sqrt(lam), len(lam)
+    coefs = []
+    for nodes in node_sets:
+        nodes = np.asarray(nodes)
+        coefs.append(np.stack([Q[2 * nodes].mean(axis=0), Q[2 * nodes + 1].mean(axis=0)]))
+    sols, ks_set = [], []
+    for c in coefs:
+        w2, Y = eigh(np.diag(lam), np.eye(N) + fixed_mass * (c.T @ c))
+        w0 = np.sqrt(w2)
+        sols.append((w0, Y))
+        ks_set.append(w0.min() - np.log(np.sum(np.exp(-ks_param * (w0 - w0.min())))) / ks_param)
+    floor = min(omega.min(), min(ks_set))
+    wt = np.exp(-ks_param * (np.array(ks_set) - floor))
+    ks = floor - np.log(wt.sum()) / ks_param
+    wt /= wt.sum()
+    omegab = np.zeros(N)
+    Qb = np.zeros(Q.shape)
+    for nodes, c, (w0, Y), e0 in zip(node_sets, coefs, sols, wt):
+        nodes = np.asarray(nodes)
+        inner = np.exp(-ks_param * (w0 - w0.min()))
+        w0b = 0.5 * (inner / inner.sum()) * e0 / w0                     # d ks / d (w0^2) chain through sqrt
+        omegab += 2.0 * omega * np.einsum("ij,j,ij->i", Y, w0b, Y)
+        cb = -2.0 * fixed_mass * np.einsum("j,aj,ij->ai", w0b * w0**2, c @ Y, Y)
+        Qb[2 * nodes] += cb[0] / len(nodes)
+        Qb[2 * nodes + 1] += cb[1] / len(nodes)
+    return float(ks), Qb, 0.5 * omegab / omega
+
+
 def thermal_compliance(lam, Q, vec):
     """sum_{i >= 1} (q_i . vec)^2 / lam_i (examples/thermal.py:428-434); Q, vec numpy"""
     val = np.asarray(Q)[:, 1:].T @ vec

@@ -307,6 +307,58 @@ def thermal_compliance_seeds(lam, Q, vec, compb=1.0):
     return Qb, lamb
 
 
+def min_frequency_ks(lam, Q, node_sets, ks_param=1.0, fixed_mass=1.0):
+    """
+    KS minimum of the natural frequencies with a point mass at each node set in turn (MinFreqOpt._eval_min_frequency,
+    natural_frequency.py:742-807, with get_point_coefficients 530-550): per set the reduced problem
+    diag(omega^2) q = w0^2 (I + m c^T c) q.  Returns (ks, omegab, {set: xcoefb}).
+    """
+    from scipy.linalg import eigh
+
+    lam = np.asarray(lam, dtype=float)
+    omega = np.sqrt(lam)
+    N = len(omega)
+    xcoef = []
+    for nodes in node_sets:
+        c0 = np.zeros((3, N))
+        c0[0] = np.sum(Q[2 * nodes, :], axis=0) / len(nodes)
+        c0[1] = np.sum(Q[2 * nodes + 1, :], axis=0) / len(nodes)
+        xcoef.append(c0)
+    eigs, ks0 = [], []
+    min_val = np.min(omega)
+    for c0 in xcoef:
+        lam0, Q0 = eigh(np.diag(omega**2), np.eye(N) + fixed_mass * (c0.T @ c0))
+        om0 = np.sqrt(lam0)
+        eigs.append((om0, Q0))
+        ks0.append(np.min(om0) - np.log(np.sum(np.exp(-ks_param * (om0 - np.min(om0))))) / ks_param)
+        min_val = min(min_val, ks0[-1])
+    eta0 = np.exp(-ks_param * (np.array(ks0) - min_val))
+    ks = min_val - np.log(np.sum(eta0)) / ks_param
+    eta0 = eta0 / np.sum(eta0)
+    omegab = np.zeros(N)
+    xcoefb = []
+    for c0, (om0, Q0), e0 in zip(xcoef, eigs, eta0):
+        w = np.exp(-ks_param * (om0 - np.min(om0)))
+        om0b = 0.5 * (w / np.sum(w)) * e0 / om0
+        omegab += 2.0 * omega * np.diag(Q0 @ (np.diag(om0b) @ Q0.T))
+        cb = np.zeros(c0.shape)
+        for i in range(N):
+            cb -= 2.0 * om0b[i] * fixed_mass * om0[i] ** 2 * np.outer(c0 @ Q0[:, i], Q0[:, i])
+        xcoefb.append(cb)
+    return float(ks), omegab, xcoefb
+
+
+def min_frequency_seeds(lam, Q, node_sets, ks_param=1.0, fixed_mass=1.0):
+    """(ks, Qb, lamb): add_frequency_derivatives 527-532 and add_point_derivative 552-562 applied to the above"""
+    ks, omegab, xcoefb = min_frequency_ks(lam, Q, node_sets, ks_param, fixed_mass)
+    lamb = 0.5 * omegab / np.sqrt(np.asarray(lam, dtype=float))
+    Qb = np.zeros(Q.shape)
+    for nodes, cb in zip(node_sets, xcoefb):
+        Qb[2 * nodes, :] += cb[0] / len(nodes)
+        Qb[2 * nodes + 1, :] += cb[1] / len(nodes)
+    return ks, Qb, lamb
+
+
 class BucklingHarness:
     """
     The derivative side of examples/buckling.py at one design point, from stored matrices and fields: callbacks of

@@ -162,3 +162,33 @@ def test_g3_noise_floor_of_the_repeated_branch():
     spread = max(relerr(out[1], out[0]), relerr(out[2], out[0]))
     print(f"df/dx moves by {spread:.2e} under a change of summation order in G")
     assert 1e-10 < spread < 1e-6
+
+
+@pytest.mark.parametrize("solver", ["basiclanczos", "iram"])
+def test_g2_min_frequency_ks_and_its_seeds(solver):
+    """MinFreqOpt (natural_frequency.py:700-807): the KS value and the adjoint seeds Q0b / lamb0 the fixture was solved for"""
+    g = load_golden("g2_natfreq32x16_" + solver)
+    sets = [g["ns_nodes"][a:b] for a, b in zip(g["ns_ptr"][:-1], g["ns_ptr"][1:])]
+    lam, Q = g["lam"][3:], g["Phi"][:, 3:]
+    ks, Qb, lamb = fe.min_frequency_seeds(lam, Q, sets, float(g["ks_param"]), float(g["fixed_mass"]))
+    assert abs(ks - float(g["ks_min"])) < 1e-13 * abs(float(g["ks_min"]))
+    assert relerr(Qb, g["Q0b"][:, 3:]) < 1e-12 and relerr(lamb, g["lamb0"][3:]) < 1e-12
+    assert relerr(2.0 * np.sqrt(lam) * lamb, g["omegab"]) < 1e-12
+    # the product's host-side statement of the same functional (eigd_amd/design.py; N-sized arithmetic, no GPU needed)
+    from eigd_amd import design
+
+    ks2, Qb2, lamb2 = design.min_frequency_ks(lam, Q, sets, float(g["ks_param"]), float(g["fixed_mass"]))
+    assert abs(ks2 - float(g["ks_min"])) < 1e-13 * abs(float(g["ks_min"]))
+    assert relerr(Qb2, g["Q0b"][:, 3:]) < 1e-12 and relerr(lamb2, g["lamb0"][3:]) < 1e-12
+    # the other host-side functionals of the product against the oracle's statements
+    gb = load_golden("g1_buckling50_basiclanczos")
+    Qfull = np.zeros((2 * (int(gb["conn"].max()) + 1), gb["Phi"].shape[1]))
+    Qfull[gb["reduced"]] = gb["Phi"]
+    node, rho = int(gb["node"]), float(gb["agg_rho"])
+    for mode in ("tanh", "exp"):
+        h, _, _, _ = fe.eigenvector_aggregate(gb["lam"], Qfull, node, rho, mode)
+        assert abs(design.eigenvector_aggregate(gb["lam"], Qfull[node], rho, mode) - h) <= 1e-14 * abs(h)
+        Qb_o, lamb_o = fe.eigenvector_aggregate_seeds(gb["lam"], Qfull, node, rho, mode=mode)
+        row, lamb_p = design.eigenvector_aggregate_seeds(gb["lam"], Qfull[node], rho, mode=mode)
+        assert np.allclose(row, Qb_o[node], rtol=1e-14, atol=0) and np.allclose(lamb_p, lamb_o, rtol=1e-13, atol=1e-300)
+    assert abs(design.ks_buckling(gb["BLF"], 30.0)[0] - float(gb["ks"])) < 1e-13 * abs(float(gb["ks"]))

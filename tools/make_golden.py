@@ -216,6 +216,14 @@ def case_g2(solver_type):
         r0=np.float64(topo.fltr.r0), p=np.float64(topo.p), rho0_K=np.float64(topo.rho0_K),
         density=np.float64(topo.density), E=np.float64(topo.E), nu=np.float64(topo.nu),
     )
+    # the KS functional of MinFreqOpt (natural_frequency.py:700-807) whose seeds Q0b / lamb0 are: point-mass node sets
+    names = sorted(topo.node_sets)
+    f.update(
+        ns_nodes=np.concatenate([topo.node_sets[k] for k in names]).astype(np.int64),
+        ns_ptr=np.cumsum([0] + [len(topo.node_sets[k]) for k in names]).astype(np.int64),
+        ks_param=np.float64(opt.ks_param), fixed_mass=np.float64(opt.fixed_mass), ks_min=np.float64(opt.ks_min),
+        omegab=np.asarray(opt.omegab, dtype=float),
+    )
     save("g2_natfreq32x16_" + solver_type.lower(), **f)
 
 
