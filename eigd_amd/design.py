@@ -10,6 +10,9 @@ between the design variables and the matrices, and between the eigenvector adjoi
   BucklingAnalysis      examples/buckling.py:548-632, 822-986   assembly of K(x), the fundamental path u = K^-1 f, G(u, x),
                                                           shift-invert eigensolve, adjoint, total derivative INCLUDING
                                                           the path adjoint through u, chain rule back to x
+  ModalAnalysis         examples/natural_frequency.py:317-392, 442-519; thermal.py:268-342, 560-623
+                                                          the K - lam M harnesses (plate with rigid-body modes, heat
+                                                          conduction) from x to df/dx
 
 Vectors of the mesh (n, nnodes, nelems long) never visit the host between x and df/dx: matrices are assembled by
 ``eigd_assemble``, the gather / scatter / averaging maps are rectangular CSR products (fixed summation order,
@@ -478,3 +481,138 @@ class BucklingAnalysis:
         acc = self.ctx.zeros(self.nelems, 1)
         dBdx.accumulate(self.u_r, self.u_r, acc, alpha=-1.0)
         return self.chain_to_design(acc)[1].get()[:, 0]
+
+
+class ModalAnalysis:
+    """
+    Device pipeline of the reference's K - lam M harnesses: ``kind="natural_frequency"`` (examples/natural_frequency.py:
+    Q4 plane-stress plate, free-free, 2 dof / node; the three rigid-body modes are solved for and dropped, 348, 383-384)
+    and ``kind="thermal"`` (examples/thermal.py: heat conduction, 1 dof / node).  Design variables x -> filter -> element
+    densities -> K(x), M(x) assembled on the device -> K phi = lam M phi by shift-invert Lanczos -> adjoint + total
+    derivative -> filter transpose -> df/dx; no vector of the mesh visits the host in between.
+
+      natural_frequency:  K = sum (rho^p + rho0_K) Ke0,               M = sum density * rho * Me0        (134-160, 205-236)
+      thermal:            K = sum kappa ((1 - beta) rho^p + beta) Kt0,  M = sum c rho_d ((1 - beta) rho + beta) Mt0  (126-148, 192-214)
+    """
+
+    def __init__(self, conn, X, kind="natural_frequency", fltr=None, N=10, m=None, sigma=None, solver_type="IRAM",
+                 tol=None, rtol=1e-10, eig_atol=1e-5, Ntarget=None, E=1.0, nu=0.3, p=3.0, rho0_K=1e-6, density=1.0,
+                 kappa=1.0, heat_capacity=1.0, beta=1e-6, adjoint_method="sibk", adjoint_options=None, ctx=None):
+        if kind not in ("natural_frequency", "thermal"):
+            raise ValueError(f"Unknown kind {kind!r}")
+        self.ctx = ctx = ctx if ctx is not None else default_context()
+        self.kind, self.fltr = kind, fltr
+        self.el = el = Q4Elements(conn, X)
+        self.nrigid = 3 if kind == "natural_frequency" else 0
+        self.N, self.m, self.solver_type, self.rtol, self.eig_atol, self.Ntarget = N, m, solver_type, rtol, eig_atol, Ntarget
+        self.sigma = sigma if sigma is not None else (-10.0 if kind == "natural_frequency" else -0.1)
+        self.tol = tol if tol is not None else (1e-14 if kind == "natural_frequency" else 0.0)
+        self.p, self.rho0_K, self.density = p, rho0_K, density
+        self.kappa, self.heat_capacity, self.beta = kappa, heat_capacity, beta
+        self.adjoint_method = adjoint_method
+        self.adjoint_options = dict(adjoint_options or {"lanczos_guess": True, "update_guess": False, "bs_target": 1})
+        self.nnodes, self.nelems = el.nnodes, el.nelems
+        if kind == "natural_frequency":
+            self.Ke0, self.Me0 = el.stiffness(plane_stress_C0(E, nu)), el.mass()
+            self.elem_dofs = el.dofs2()
+            self.n = 2 * el.nnodes
+            coords = np.repeat(el.X, 2, axis=0)
+        else:
+            self.Ke0, self.Me0 = el.conduction(), el.capacity()
+            self.elem_dofs = el.conn.astype(np.int32)
+            self.n = el.nnodes
+            coords = el.X
+        self.avg = element_average(ctx, el.conn, el.nnodes)
+        self.asm = ElementAssembler(ctx, self.elem_dofs, self.n)
+        pat = self.asm.pattern()
+        ones = sparse.csr_matrix((np.ones(pat.nnz), pat.indices, pat.indptr), shape=pat.shape) \
+            + sparse.identity(self.n, format="csr") * (10.0 * pat.nnz)   # placeholder values: analysis only
+        ones.sort_indices()
+        if ones.nnz != pat.nnz or not np.array_equal(ones.indices, pat.indices):
+            raise ValueError("every dof needs a diagonal entry in the assembled pattern")
+        self.factor = SpLuOperator(ones, ctx=ctx, check_symmetry=False, coords=coords)
+        self.dK, self.dM, self._shifted = CSRMatrix(ctx, ones), CSRMatrix(ctx, ones), CSRMatrix(ctx, ones)
+
+    def _scales(self, rhoE):
+        """(K scale, M scale, dK/drho factor, dM/drho factor) per element, on the device"""
+        ctx, one = self.ctx, None
+        if self.kind == "natural_frequency":
+            sK = design_map(ctx, SIMP, rhoE, p=self.p, c0=self.rho0_K)
+            sM = design_map(ctx, AFFINE, rhoE, c0=self.density, c1=0.0)
+            dK = design_map(ctx, SIMP_DERIV, rhoE, p=self.p)
+            dM = design_map(ctx, AFFINE, rhoE, c0=0.0, c1=self.density)
+        else:
+            a = self.kappa * (1.0 - self.beta)
+            sK = design_map(ctx, SIMP, rhoE, p=self.p, c0=0.0)
+            sK = design_map(ctx, AFFINE, sK, c0=a, c1=self.kappa * self.beta)
+            c = self.heat_capacity * self.density
+            sM = design_map(ctx, AFFINE, rhoE, c0=c * (1.0 - self.beta), c1=c * self.beta)
+            dK = design_map(ctx, SIMP_DERIV, rhoE, p=self.p)
+            dK = design_map(ctx, AFFINE, dK, c0=a, c1=0.0)
+            dM = design_map(ctx, AFFINE, rhoE, c0=0.0, c1=c * (1.0 - self.beta))
+        return sK, sM, dK, dM
+
+    def initialize(self, x):
+        """assemble K(x), M(x), factor K - sigma M, solve the eigenproblem; returns (lam, Q) without the rigid-body modes"""
+        ctx = self.ctx
+        self.x = np.asarray(x, dtype=float)
+        self.x_dev = ctx.from_host(self.x)
+        self.rho = self.fltr.apply_device(self.x_dev) if self.fltr is not None else self.x_dev
+        self.rhoE = self.avg.apply(self.rho)
+        sK, sM, self._dKs, self._dMs = self._scales(self.rhoE)
+        vK = self.asm.assemble(self.Ke0, sK)
+        vM = self.asm.assemble(self.Me0, sM)
+        self.dK.update_values_device(vK)
+        self.dM.update_values_device(vM)
+        vS = ctx.empty(vK.n, 1).assign_lincomb([(1.0, vK), (-float(self.sigma), vM)])
+        self._shifted.update_values_device(vS)
+        self.factor.refactor_device(vS, indefinite_matrix=self._shifted)
+        self.factor.count = 0
+        from .lanczos import IRAM, BasicLanczos
+
+        Nall = self.N + self.nrigid
+        if self.solver_type == "IRAM":
+            m = self.m if self.m is not None else max(2 * Nall + 1, 60)
+            self.eig_solver = IRAM(N=Nall, m=m, eig_atol=self.eig_atol, ctx=ctx)
+        else:
+            m = self.m if self.m is not None else max(3 * Nall + 1, 60)
+            self.eig_solver = BasicLanczos(N=Nall, m=m, eig_atol=self.eig_atol, tol=self.tol, Ntarget=self.Ntarget, ctx=ctx)
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")   # (the rigid-body cluster at lam ~ 1e-15 is numerically repeated by construction)
+            lam, Q = self.eig_solver.solve(self.dK, self.dM, self.factor, self.sigma)
+        self.lam_all, self.Q_all = lam, Q
+        self.lam, self.Q = lam[self.nrigid:], Q[:, self.nrigid:]
+        return self.lam, self.Q
+
+    def finalize_adjoint(self, Qb, lamb):
+        """
+        solve_adjoint + total derivative + chain rule for seeds on the non-rigid modes (natural_frequency.py:442-519,
+        thermal.py:560-623); returns psi, corr_data, rhoEb, rhob, xb.
+        """
+        ctx, r = self.ctx, self.nrigid
+        Q0b = np.zeros((self.n, len(self.lam_all)))
+        Q0b[:, r:] = Qb
+        lamb0 = np.zeros(len(self.lam_all))
+        lamb0[r:] = lamb
+        dQ0b = ctx.from_host(Q0b)
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            dpsi, data = self.eig_solver.solve_adjoint(dQ0b, rtol=self.rtol, method=self.adjoint_method,
+                                                       **self.adjoint_options)
+        data0 = {}
+        for i in data:                       # pairs that involve a rigid-body mode are dropped (486-497)
+            if i >= r:
+                items = [(j, xi, eta) for j, xi, eta in data[i] if j >= r]
+                if items:
+                    data0[i] = items
+        dAdx = ElementBilinear.from_device(ctx, self.elem_dofs, self.Ke0, self._dKs)
+        dBdx = ElementBilinear.from_device(ctx, self.elem_dofs, self.Me0, self._dMs)
+        rhoEb = self.eig_solver.add_total_derivative(lamb0, dQ0b, dpsi, dAdx, dBdx, np.zeros(self.nelems),
+                                                     adj_corr_data=data0, deriv_type="tensor")
+        rhob = self.avg.apply_t(ctx.from_host(rhoEb))
+        xb = rhob if self.fltr is None else self.fltr.apply_gradient_device(rhob, self.x_dev)
+        return {"psi": dpsi, "corr_data": data, "rhoEb": rhoEb, "rhob": rhob.get()[:, 0], "xb": xb.get()[:, 0]}

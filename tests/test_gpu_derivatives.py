@@ -340,3 +340,59 @@ def test_node_filter_units_g7():
                 tag = f"{ftype}_{'proj' if proj else 'lin'}_{'map' if use_map else 'nomap'}_"
                 assert relerr(flt.apply(g[tag + "x"]), g[tag + "rho"]) < 1e-11, tag
                 assert relerr(flt.apply_gradient(g["g"], g[tag + "x"]), g[tag + "grad"]) < 1e-11, tag
+
+
+@pytest.mark.parametrize("solver", ["basiclanczos", "iram"])
+def test_g2_natural_frequency_from_the_design_variables(solver):
+    """examples/natural_frequency.py end to end on the device: x -> filter -> K(x), M(x) -> eigensolve -> MinFreqOpt's KS
+    functional -> adjoint -> df/dx -> filter transpose; value and gradient against the reference's ks_min and xb"""
+    from eigd_amd.design import ModalAnalysis, NodeFilter, min_frequency_ks
+    from eigd_amd.device import default_context
+
+    g = load_golden("g2_natfreq32x16_" + solver)
+    ctx = default_context()
+    flt = NodeFilter(g["conn"], g["X"], r0=float(g["r0"]), dvmap=g["dvmap"], num_design_vars=int(g["num_design_vars"]), ctx=ctx)
+    an = ModalAnalysis(g["conn"], g["X"], kind="natural_frequency", fltr=flt, N=10, m=60, sigma=float(g["sigma"]),
+                       solver_type="BasicLanczos" if solver == "basiclanczos" else "IRAM", p=float(g["p"]),
+                       rho0_K=float(g["rho0_K"]), density=float(g["density"]), E=float(g["E"]), nu=float(g["nu"]), ctx=ctx)
+    lam, Q = an.initialize(g["x"])
+    assert relerr(lam, g["lam"][3:]) < TOL
+    assert np.all(np.abs(an.lam_all[:3]) < 1e-7)                            # the rigid-body modes that are dropped
+    Kv = an.asm.values_to_host(an.asm.assemble(an.Ke0, an._scales(an.rhoE)[0]))
+    assert np.abs(Kv - csr_from(g, "K").data).max() < 1e-13 * np.abs(Kv).max()
+    sets = [g["ns_nodes"][a:b] for a, b in zip(g["ns_ptr"][:-1], g["ns_ptr"][1:])]
+    ks, Qb, lamb = min_frequency_ks(lam, Q, sets, float(g["ks_param"]), float(g["fixed_mass"]))
+    assert abs(ks - float(g["ks_min"])) < TOL * abs(float(g["ks_min"]))
+    out = an.finalize_adjoint(Qb, lamb)
+    assert relerr(out["rhoEb"], g["rhoEb"]) < TOL                            # (a function of the eigenpairs: sign-free)
+    assert relerr(out["xb"], g["xb"]) < TOL
+
+
+@pytest.mark.parametrize("name,tol", [("g3_thermal32_eps1e-1_basiclanczos", 1e-8), ("g3_thermal32_eps1e-8_basiclanczos", 1e-7),
+                                      ("g3_thermal32_eps1e-8_iram", 1e-7)])
+def test_g3_thermal_from_the_design_variables(name, tol):
+    """examples/thermal.py end to end on the device (1 dof / node, K and M both design dependent): compliance value and
+    df/dx against the reference.  epsilon = 1e-8: the repeated-pair terms carry the 1e-8-level noise of xi / eta
+    (test_g3_thermal_repeated_branch_rhoEb) -- held to 1e-7 here, where nothing of the reference's eigen data is adopted."""
+    from eigd_amd import design
+    from eigd_amd.device import default_context
+
+    g = load_golden(name)
+    ctx = default_context()
+    flt = design.NodeFilter(g["conn"], g["X"], r0=float(g["r0"]), dvmap=g["dvmap"], num_design_vars=int(g["num_design_vars"]),
+                            ctx=ctx)
+    an = design.ModalAnalysis(g["conn"], g["X"], kind="thermal", fltr=flt, N=8, m=60, sigma=float(g["sigma"]),
+                              solver_type="IRAM" if "iram" in name else "BasicLanczos", tol=0.0, rtol=1e-12, p=float(g["p"]),
+                              kappa=float(g["kappa"]), heat_capacity=float(g["heat_capacity"]), density=float(g["density"]),
+                              beta=float(g["th_beta"]), ctx=ctx)
+    lam, Q = an.initialize(g["x"])
+    assert relerr(lam, g["lam"]) < TOL
+    Mv = an.asm.values_to_host(an.asm.assemble(an.Me0, an._scales(an.rhoE)[1]))
+    assert np.abs(Mv - csr_from(g, "M").data).max() < 1e-13 * np.abs(Mv).max()
+    comp = design.thermal_compliance(lam, Q, g["vec"])
+    assert abs(comp - float(g["compliance"])) < TOL * abs(float(g["compliance"]))
+    Qb, lamb = design.thermal_compliance_seeds(lam, Q, g["vec"])
+    out = an.finalize_adjoint(Qb, lamb)
+    assert index_sets(out["corr_data"]) == index_sets(corr_from(g, "corr"))
+    assert relerr(out["rhoEb"], g["rhoEb"]) < tol
+    assert relerr(out["xb"], g["xb"]) < tol
