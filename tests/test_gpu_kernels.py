@@ -623,3 +623,23 @@ def test_fused_bottom_subtrees_give_the_same_bits(ctx):
         assert r.returncode == 0, r.stderr[-2000:]
         out[flag] = r.stdout.strip().splitlines()[-1]
     assert out["0"] == out["1"]
+
+
+def test_bunch_kaufman_over_many_interior_shifts(ctx):
+    """60 random shifts inside the spectra of three pencils: no refusal, residual of the pivoted factor alone <= 1e-9
+    (measured worst 1.5e-11 over 100 shifts, tools/bk_probe.py), with the refinement step <= 1e-12"""
+    import eigd_amd as eg
+
+    rng = np.random.default_rng(0)
+    for (nx, ny, dof, seed) in ((40, 37, 1, 1), (25, 24, 2, 2), (60, 50, 2, 3)):
+        K = grid_matrix(nx, ny, dof, seed)
+        n = K.shape[0]
+        M = sparse.diags(rng.uniform(0.5, 1.5, size=n)).tocsr()
+        top = 1.2 * (K.diagonal() / M.diagonal()).max()
+        B = rng.normal(size=(n, 3))
+        for sigma in rng.uniform(0.0, top, size=20):
+            mat = (K - sigma * M).tocsr()
+            op = eg.SpLuOperator(mat.tocsc(), ctx=ctx)
+            Xf = op.factor.solve_inplace(ctx.from_host(B)).get()
+            assert np.linalg.norm(mat @ Xf - B) / np.linalg.norm(B) < 1e-9, sigma
+            assert np.linalg.norm(mat @ op(B) - B) / np.linalg.norm(B) < 1e-12, sigma
