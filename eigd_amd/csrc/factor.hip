@@ -38,6 +38,12 @@ namespace eigd {
 
 constexpr int TW = 64;       // tile edge == max panel width == row chunk
 constexpr int TLD = TW + 1;  // padded LDS leading dimension
+#ifndef EIGD_FRAG_WAVES_FWD
+#define EIGD_FRAG_WAVES_FWD 2  // (32 columns, forward: 168 registers would spill)
+#endif
+#ifndef EIGD_FRAG_WAVES
+#define EIGD_FRAG_WAVES 3  // waves per SIMD the direct-fragment level kernels are compiled for
+#endif
 constexpr int KBMAX = 32;    // right-hand sides per sweep
 
 struct FrontArrays {
@@ -711,7 +717,30 @@ struct WgRec {
   int64_t scratch;       // 1: surplus child (slot >= kMaxS): its carry goes to the scratch plane, at its own border rows
   int64_t ftoff;         // the front's block in the transposed copy Ft
   int64_t ldt;           // leading dimension of T as the sweeps read it: d in the packed panel
+  int64_t moff;          // fronts with several column tiles: first tile of this record's chain in the fragment-major copy
 };
+
+struct FragFront {
+  int f, nst, nbt, nko;  // nko: K-steps of the last own tile (columns in Fm, rows in Bm), nkb: of the last border tile
+  int nkb, pad;
+  int64_t fm, bm;        // the front's blocks in Fm / Bm (doubles)
+};
+
+__device__ __host__ inline int64_t frag_fwd_steps(int nst, int nko, int rt) {  // K-steps before row tile rt
+  const int64_t ks = 16 * (nst - 1) + nko;
+  return (rt <= nst - 1) ? 8LL * rt * (rt + 1) : 8LL * (nst - 1) * nst + ks * (rt - (nst - 1));
+}
+__device__ __host__ inline int64_t frag_bwd_chain(int nst, int nbt, int nko, int nkb, int ct) {  // K-steps of chain ct
+  return 16LL * (nst - 1 - ct) + nko + (nbt > 0 ? 16LL * (nbt - 1) + nkb : 0);
+}
+__device__ __host__ inline int64_t frag_bwd_steps(int nst, int nbt, int nko, int nkb, int ct) {  // ... before chain ct
+  int64_t sum = 0;
+  for (int c = 0; c < ct; ++c) sum += frag_bwd_chain(nst, nbt, nko, nkb, c);
+  return sum;
+}
+__device__ __host__ inline int64_t frag_bwd_in_chain(int nown, int nko, int t) {  // K-steps of chain steps before t
+  return (t < nown) ? 16LL * t : 16LL * (nown - 1) + nko + 16LL * (t - nown);
+}
 
 struct LevelArgs {
   const WgRec* wg;
@@ -719,7 +748,18 @@ struct LevelArgs {
   int* tickets;   // one per split tile, zero between sweeps
   int kb;
   int kd;         // rows of the LDS tiles this launch was given (multiple of 8, <= 64): the longest product of the level
+  int nwg;        // records of this launch
+  int per_xcd;    // multi-tile launches: records per XCD (grid = 8 * per_xcd, see xcd_record); 0 = blockIdx is the record
 };
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one; observed, used for speed only):
+// give every XCD a contiguous range of the level's records.  The records of a front are neighbours, so the workgroups
+// that read the same right-hand side blocks of a front (all its row tiles in the forward sweep, all its column tiles
+// in the backward sweep) sit behind one L2 and fetch them from HBM once instead of once per workgroup.
+__device__ __forceinline__ int xcd_record(const LevelArgs& la) {
+  if (la.per_xcd == 0) return blockIdx.x;
+  return (blockIdx.x & 7) * la.per_xcd + (blockIdx.x >> 3);
+}
 
 constexpr int TILE_IT = TW * TW / kThreads;  // 16 matrix elements per lane and tile
 
@@ -794,8 +834,10 @@ __device__ __forceinline__ bool fold_groups(const WgRec& w, const LevelArgs& la,
 // Matrix tiles and vector blocks are register staged one step ahead (the gather indices two), so the loads of
 // step t+1 are in flight while step t multiplies.  Masked lanes load from a zero word (address select): a branch
 // around the load would serialise the loads of a tile.
-template <int KPT, bool SINGLE, bool DEEP, int NSL>  // NSL: carry planes compiled in (2: binary trees, else kMaxS + 1)
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((SINGLE && (KPT == 4 || (KPT == 8 && !DEEP))) ? 3 : 1)))
+// NSL: carry planes compiled in (2: binary trees, else kMaxS + 1); FRAG (fronts with several column tiles, MFMA widths):
+// matrix operands straight from the fragment-major copy instead of staged through LDS
+template <int KPT, bool SINGLE, bool DEEP, int NSL, bool FRAG = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(((SINGLE && (KPT == 4 || (KPT == 8 && !DEEP))) || (FRAG && KPT >= 4)) ? ((FRAG && KPT >= 8) ? EIGD_FRAG_WAVES_FWD : 3) : 1)))
 void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
                                                             const double* __restrict__ Tb, const double* X, int ldx,
                                                             double alpha, double* V, double* __restrict__ Y) {
@@ -804,8 +846,10 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
   extern __shared__ double lds_tiles[];  // la.kd (+ 1 spare) rows of the matrix tile, as many of the vector block
   double* const As = lds_tiles;
   const int kdl = SINGLE ? la.kd : TW;  // (a constant where the fronts have several column tiles: folded LDS offsets)
-  double* const Bs = lds_tiles + ((SINGLE && KPT == 4) ? 0 : (kdl + 1) * TLD);  // (the direct-fragment path has no matrix tile)
-  const WgRec w = la.wg[blockIdx.x];
+  double* const Bs = lds_tiles + (((SINGLE && KPT == 4) || FRAG) ? 0 : (kdl + 1) * TLD);  // (the direct-fragment paths have no matrix tile)
+  const int rec = SINGLE ? static_cast<int>(blockIdx.x) : xcd_record(la);
+  if (!SINGLE && rec >= la.nwg) return;
+  const WgRec w = la.wg[rec];
   const int kb = la.kb;
   const int ns = w.ns;
   const int d = ns + w.bs;
@@ -1033,6 +1077,69 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
       commit_b();
       for (int rt = w.s0; rt < w.s1; ++rt) step(rt, av, rt + 1);
     }
+  } else if constexpr (FRAG) {
+    static_assert(!FRAG || T::kMfma, "fragments feed MFMAs");
+    // Several column tiles, MFMA path: the chain over the column tiles with the matrix operands loaded from global
+    // memory straight into the MFMA layout: wave v owns output rows 16v..16v+15 and reads exactly the fragments its
+    // MFMAs consume, one tile ahead, from the fragment-major copy of the front (pack_frag_kernel: a tile is one
+    // contiguous 32 KB block in consumption order).  Only the vector block goes through LDS -- a third of the
+    // footprint of the staged form, no matrix commit between the barriers, no lane masks.  Same products in the same
+    // order as the staged form (K ascending in steps of 4): bitwise the same result.
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int rt = w.tile;
+    const bool own = rt < nst;
+    const int row0 = own ? rt * TW : ns + (rt - nst) * TW;
+    const int rows = min(TW, (own ? ns : d) - row0);
+    const bool wok = 16 * wave < rows;  // (wave-uniform) the wave's 16 rows meet the front
+    // F = the fragment-major copy Fm here: tile ct of this row of tiles at moff + ct * 4096 doubles, K-step kk of the
+    // workgroup 2 KB further on each time, no masks (cells outside the front hold zeros)
+    const double* Am = F + w.moff + wave * 64 + lane;
+    auto fetch_frag = [&](int ct, double (&a)[16]) {
+      const int nk = (min(TW, ns - ct * TW) + 3) >> 2;
+      const double* Ac = Am + static_cast<int64_t>(ct) * (TW * TW);
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) a[kk] = (wok && kk < nk) ? Ac[kk * 256] : 0.0;
+    };
+    double4_t c[T::NT];
+#pragma unroll
+    for (int n = 0; n < T::NT; ++n) c[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+    auto stepf = [&](int ct, double (&cur)[16], double (&nxt)[16]) {
+      commit_b();
+      __syncthreads();
+      if (ct + 1 < w.s1) {
+        fetch_b(ct + 1);
+        fetch_frag(ct + 1, nxt);
+        if (ct + 2 < w.s1) fetch_idx(ct + 2);
+      }
+      const int nk = (min(TW, ns - ct * TW) + 3) >> 2;  // K-steps that meet columns of the front (uniform)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        if (kk < nk) {
+          const int k = 4 * kk + lk;
+#pragma unroll
+          for (int n = 0; n < T::NT; ++n)
+            c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[kk], Bs[k * T::BLD + 16 * n + li], c[n], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    };
+    double a0[16], a1[16];
+    fetch_frag(w.s0, a0);  // (no index round in front of the matrix operands)
+    fetch_idx(w.s0);
+    fetch_b(w.s0);
+    if (w.s0 + 1 < w.s1) fetch_idx(w.s0 + 1);
+    for (int ct = w.s0; ct < w.s1; ct += 2) {
+      stepf(ct, a0, a1);
+      if (ct + 1 < w.s1) stepf(ct + 1, a1, a0);
+    }
+#pragma unroll
+    for (int n = 0; n < T::NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[4 * n + r] = c[n][r];
+    if (rt >= nst) fetch_carry(rt, cg, di);  // in flight while the groups of a split chain are joined
+    if (w.G > 1 && !fold_groups<KPT>(w, la, acc, reinterpret_cast<int*>(Bs))) return;
+    store_tile(rt, acc, cg, di);
   } else {
   const int rt = w.tile;
   fetch_idx(w.s0);
@@ -1061,17 +1168,21 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
 //   x1(ct) = sum_{rt >= ct} T(rt, ct)^T y(rt)  -  sum_bt M21(bt, ct)^T x_border(bt)
 // y = S z from the forward sweep (Y); x_border are rows of the caller's block Out that the ancestors' launches
 // have already written (bout = their row numbers).  The solution goes straight to Out.
-template <int KPT, bool SINGLE>  // SINGLE: fronts with one column tile, LDS tiles of la.kd rows
-__global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
-                                                            const double* __restrict__ Tb,
+// SINGLE: fronts with one column tile, LDS tiles of la.kd rows; FRAG: as in the forward kernel (Ft = the copy Bm then)
+template <int KPT, bool SINGLE, bool FRAG = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FRAG ? EIGD_FRAG_WAVES : 1)))
+void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
+                                                            const double* __restrict__ Tb, const double* __restrict__ Ft,
                                                             const double* __restrict__ Y, double* Out, int ldo) {
   using T = Tile<KPT>;
   constexpr int IT = KPT;
   extern __shared__ double lds_tiles[];
   double* const As = lds_tiles;
   const int kdl = SINGLE ? la.kd : TW;
-  double* const Bs = lds_tiles + (kdl + 1) * TLD;
-  const WgRec w = la.wg[blockIdx.x];
+  double* const Bs = lds_tiles + (FRAG ? 0 : (kdl + 1) * TLD);  // (direct fragments: no matrix tile)
+  const int rec = SINGLE ? static_cast<int>(blockIdx.x) : xcd_record(la);
+  if (!SINGLE && rec >= la.nwg) return;
+  const WgRec w = la.wg[rec];
   const int ct = w.tile;
   const int kb = la.kb;
   const int ns = w.ns, bs = w.bs;
@@ -1140,8 +1251,95 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
   };
 
   double acc[T::NOUT];
+  int oi[T::NOUT];  // rows of the caller's block the results go to
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) acc[t] = 0.0;
+  if constexpr (FRAG) {
+    static_assert(!FRAG || (!SINGLE && T::kMfma), "fragments: several column tiles, MFMA widths");
+    // Direct fragments (see the forward kernel): wave v owns the output rows (= own columns of the front) 16v..16v+15
+    // and reads its MFMA operands from the fragment-major copy Bm, one tile ahead; only the vector block goes
+    // through LDS.
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const bool wok = 16 * wave < wc;  // (wave-uniform) the wave's 16 columns meet the front
+    // Ft = the fragment-major copy Bm here: the tiles of this column tile's chain one after the other from moff
+    const int nko = (ns - TW * (nst - 1) + 3) >> 2;  // K-steps of the last own tile
+    const double* Am = Ft + w.moff + wave * 64 + lane;
+    int frag_rows = 0;
+    auto fetch_vec = [&](int t) {
+      const bool border = t >= nown;
+      const int rbase = border ? ns + (t - nown) * TW : (ct + t) * TW;
+      const int rows = min(TW, (border ? d : ns) - rbase);
+      if (!border) {
+        const double* Yp = Y + (vbase + rbase) * kb;
+#pragma unroll
+        for (int e = 0; e < IT; ++e) {
+          const int idx = threadIdx.x + e * kThreads;
+          const int r = idx / T::KB, c = idx & (T::KB - 1);
+          bv[e] = *((r < rows && c < kb) ? Yp + static_cast<int64_t>(r) * kb + c : fa.zero);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < IT; ++e) {
+          const int c = (threadIdx.x + e * kThreads) & (T::KB - 1);
+          bv[e] = -*((ri[e] >= 0 && c < kb) ? Out + static_cast<int64_t>(ri[e]) * ldo + c : fa.zero);
+        }
+      }
+    };
+    auto fetch_frag = [&](int t, double (&a)[16]) {
+      const bool border = t >= nown;
+      const int rbase = border ? ns + (t - nown) * TW : (ct + t) * TW;
+      const int rows = min(TW, (border ? d : ns) - rbase);
+      const int nk = (rows + 3) >> 2;
+      const double* Ac = Am + 256 * frag_bwd_in_chain(nown, nko, t);
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) a[kk] = (wok && kk < nk) ? Ac[kk * 256] : 0.0;
+      frag_rows = rows;
+    };
+    auto commit_vec = [&]() {
+#pragma unroll
+      for (int e = 0; e < IT; ++e) {
+        const int idx = threadIdx.x + e * kThreads;
+        Bs[(idx / T::KB) * T::BLD + (idx & (T::KB - 1))] = bv[e];
+      }
+    };
+    double4_t c[T::NT];
+#pragma unroll
+    for (int n = 0; n < T::NT; ++n) c[n] = double4_t{0.0, 0.0, 0.0, 0.0};
+    auto stepb = [&](int t, double (&cur)[16], double (&nxt)[16]) {
+      const int nk = (frag_rows + 3) >> 2;  // (of the tile in `cur`)
+      commit_vec();
+      __syncthreads();
+      if (t + 1 < w.s1) {
+        fetch_vec(t + 1);
+        fetch_frag(t + 1, nxt);
+        if (t + 2 < w.s1) fetch_idx(t + 2);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        if (kk < nk) {
+          const int k = 4 * kk + lk;
+#pragma unroll
+          for (int n = 0; n < T::NT; ++n)
+            c[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[kk], Bs[k * T::BLD + 16 * n + li], c[n], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    };
+    double a0[16], a1[16];
+    fetch_frag(w.s0, a0);
+    fetch_idx(w.s0);
+    fetch_vec(w.s0);
+    if (w.s0 + 1 < w.s1) fetch_idx(w.s0 + 1);
+    for (int t = w.s0; t < w.s1; t += 2) {
+      stepb(t, a0, a1);
+      if (t + 1 < w.s1) stepb(t + 1, a1, a0);
+    }
+#pragma unroll
+    for (int n = 0; n < T::NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[4 * n + r] = c[n][r];
+  } else {
   fetch_idx(w.s0);
   fetch_val(w.s0);
   if (w.s0 + 1 < w.s1) fetch_idx(w.s0 + 1);
@@ -1156,16 +1354,16 @@ __global__ __launch_bounds__(kThreads) void bwd_level_kernel(FrontArrays fa, Lev
     T::mac(As, Bs, kdim, acc);
     __syncthreads();
   }
+  }
   // destination rows first (in flight while the groups of a split chain are joined), ONE explicit wait, then the
   // stores: an index load inside each masked store block would make every store wait for the one before it
-  int oi[T::NOUT];
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) {
     int o, c;
     T::coords(t, o, c);
     oi[t] = *((o < wc && c < kb) ? fa.v_src + vbase + c0t + o : fa.neg1);
   }
-  if (w.G > 1 && !fold_groups<KPT>(w, la, acc, reinterpret_cast<int*>(As))) return;
+  if (w.G > 1 && !fold_groups<KPT>(w, la, acc, reinterpret_cast<int*>(lds_tiles))) return;
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll
   for (int t = 0; t < T::NOUT; ++t) {
@@ -1734,6 +1932,57 @@ __global__ __launch_bounds__(kThreads) void pack_front_kernel(FrontArrays fa, co
     dst[static_cast<int64_t>(go) * d] = src[static_cast<int64_t>(go) * lds];
 }
 
+// Fragment-major copies of [T; M21] for the fronts with several column tiles.  The level kernels of those fronts feed
+// v_mfma_f64_16x16x4 from global memory; read from the column-major panel, a wave's operand load is four 128-byte
+// pieces a leading dimension apart (measured: slower than staging 512-byte column pieces through LDS).  Here every
+// 64 x 64 tile is stored in the order the four waves of a workgroup consume it: K-step kk, wave v, lane l at
+// kk*256 + v*64 + l, so one K-step of the workgroup is 2 KB of consecutive memory and a tile one contiguous block.
+//   forward  (Fm): tile (row tile rt, column tile ct), lane (i, k) = R(row0 + 16 v + i, 64 ct + 4 kk + k); row tiles =
+//                  the own tiles (ct <= rt) and then the border tiles (from row ns); K-steps: those meeting columns < ns
+//   backward (Bm): tile (column tile ct, chain step t), lane (i, k) = R(rbase + 4 kk + k, 64 ct + 16 v + i); K-steps:
+//                  those meeting rows of the tile
+// Cells outside the front hold zeros: the sweeps need no lane masks.
+__global__ __launch_bounds__(kThreads) void pack_frag_kernel(FrontArrays fa, const FragFront* __restrict__ ff,
+                                                            const int* __restrict__ mt_pref, int nff,
+                                                            const double* __restrict__ F, const double* __restrict__ Tb,
+                                                            double* __restrict__ Fm, double* __restrict__ Bm) {
+  __shared__ double tile[TW][TW + 1];
+  const int q = find_slot(mt_pref, nff, blockIdx.x);
+  const FragFront r = ff[q];
+  const int f = r.f;
+  const int ns = fa.ns[f], d = ns + fa.bs[f];
+  const int local = blockIdx.x - mt_pref[q];
+  const int rt = local / r.nst, ct = local - rt * r.nst;
+  const bool own = rt < r.nst;
+  if (own && ct > rt) return;  // T is block lower triangular: those tiles are never read
+  const int row0 = own ? rt * TW : ns + (rt - r.nst) * TW;
+  const int rows = min(TW, (own ? ns : d) - row0);
+  const int c0 = ct * TW, cols = min(TW, ns - c0);
+  const int tr = threadIdx.x & (TW - 1), tq = threadIdx.x >> 6;
+  for (int oo = tq; oo < TW; oo += kThreads / TW) {  // coalesced along the rows of the column-major source
+    double v = 0.0;
+    if (tr < rows && oo < cols)
+      v = own ? Tb[fa.toff[f] + static_cast<int64_t>(c0 + oo) * ns + row0 + tr]
+              : F[fa.foff[f] + static_cast<int64_t>(c0 + oo) * d + row0 + tr];
+    tile[tr][oo] = v;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  {
+    const int nk = (cols + 3) >> 2;
+    double* dst = Fm + r.fm + 256 * (frag_fwd_steps(r.nst, r.nko, rt) + 16LL * ct) + wave * 64 + lane;
+    for (int kk = 0; kk < nk; ++kk) dst[kk * 256] = tile[16 * wave + li][4 * kk + lk];
+  }
+  {
+    const int nown = r.nst - ct;
+    const int t = own ? rt - ct : nown + (rt - r.nst);
+    const int nk = (rows + 3) >> 2;
+    double* dst = Bm + r.bm + 256 * (frag_bwd_steps(r.nst, r.nbt, r.nko, r.nkb, ct) + frag_bwd_in_chain(nown, r.nko, t)) +
+                  wave * 64 + lane;
+    for (int kk = 0; kk < nk; ++kk) dst[kk * 256] = tile[4 * kk + lk][16 * wave + li];
+  }
+}
+
 }  // namespace eigd
 
 using namespace eigd;
@@ -1774,6 +2023,11 @@ struct eigd_factor {
   int64_t* d_ftoff = nullptr;
   int* d_tr_pref = nullptr;
   double* d_Ft = nullptr;
+  double *d_Fm = nullptr, *d_Bm = nullptr;  // fragment-major copies (fronts with several column tiles)
+  FragFront* d_ff = nullptr;
+  int* d_mt_pref = nullptr;
+  int n_ff = 0, n_mt = 0;
+  int64_t fm_doubles = 0, bm_doubles = 0;
   int64_t* d_pkoff = nullptr;  // packed sweep panels (level-major), nullptr: the sweeps read F and T
   double* d_Pk = nullptr;
   int64_t ft_doubles = 0;
@@ -1897,6 +2151,11 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false, bool piv
       EIGD_LAUNCH_CHECK();
     }
   }
+  if (f->n_mt > 0) {
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(f->n_mt), dim3(kThreads), 0, st, fa, f->d_ff, f->d_mt_pref, f->n_ff, f->d_F,
+                       f->d_T, f->d_Fm, f->d_Bm);
+    EIGD_LAUNCH_CHECK();
+  }
   int flag[2] = {0, 0};
   EIGD_HIP(hipMemcpyAsync(flag, f->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   EIGD_HIP(hipStreamSynchronize(st));
@@ -1933,16 +2192,30 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     const char* v = std::getenv("EIGD_DEEP");
     return (v && *v) ? std::atoi(v) != 0 : false;
   }();
-  auto level_args = [&](const WgRec* wg, int kd = TW) {
+  static const bool xcd_ranges = [] {  // EIGD_XCD=0: records in launch order (round-robin over the XCDs)
+    const char* v = std::getenv("EIGD_XCD");
+    return (v && *v) ? std::atoi(v) != 0 : true;
+  }();
+  auto level_args = [&](const WgRec* wg, int kd = TW, int nwg = 0, bool multi = false) {
     LevelArgs la;
     la.wg = wg;
     la.P = wP;
     la.tickets = wT;
     la.kb = kb;
     la.kd = kd;
+    la.nwg = nwg;
+    la.per_xcd = (multi && xcd_ranges) ? (nwg + 7) / 8 : 0;
     return la;
   };
+  auto multi_grid = [&](int nwg) { return dim3(xcd_ranges ? 8 * ((nwg + 7) / 8) : nwg); };
   auto lds_bytes = [](int kd) { return static_cast<unsigned>(sizeof(double) * (kd + 1) * (TLD + Tile<KPT>::BLD)); };
+  // fronts with several column tiles, MFMA widths: matrix operands straight from the fragment-major copies (only the
+  // vector block in LDS); EIGD_FRAG=0: staged through LDS from the column-major panels
+  static const bool frag = [] {
+    const char* v = std::getenv("EIGD_FRAG");
+    return (v && *v) ? std::atoi(v) != 0 : true;
+  }();
+  const unsigned lds_frag = static_cast<unsigned>(sizeof(double) * (TW + 1) * Tile<KPT>::BLD);
   const double* sF = f->d_Pk ? f->d_Pk : f->d_F;  // the panels [T; M21]: packed copy, or in place (F and T)
   const double* sT = f->d_Pk ? f->d_Pk : f->d_T;
   // fused bottom subtrees (16 / 32 columns): one launch for all their levels; the per-level launches below then
@@ -2071,13 +2344,27 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
       EIGD_LAUNCH_CHECK();
     }
     if (nwg > nsingle) {
-      if (two)
-        hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, 2>), dim3(nwg - nsingle), dim3(kThreads), lds_bytes(TW), st,
-                           fa, level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), sF, sT, dIn, ldin, alpha, wV, wY);
-      else
-        hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, kMaxS + 1>), dim3(nwg - nsingle), dim3(kThreads),
-                           lds_bytes(TW), st, fa, level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle), sF, sT, dIn, ldin,
-                           alpha, wV, wY);
+      const LevelArgs la = level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle, TW, nwg - nsingle, true);
+      bool done = false;
+      if constexpr (Tile<KPT>::kMfma) {
+        if (frag) {
+          if (two)
+            hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, 2, true>), multi_grid(nwg - nsingle), dim3(kThreads),
+                               lds_frag, st, fa, la, f->d_Fm, sT, dIn, ldin, alpha, wV, wY);
+          else
+            hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, kMaxS + 1, true>), multi_grid(nwg - nsingle),
+                               dim3(kThreads), lds_frag, st, fa, la, f->d_Fm, sT, dIn, ldin, alpha, wV, wY);
+          done = true;
+        }
+      }
+      if (!done) {
+        if (two)
+          hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, 2>), multi_grid(nwg - nsingle), dim3(kThreads),
+                             lds_bytes(TW), st, fa, la, sF, sT, dIn, ldin, alpha, wV, wY);
+        else
+          hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, kMaxS + 1>), multi_grid(nwg - nsingle), dim3(kThreads),
+                             lds_bytes(TW), st, fa, la, sF, sT, dIn, ldin, alpha, wV, wY);
+      }
       EIGD_LAUNCH_CHECK();
     }
   }
@@ -2091,8 +2378,18 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     bool thin = false;
     if constexpr (KPT >= 4) thin = !narrow && nwave > 0 && f->h_thin_bwd[l] > 0;
     if (nwg > nsb) {  // fronts with several column tiles: full 64-row tiles
-      hipLaunchKernelGGL((bwd_level_kernel<KPT, false>), dim3(nwg - nsb), dim3(kThreads), lds_bytes(TW), st, fa,
-                         level_args(f->d_bwd_wg + f->h_bwd_ptr[l] + nsb), sF, sT, wY, dX, ldx);
+      const LevelArgs la = level_args(f->d_bwd_wg + f->h_bwd_ptr[l] + nsb, TW, nwg - nsb, true);
+      bool done = false;
+      if constexpr (Tile<KPT>::kMfma) {
+        if (frag) {
+          hipLaunchKernelGGL((bwd_level_kernel<KPT, false, true>), multi_grid(nwg - nsb), dim3(kThreads), lds_frag, st, fa, la,
+                             sF, sT, f->d_Bm, wY, dX, ldx);
+          done = true;
+        }
+      }
+      if (!done)
+        hipLaunchKernelGGL((bwd_level_kernel<KPT, false>), multi_grid(nwg - nsb), dim3(kThreads), lds_bytes(TW), st, fa, la, sF,
+                           sT, f->d_Ft, wY, dX, ldx);
       EIGD_LAUNCH_CHECK();
     }
     if (narrow) {
@@ -2123,7 +2420,7 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
       }
     } else if (nsb > 0) {  // single-column-tile fronts: LDS tiles as tall as the level needs
       hipLaunchKernelGGL((bwd_level_kernel<KPT, true>), dim3(nsb), dim3(kThreads), lds_bytes(f->h_bwd_kd[l]), st, fa,
-                         level_args(f->d_bwd_wg + f->h_bwd_ptr[l], f->h_bwd_kd[l]), sF, sT, wY, dX, ldx);
+                         level_args(f->d_bwd_wg + f->h_bwd_ptr[l], f->h_bwd_kd[l]), sF, sT, f->d_Ft, wY, dX, ldx);
       EIGD_LAUNCH_CHECK();
     }
   }
@@ -2232,6 +2529,7 @@ int eigd_factor_free(eigd_factor* f) {
                   f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_ov_dst,   f->d_ov_ptr, f->d_ov_src,
                   f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux,      f->d_bout,  f->d_tickets,
                   f->d_P,         f->d_wave_wg,     f->d_ftoff,      f->d_tr_pref,  f->d_Ft,
+                  f->d_Fm,        f->d_Bm,          f->d_ff,         f->d_mt_pref,
                   f->d_pkoff,     f->d_Pk,          f->d_sub_trees,  f->d_sub_fronts};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -2257,6 +2555,29 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     toff[q + 1] = toff[q] + ns * ns;
     tri_pref[q + 1] = tri_pref[q] + static_cast<int>((ns + s.W - 1) / s.W);
     m_pref[q + 1] = m_pref[q] + (s.f_bs[q] + TW - 1) / TW;
+  }
+  // fragment-major copies for the fronts with several column tiles (see pack_frag_kernel)
+  std::vector<FragFront> ffr;
+  std::vector<int> mt_pref(1, 0), ff_of(static_cast<size_t>(nf), -1);
+  int64_t fm_doubles = 0, bm_doubles = 0;
+  for (int q = 0; q < nf; ++q) {
+    const int ns = s.f_ns[q], bs = s.f_bs[q];
+    const int nst = (ns + TW - 1) / TW, nbt = (bs + TW - 1) / TW;
+    if (nst < 2) continue;
+    FragFront r;
+    r.f = q;
+    r.nst = nst;
+    r.nbt = nbt;
+    r.nko = (ns - TW * (nst - 1) + 3) / 4;
+    r.nkb = (nbt > 0) ? (bs - TW * (nbt - 1) + 3) / 4 : 0;
+    r.pad = 0;
+    r.fm = fm_doubles;
+    r.bm = bm_doubles;
+    fm_doubles += 256 * frag_fwd_steps(nst, r.nko, nst + nbt);
+    bm_doubles += 256 * frag_bwd_steps(nst, nbt, r.nko, r.nkb, nst);
+    ff_of[q] = static_cast<int>(ffr.size());
+    ffr.push_back(r);
+    mt_pref.push_back(mt_pref.back() + (nst + nbt) * nst);
   }
   // carry planes: child number q of a front (ascending front order) writes plane q; children beyond kMaxS write
   // the scratch plane and are summed into the extra plane (overflow_sum_kernel) before their parent's level runs
@@ -2347,16 +2668,25 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     w.ldt = packed ? s.f_ns[fr] + s.f_bs[fr] : s.f_ns[fr];
     w.bptr = s.f_bptr[fr];
     w.ftoff = ftoff[fr];
+    w.moff = 0;
     const int par = s.f_parent[fr];
     w.pvoff = (par >= 0) ? s.f_voff[par] : -1;
     w.scratch = (child_no[fr] >= kMaxS) ? 1 : 0;
     w.slot = w.scratch ? nslot : child_no[fr];
   };
-  auto push_chain = [&](std::vector<WgRec>& out, int64_t& slabs, int fr, int tile, int L, bool split, int flags) {
+  auto push_chain = [&](std::vector<WgRec>& out, int64_t& slabs, int fr, int tile, int L, bool split, int flags,
+                        bool backward) {
     const int G = (split && L > split_min) ? std::min(split_maxg, (L + split_len - 1) / split_len) : 1;
+    int64_t moff = 0;  // the chain's first tile in the fragment-major copy
+    if (ff_of[fr] >= 0) {
+      const FragFront& r = ffr[ff_of[fr]];
+      moff = backward ? r.bm + 256 * frag_bwd_steps(r.nst, r.nbt, r.nko, r.nkb, tile)
+                      : r.fm + 256 * frag_fwd_steps(r.nst, r.nko, tile);
+    }
     for (int g = 0; g < G; ++g) {
       WgRec w;
       front_numbers(w, fr);
+      w.moff = moff;
       w.tile = tile;
       w.s0 = static_cast<int>(static_cast<int64_t>(L) * g / G);
       w.s1 = static_cast<int>(static_cast<int64_t>(L) * (g + 1) / G);
@@ -2409,13 +2739,13 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
         }
       } else {
         for (int t = nst + nbt - 1; t >= 0; --t)  // border tiles (nst products) first, then the own tiles, longest first
-          push_chain(multi, fwd_slabs, fr, t, t < nst ? t + 1 : nst, split_level, kids);
+          push_chain(multi, fwd_slabs, fr, t, t < nst ? t + 1 : nst, split_level, kids, false);
       }
       const int nbt_b = (s.f_parent[fr] >= 0) ? nbt : 0;
       for (int t = 0; t < nst; ++t)
         // (a single-column-tile front is never split: the wave kernels run it in one piece, and a column's solution
         // must not depend on the width of the sweep it is part of)
-        push_chain(nst == 1 ? bwd_wg : bmulti, bwd_slabs, fr, t, nst - t + nbt_b, split_level && nst > 1, 0);
+        push_chain(nst == 1 ? bwd_wg : bmulti, bwd_slabs, fr, t, nst - t + nbt_b, split_level && nst > 1, 0, true);
     }
     h_fwd_nsingle[l] = static_cast<int>(fwd_wg.size()) - h_fwd_ptr[l];
     h_bwd_nsingle[l] = static_cast<int>(bwd_wg.size()) - h_bwd_ptr[l];
@@ -2432,7 +2762,8 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   size_t free_b = 0, total_b = 0;
   EIGD_HIP(hipMemGetInfo(&free_b, &total_b));
   const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + toff[nf] +
-                                        (packed ? 2 : 1) * ftoff[nf] + (2 * nplanes + 1) * v_rows * KBMAX + n_slabs * TW * KBMAX) +
+                                        (packed ? 2 : 1) * ftoff[nf] + fm_doubles + bm_doubles + (2 * nplanes + 1) * v_rows * KBMAX +
+                                        n_slabs * TW * KBMAX) +
                       16 * s.a_src.size() + (size_t(64) << 20);
   if (need > free_b) {
     set_error("factor needs %.2f GiB of device memory, %.2f GiB free", need / 1073741824.0, free_b / 1073741824.0);
@@ -2483,6 +2814,10 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   }
   f->h_wave_ptr = h_wave_ptr;
   f->ft_doubles = ftoff[nf];
+  f->fm_doubles = fm_doubles;
+  f->bm_doubles = bm_doubles;
+  f->n_ff = static_cast<int>(ffr.size());
+  f->n_mt = mt_pref.back();
   f->n_tr = tr_pref[nf];
   f->h_bwd_ptr = h_bwd_ptr;
   f->ov_lvl_ptr = ov_lvl_ptr;
@@ -2627,6 +2962,10 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     UP(d_pkoff, pkoff)
   }
   UP(d_tr_pref, tr_pref)
+  UP(d_mt_pref, mt_pref)
+  if (!ffr.empty()) {
+    UP(d_ff, ffr)
+  }
   UP(d_bout, bout)
   UP(d_tri_pref, tri_pref)
   UP(d_m_pref, m_pref)
@@ -2673,6 +3012,8 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   rc = dmalloc(&f->d_T, static_cast<size_t>(f->t_doubles));
   rc = dmalloc(&f->d_aux, 2);
   rc = dmalloc(&f->d_Ft, static_cast<size_t>(f->ft_doubles));
+  rc = dmalloc(&f->d_Fm, static_cast<size_t>(std::max<int64_t>(f->fm_doubles, 1)));
+  rc = dmalloc(&f->d_Bm, static_cast<size_t>(std::max<int64_t>(f->bm_doubles, 1)));
   if (packed) rc = dmalloc(&f->d_Pk, static_cast<size_t>(std::max<int64_t>(pkoff[nf], 1)));
   rc = dmalloc(&f->d_P, static_cast<size_t>(n_slabs) * TW * KBMAX);
   if (rc == EIGD_OK) {
