@@ -1642,10 +1642,18 @@ __global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, cons
     double4_t c[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) c[nb] = double4_t{0.0, 0.0, 0.0, 0.0};
+    // K-steps past the front's columns or (own rows) past the diagonal block multiply zeros: skipped (wave-uniform
+    // bound; on gfx950 an fp64 MFMA holds the SIMD's matrix pipe for 64 cycles -- at the leaf level they were a third
+    // of the SIMD time, 40 % of them on zeros)
+    // (not in the 12- to 16-step variants: the guarded form costs them 40 registers and a wave per SIMD; the leaf
+    // level gets a variant with as many K-steps as its widest front needs instead)
+    const int kmax = (NKS <= 8) ? min(smax, (ns + 3) >> 2) : NKS;
 #pragma unroll
     for (int s = 0; s < NKS; ++s)
+      if (NKS > 8 || s < kmax) {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) c[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s][nb], c[nb], 0, 0, 0);
+        for (int nb = 0; nb < NB; ++nb) c[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s][nb], c[nb], 0, 0, 0);
+      }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one wait, then the stores back to back
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -1722,12 +1730,18 @@ __global__ __launch_bounds__(64) void bwd_thin_kernel(FrontArrays fa, const WgRe
       }
     }
 #pragma unroll
-    for (int s = 0; s < CH; ++s)
+    for (int s = 0; s < CH; ++s) {
+      const int k0 = 4 * CH * ch + 4 * s;  // products with rows past the front, columns past the front's or entries above
+      if (KB < 32 || k0 < d) {             // the diagonal block are products with zeros: skipped (wave-uniform tests;
+#pragma unroll                             // 32 columns only: the 16-column variants schedule worse with the guards)
+        for (int ob = 0; ob < NOB; ++ob)
+          if (KB < 32 || (16 * ob < ns && !(TRI && k0 + 3 < 16 * ob))) {
 #pragma unroll
-      for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          c[ob][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][ob], b[s][nb], c[ob][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb)
+              c[ob][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][ob], b[s][nb], c[ob][nb], 0, 0, 0);
+          }
+      }
+    }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll
@@ -2304,6 +2318,10 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
           EIGD_THIN_FWD(4, 0);
         else if (leaf && nks == 8)
           EIGD_THIN_FWD(8, 0);
+        else if (leaf && nks == 12)
+          EIGD_THIN_FWD(12, 0);
+        else if (leaf && nks == 14)
+          EIGD_THIN_FWD(14, 0);
         else if (leaf)
           EIGD_THIN_FWD(16, 0);
         else if (nks == 4 && two)
@@ -2797,8 +2815,11 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     f->h_thin_bwd.assign(static_cast<size_t>(s.nlevels), 0);
     for (int l = 0; l < s.nlevels; ++l) {
       const int nks = (mxns[l] <= 16) ? 4 : (mxns[l] <= 32) ? 8 : 16;
+      // leaf level: K-steps of the forward kernel cut to the widest front (12 / 14 instead of 16: fewer MFMAs on zeros)
+      const int nks_leaf = (mxns[l] > 32 && mxns[l] <= 48) ? 12 : (mxns[l] > 48 && mxns[l] <= 56) ? 14 : nks;
       // (with carries to gather, the 16-step forward variant needs 244 VGPRs: those levels stay with the tile kernels)
-      if (mxns[l] > 0 && mxns[l] <= (f->h_lvl_leaf[l] ? thin_fwd : std::min(thin_fwd, 32))) f->h_thin_fwd[l] = nks;
+      if (mxns[l] > 0 && mxns[l] <= (f->h_lvl_leaf[l] ? thin_fwd : std::min(thin_fwd, 32)))
+        f->h_thin_fwd[l] = f->h_lvl_leaf[l] ? nks_leaf : nks;
       // (backward: one wave per front -- with more than 32 own columns only where the level has fronts enough to
       // fill the chip that way)
       const int nfl = h_wave_ptr[l + 1] - h_wave_ptr[l];
