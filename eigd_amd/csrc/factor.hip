@@ -1551,7 +1551,7 @@ template <int KB, int NKS, int NSL, int WPF, bool TRI>
 __global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
                                                        const double* __restrict__ F, const double* __restrict__ Tb,
                                                        const double* X, int ldx, double alpha, double* V,
-                                                       double* __restrict__ Y, int kb) {
+                                                       double* __restrict__ Y, int kb, const double* __restrict__ Ftp) {
   constexpr int NB = KB / 16;
   const WgRec w = recs[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1602,7 +1602,9 @@ __global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, cons
 #pragma unroll
     for (int s = 0; s < NKS; ++s) {
       const int o = 4 * s + lk;
-      const double* p = (r < ns) ? Tf + static_cast<int64_t>(o) * w.ldt + r : Ff + static_cast<int64_t>(o) * d + r;
+      // (Ftp: the row-major copy Ft -- a block of 16 rows is one contiguous piece of memory there)
+      const double* p = Ftp ? Ftp + w.ftoff + static_cast<int64_t>(r) * ns + o
+                            : (r < ns) ? Tf + static_cast<int64_t>(o) * w.ldt + r : Ff + static_cast<int64_t>(o) * d + r;
       a[s] = *((o < ns && r < d && s < smax) ? p : fa.zero);
     }
     // what the results meet: lane (reg, nb) <-> row 16 rb + lk + 4 reg, column 16 nb + li
@@ -2302,17 +2304,25 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
           return (v && *v) ? std::atoi(v) : 1;
         }();
         const bool one = thin_wpf != 2;
+        // matrix operands from the row-major copy Ft (16 rows of [T; M21] = one contiguous piece: every line is fetched
+        // once -- from the column-major panels a line shared by two row blocks often came from HBM twice, and M21
+        // sits strided inside F): -0.28 GB per 32-column sweep, time unchanged.  EIGD_THIN_ROWM=0: column-major, 1: leaf level only
+        static const int thin_rowm = [] {
+          const char* v = std::getenv("EIGD_THIN_ROWM");
+          return (v && *v) ? std::atoi(v) : 2;
+        }();
+        const double* thin_ft = (thin_rowm == 2 || (thin_rowm == 1 && leaf)) ? f->d_Ft : nullptr;
 #define EIGD_THIN_FWD(NKS, NSLV)                                                                                        \
   do {                                                                                                                  \
     if (!fa.tri)                                                                                                        \
       hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, false>), dim3(nwave), dim3(64), 0, st, fa, recs, sF, sT, dIn, \
-                         ldin, alpha, wV, wY, kb);                                                                      \
+                         ldin, alpha, wV, wY, kb, thin_ft);                                                             \
     else if (one)                                                                                                       \
       hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, true>), dim3(nwave), dim3(64), 0, st, fa, recs, sF, sT, dIn,  \
-                         ldin, alpha, wV, wY, kb);                                                                      \
+                         ldin, alpha, wV, wY, kb, thin_ft);                                                             \
     else                                                                                                                \
       hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 2, true>), dim3(nwave), dim3(128), 0, st, fa, recs, sF, sT, dIn, \
-                         ldin, alpha, wV, wY, kb);                                                                      \
+                         ldin, alpha, wV, wY, kb, thin_ft);                                                             \
   } while (0)
         if (leaf && nks == 4)
           EIGD_THIN_FWD(4, 0);

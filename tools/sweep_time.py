@@ -27,6 +27,10 @@ for k in (1, 4, 8, 16, 32):
         F.solve_to(B, X)
     ctx.sync()
     out.append(f"k={k}: {1e3 * (time.perf_counter() - t0) / 20:.3f} ms")
+    if os.environ.get("DIGEST"):  # bitwise comparison of kernel variants between runs
+        import hashlib
+
+        out.append("[" + hashlib.sha1(X.get().tobytes()).hexdigest()[:10] + "]")
 x = X.get()
 r = np.linalg.norm(K @ x - B.get()) / np.linalg.norm(B.get())
 print({k: os.environ[k] for k in os.environ if k.startswith("EIGD_SPLIT")}, " ".join(out), f"resid {r:.1e}")
