@@ -643,3 +643,44 @@ def test_bunch_kaufman_over_many_interior_shifts(ctx):
             Xf = op.factor.solve_inplace(ctx.from_host(B)).get()
             assert np.linalg.norm(mat @ Xf - B) / np.linalg.norm(B) < 1e-9, sigma
             assert np.linalg.norm(mat @ op(B) - B) / np.linalg.norm(B) < 1e-12, sigma
+
+
+def test_multi_tile_fronts_with_ragged_sizes_through_the_fragment_kernels(ctx):
+    """
+    Fronts with several column tiles whose sizes are multiples of nothing (own columns and borders that end inside a
+    64-tile, inside a 16-row wave strip and inside a K-step of 4): the 16- and 32-column level kernels read them from the
+    fragment-major copies (pack_frag_kernel), the narrow ones from the column-major panels -- every width against
+    SuperLU, columns bitwise independent of the width, after a refactorisation too, and on the Bunch-Kaufman path
+    (dense diagonal blocks in the copies).
+    """
+    import eigd_amd as eg
+    from eigd_amd.device import Factor, Symbolic
+
+    A = lap3d(23)                                   # 12 167 dofs, separators of 23 x 23 = 529 and ragged smaller ones
+    sym = Symbolic(A, leaf_size=24)
+    ns, bs = sym.array("f_ns"), sym.array("f_bs")
+    multi = ns > 64
+    assert multi.sum() >= 3 and (ns[multi] % 4 != 0).any() and (ns[multi] % 64 != 0).all() and (bs[multi] % 16 != 0).any()
+    F = Factor(ctx, A, symbolic=sym)
+    lu = splu(A.tocsc())
+    rng = np.random.default_rng(11)
+    B = rng.normal(size=(A.shape[0], 32))
+    Xall = F.solve_inplace(ctx.from_host(B)).get()
+    assert relerr(Xall, lu.solve(B)) < 1e-11
+    for lo, hi in ((0, 1), (3, 7), (5, 13), (2, 18), (16, 32)):       # 4-, 8-, 16- and 32-column kernels
+        Xp = F.solve_inplace(ctx.from_host(B[:, lo:hi])).get()
+        assert np.array_equal(Xall[:, lo:hi], Xp), (lo, hi)
+    A2 = (A + 0.37 * sparse.identity(A.shape[0])).tocsr()
+    F.refactor(A2)                                                     # the copies follow the numeric phase
+    X2 = F.solve_inplace(ctx.from_host(B)).get()
+    assert relerr(X2, splu(A2.tocsc()).solve(B)) < 1e-11
+    ev = np.sort(np.linalg.eigvalsh(A[:400, :400].toarray()))
+    sigma = 0.5 * (ev[200] + ev[201])                                  # well inside the spectrum of A (interlacing)
+    Ai = (A - sigma * sparse.identity(A.shape[0])).tocsr()
+    op = eg.SpLuOperator(Ai.tocsc(), ctx=ctx)
+    assert op.negative_pivots > 100
+    Xi = op.factor.solve_inplace(ctx.from_host(B)).get()               # the factor alone, no refinement
+    assert np.linalg.norm(Ai @ Xi - B) / np.linalg.norm(B) < 1e-8
+    assert relerr(op(B), splu(Ai.tocsc()).solve(B)) < 1e-8
+    Xn = op.factor.solve_inplace(ctx.from_host(B[:, 4:9])).get()
+    assert np.array_equal(Xi[:, 4:9], Xn)
