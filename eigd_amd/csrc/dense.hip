@@ -78,10 +78,10 @@ __global__ __launch_bounds__(kThreads) void stack_dot_kernel(int n, int k, int n
   if (c < k)
     for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
       const double t = T[r * ldt + c];
-      const double* sp = S + r * lds + c;
+      const unsigned off = static_cast<unsigned>(r * lds + c);  // uniform slab base + 32-bit lane offset (n * lds < 2^31)
       double sv[JB];
 #pragma unroll
-      for (int j = 0; j < JB; ++j) sv[j] = (j < nj) ? sp[j * slab] : 0.0;
+      for (int j = 0; j < JB; ++j) sv[j] = (j < nj) ? (S + j * slab)[off] : 0.0;
 #pragma unroll
       for (int j = 0; j < JB; ++j) acc[j] += sv[j] * t;
     }
@@ -153,10 +153,11 @@ __global__ __launch_bounds__(kThreads) void stack_axpy_dot_kernel(int n, int k, 
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) hc[j] = (j < ns) ? alpha * Hs[j * k + c] : 0.0;
     for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
-      const double* sp = S + r * lds + c;
+      // uniform slab base + one 32-bit lane offset (the host checks n * lds < 2^31): no 64-bit address per slab in VGPRs
+      const unsigned off = static_cast<unsigned>(r * lds + c);
       double sv[JMAX];
 #pragma unroll
-      for (int j = 0; j < JMAX; ++j) sv[j] = (j < ns) ? sp[j * slab] : 0.0;
+      for (int j = 0; j < JMAX; ++j) sv[j] = (j < ns) ? (S + j * slab)[off] : 0.0;
       double t = T[r * ldt + c];
 #pragma unroll
       for (int j = 0; j < JMAX; ++j) t += sv[j] * hc[j];
@@ -731,8 +732,8 @@ int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_
                    int ldt, double* hH) {
   EIGD_REQUIRE(ctx && dS && dT && hH, "null argument");
   EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && lds >= k &&
-                   slab >= static_cast<int64_t>(n - 1) * lds + k,
-               "bad shape n=%d k=%d ns=%d", n, k, ns);
+                   slab >= static_cast<int64_t>(n - 1) * lds + k && static_cast<int64_t>(n) * lds < (int64_t(1) << 31),
+               "bad shape n=%d k=%d ns=%d (a slab must hold fewer than 2^31 doubles)", n, k, ns);
   constexpr int JB = 16;
   const int kp = next_pow2(k);
   const int nb = grid_for_rows(n, (kThreads / kp) * 8);
@@ -826,8 +827,8 @@ int eigd_stack_cgs2(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
                     double tol, double* hH, int* hpasses) {
   EIGD_REQUIRE(ctx && dS && dT && hH, "null argument");
   EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && lds >= k &&
-                   slab >= static_cast<int64_t>(n - 1) * lds + k,
-               "bad shape n=%d k=%d ns=%d", n, k, ns);
+                   slab >= static_cast<int64_t>(n - 1) * lds + k && static_cast<int64_t>(n) * lds < (int64_t(1) << 31),
+               "bad shape n=%d k=%d ns=%d (a slab must hold fewer than 2^31 doubles)", n, k, ns);
   EIGD_REQUIRE(static_cast<size_t>(ns) * k * sizeof(double) <= 60 * 1024, "stack too deep for one pass: ns*k=%d", ns * k);
   const size_t nh = static_cast<size_t>(ns) * k;
   int rc = ctx->ensure_coef(sizeof(double) * 2 * nh);  // [h1][h2]: device copies of the coefficients
@@ -958,8 +959,8 @@ int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
                     double* dT, int ldt, double alpha) {
   EIGD_REQUIRE(ctx && dS && dT && hH, "null argument");
   EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && lds >= k &&
-                   slab >= static_cast<int64_t>(n - 1) * lds + k,
-               "bad shape n=%d k=%d ns=%d", n, k, ns);
+                   slab >= static_cast<int64_t>(n - 1) * lds + k && static_cast<int64_t>(n) * lds < (int64_t(1) << 31),
+               "bad shape n=%d k=%d ns=%d (a slab must hold fewer than 2^31 doubles)", n, k, ns);
   EIGD_REQUIRE(static_cast<size_t>(ns) * k * sizeof(double) <= 60 * 1024, "stack too deep for one pass: ns*k=%d", ns * k);
   int rc = ctx->ensure_coef(sizeof(double) * ns * k);
   if (rc) return rc;
@@ -980,8 +981,8 @@ int eigd_stack_axpy_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, i
                         double* dT, int ldt, double alpha, double* hH2) {
   EIGD_REQUIRE(ctx && dS && dT && hH1 && hH2, "null argument");
   EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ns <= 32 && ldt >= k && lds >= k &&
-                   slab >= static_cast<int64_t>(n - 1) * lds + k,
-               "bad shape n=%d k=%d ns=%d", n, k, ns);
+                   slab >= static_cast<int64_t>(n - 1) * lds + k && static_cast<int64_t>(n) * lds < (int64_t(1) << 31),
+               "bad shape n=%d k=%d ns=%d (a slab must hold fewer than 2^31 doubles)", n, k, ns);
   const int kp = next_pow2(k);
   const int nb = grid_for_rows(n, (kThreads / kp) * 8);
   int rc = ctx->ensure_coef(sizeof(double) * ns * k);
