@@ -79,6 +79,8 @@ _SIGNATURES = {
     "eigd_stack_axpy": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_dbl],
     "eigd_stack_axpy_dot": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_dbl, c_vp],
     "eigd_stack_cgs2": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_int, c_dbl, c_vp, c_vp],
+    "eigd_stack_cgs2_pair": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_int, c_dbl, c_vp, c_vp],
+    "eigd_pair_orthonormalise": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp],
     "eigd_csr_update_values_dev": [c_vp, c_vp],
     "eigd_factor_refactor_dev": [c_vp, c_vp],
     "eigd_assembler_create": [c_vp, c_int, c_int, c_int, c_vp, c_vp],

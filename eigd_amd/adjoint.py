@@ -642,6 +642,166 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist, compa
     return dpsi, converged, info
 
 
+def _sstep_default():
+    import os
+
+    # Krylov steps per Gram-Schmidt pass of the lock-step solver (2: _sibk_round_pair; 1: every step is orthogonalised
+    # before the next operator application, as the reference's loop is written)
+    return int(os.environ.get("EIGD_SSTEP", "2"))
+
+
+def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
+    """
+    The lock-step solver with TWO Krylov steps per Gram-Schmidt pass.  Same Krylov spaces, same Hessenberg matrices
+    and residual history (to rounding) and therefore the same iteration counts and solutions as _sibk_round; half the
+    passes over the Krylov history, which are a third of a step at 1 M dof.
+
+    A cycle starts from an orthonormal w_j and applies the operator twice without orthogonalising in between:
+        z1 = factor(w_j),  v1 = P K z1            (reference 1248-1252)
+        z2 = factor(v1),   v2 = P K z2
+    Then the pair [v1 | v2] is orthogonalised against W_0..W_j in ONE classical Gram-Schmidt step with measured second
+    pass (two passes over the stack for two new vectors, ref 1254-1256), projected (1257), and orthonormalised inside
+    the pair on the device: w_{j+1} = v1'/b1, w_{j+2} = (v2' - (w_{j+1}.v2') w_{j+1})/b2.  With v1 = W h1 + b1 w_{j+1}
+    and v2 = W g1 + gw w_{j+1} + b2 w_{j+2} the Arnoldi columns are
+        H[:, j]   = [h1; b1]
+        H[:, j+1] = ([g1; gw; b2] - H[:, :j+1] h1) / b1        (OP w_{j+1} = (v2 - OP W_{<=j} h1) / b1)
+    and factor(w_{j+1}) = (z2 - sum_i h1[i] factor(w_i)) / b1 is never formed: the solution update psi += Z y (1277)
+    uses the stored slabs with coefficients transformed on the host (Cz).  The residual of every step is evaluated from
+    H as before, so a mode stops at the same step as in the one-step form.  The operator does not amplify along the
+    Krylov vectors here (|OP w| / b is 2-3 on the 1 M-dof benchmark; measured against the one-step form on the CPU:
+    identical iteration counts, psi equal to 1e-14): two unorthogonalised steps lose no accuracy.  What one
+    Gram-Schmidt pass inside the pair leaves (w_{j+1}.w_{j+2}) is measured on the device; if it ever exceeds 1e-10 the
+    caller repeats the solve with the one-step form.
+    """
+    ctx, mode = prob.ctx, prob.mode
+    n, k = prob.n, R0.k
+    Kop = prob.opB if mode == "normal" else prob.opA
+    sgn = 1.0 if mode == "normal" else -1.0
+    info = [None] * k
+    done = np.zeros(k, dtype=bool)
+    converged = np.zeros(k, dtype=bool)
+    beta0 = R0.colnorms()
+    for c in range(k):
+        hist[c].append(beta0[c])
+        if beta0[c] < rtol * rnorm0 or beta0[c] < atol:  # ref 1223-1225
+            info[c] = 0
+            done[c] = converged[c] = True
+    dpsi = ctx.zeros(n, k)
+    if done.all():
+        return dpsi, converged, info, True
+    W = ctx.workspace_stack("krylov_W2", maxiter + 2, n, k)
+    Z = ctx.workspace_stack("krylov_Z2", maxiter + 1, n, k)
+    W0 = W[0]
+    W0.copy_from(R0)
+    prob.project_r(W0)                                   # ref 1232
+    r00 = W0.colnorms()                                  # ref 1233
+    scale = np.where(done | (r00 == 0.0), 0.0, 1.0 / np.where(r00 == 0.0, 1.0, r00))
+    W0.assign_lincomb([(scale, W0)])                     # ref 1234
+    H = np.zeros((k, maxiter + 3, maxiter + 2))
+    Cz = np.zeros((k, maxiter + 2, maxiter + 2))         # factor(w_i) = sum_s Cz[c][s, i] * (stored slab s)
+    Ycoef = np.zeros((maxiter + 1, k))                   # coefficients of the STORED slabs in psi += Z y
+    TP = ctx.empty(n, 2 * k)
+    ok = True
+
+    def enqueue_cycle(j, lo, hi):
+        """device work of one cycle up to the pair of raw vectors (no synchronisation)"""
+        kk = hi - lo
+        T1, T2 = TP.cols(0, kk), TP.cols(kk, 2 * kk)
+        Zj, Zj1 = Z[j].cols(lo, hi), Z[j + 1].cols(lo, hi)
+        prob.fac.apply_to(W[j].cols(lo, hi), Zj, count=0)
+        Kop.apply(Zj, T1)
+        prob.project_r(T1)
+        prob.fac.apply_to(T1, Zj1, count=0)
+        Kop.apply(Zj1, T2)
+        prob.project_r(T2)
+
+    def small_solves(j, lo, hi, h, vals):
+        """host side of a cycle: two Arnoldi columns, the coefficient transform and the residuals of steps j+1, j+2"""
+        nonlocal ok
+        kk = hi - lo
+        ns = j + 1
+        n1sq, gam, n2sq, defect = vals[:kk], vals[kk: 2 * kk], vals[2 * kk: 3 * kk], vals[3 * kk:]
+        for cl in range(lo, hi):
+            c, q = cl, cl - lo
+            if done[c]:
+                continue
+            Hc, Czc = H[c], Cz[c]
+            h1, g1 = h[:, q], h[:, kk + q]
+            b1 = np.sqrt(n1sq[q])
+            Hc[:ns, j] = h1
+            Hc[ns, j] = b1
+            Czc[j, j] = 1.0                               # slab j holds factor(w_j) itself
+            steps = (j + 1, j + 2)
+            if b1 > 0.0:
+                b2 = np.sqrt(n2sq[q])
+                if abs(defect[q]) > 1e-10 * max(b2, np.finfo(float).tiny):
+                    ok = False                            # (never seen: the pair was not orthogonalised well enough)
+                colv = np.zeros(ns + 2)
+                colv[:ns] = g1
+                colv[ns] = gam[q] / b1
+                colv[ns + 1] = b2
+                colv[: ns + 1] -= Hc[: ns + 1, :ns] @ h1
+                Hc[: ns + 2, j + 1] = colv / b1
+                Czc[:, j + 1] = 0.0
+                Czc[j + 1, j + 1] = 1.0 / b1
+                Czc[:ns, j + 1] -= (Czc[:ns, :ns] @ h1) / b1
+            else:
+                steps = (j + 1,)                          # breakdown: the Krylov space is exhausted at step j+1
+            for jj in steps:
+                if jj > maxiter:
+                    break
+                rvec = np.zeros(jj + 1)
+                rvec[0] = r00[c]
+                y, res = solve_shifted_lstsq(sgn * (lam_c[c] - sigma), Hc[: jj + 1, :jj], rvec)  # ref 1262-1270
+                hist[c].append(res)
+                if res < rtol * rnorm0 or res < atol:    # ref 1275
+                    info[c] = jj
+                    Ycoef[:jj, c] = Czc[:jj, :jj] @ y
+                    done[c] = converged[c] = True
+                    break
+                if jj == maxiter or (jj == steps[-1] and len(steps) == 1):   # ref 1312-1313: keep the best iterate
+                    Ycoef[:jj, c] = Czc[:jj, :jj] @ y
+                    done[c] = True
+                    break
+
+    lo, hi = _active_range(done)
+    j = 0
+    enqueue_cycle(0, lo, hi)
+    while True:
+        kk = hi - lo
+        TPv = TP.cols(0, 2 * kk)
+        h, _ = W.cgs2_pair(TPv, j + 1, c0=lo, tol=_REORTH_TOL)      # ref 1254-1256 for both vectors; one host sync
+        n2 = prob.project_r_norm2(TPv)                                # ref 1257 + 1259
+        TPv.pair_orthonormalise(n2, W[j + 1].cols(lo, hi), W[j + 2].cols(lo, hi), done[lo:hi])   # ref 1260
+        more = j + 2 < maxiter
+        if more:
+            enqueue_cycle(j + 2, lo, hi)                  # the next cycle is in flight while the host solves this one
+        vals = ctx.fetch_colnorm2(4 * kk)
+        small_solves(j, lo, hi, h, vals)
+        jlast = min(j + 2, maxiter)
+        if done.all() or not more or not ok:
+            break
+        j += 2
+        nlo, nhi = _active_range(done)
+        if (nlo, nhi) != (lo, hi):
+            # the cycle in flight was launched on the old range: move its pair to the layout of the new one
+            nk = nhi - nlo
+            T1n = ctx.empty(n, nk).copy_from(TP.cols(nlo - lo, nlo - lo + nk))
+            T2n = ctx.empty(n, nk).copy_from(TP.cols(kk + nlo - lo, kk + nlo - lo + nk))
+            TP.cols(0, nk).copy_from(T1n)
+            TP.cols(nk, 2 * nk).copy_from(T2n)
+            lo, hi = nlo, nhi
+    if prob.fac.native:                                   # one factor application per Krylov step and mode (ref 1248)
+        with prob.fac.factor._count_lock:
+            prob.fac.factor.count += int(sum((i if i is not None else maxiter) for i in info))
+    fin = np.flatnonzero(done)
+    if len(fin) and jlast > 0:
+        upd = ctx.zeros(n, k)
+        Z.axpy_into(upd, Ycoef[:jlast], alpha=1.0)       # ref 1277 / 1313: psi += Z y
+        dpsi.copy_from(upd)
+    return dpsi, converged, info, ok
+
+
 def _default_streams():
     import os
 
@@ -658,6 +818,29 @@ def _run_groups(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist, s
     k = Rc.k
     groups = max(1, min(int(streams), k))
     if groups == 1:
+        if _sstep_default() == 2:
+            keep = [list(hh) for hh in sub_hist]
+            if 2 * k <= 64:
+                upd, conv, inf, ok = _sibk_round_pair(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist)
+            else:
+                # a pair of blocks holds 2 x 32 columns: wider problems go chunk by chunk (the sweeps take 32 columns at
+                # a time anyway, and the low modes, which finish first, share a chunk)
+                upd = prob.ctx.zeros(Rc.n, k)
+                conv, inf, ok = np.zeros(k, dtype=bool), [None] * k, True
+                for a in range(0, k, 32):
+                    b = min(k, a + 32)
+                    ua, ca, ia, oka = _sibk_round_pair(prob, Rc.cols(a, b), lam_p[a:b], sigma, rnorm0, rtol, atol, maxiter,
+                                                       sub_hist[a:b])
+                    upd.cols(a, b).copy_from(ua)
+                    conv[a:b] = ca
+                    inf[a:b] = ia
+                    ok = ok and oka
+                    if not ok:
+                        break
+            if ok:
+                return upd, conv, inf
+            for hh, h0 in zip(sub_hist, keep):            # (a pair lost orthogonality: the one-step form decides)
+                hh[:] = h0
         return _sibk_round(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist)
     import threading
 

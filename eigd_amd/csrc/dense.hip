@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kThreads) void coldot_kernel(int n, int k, const do
 template <int KP, int JB>
 __global__ __launch_bounds__(kThreads) void stack_dot_kernel(int n, int k, int nj, const double* __restrict__ S,
                                                             int64_t slab, int lds, const double* __restrict__ T,
-                                                            int ldt, double* __restrict__ partial) {
+                                                            int ldt, double* __restrict__ partial, int kslab) {
   constexpr int RP = kThreads / KP;
   __shared__ double red[kThreads];
   const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
@@ -78,7 +78,9 @@ __global__ __launch_bounds__(kThreads) void stack_dot_kernel(int n, int k, int n
   if (c < k)
     for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
       const double t = T[r * ldt + c];
-      const unsigned off = static_cast<unsigned>(r * lds + c);  // uniform slab base + 32-bit lane offset (n * lds < 2^31)
+      // uniform slab base + 32-bit lane offset (n * lds < 2^31); kslab < k: T is a pair of blocks [T1 | T2] that both meet
+      // the slabs' columns 0..kslab-1 (column c of T pairs with slab column c - kslab past the first block)
+      const unsigned off = static_cast<unsigned>(r * lds + (c >= kslab ? c - kslab : c));
       double sv[JB];
 #pragma unroll
       for (int j = 0; j < JB; ++j) sv[j] = (j < nj) ? (S + j * slab)[off] : 0.0;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void stack_dot_kernel(int n, int k, int n
 template <int KP>
 __global__ __launch_bounds__(kThreads) void stack_axpy_kernel(int n, int k, int ns, const double* __restrict__ S,
                                                              int64_t slab, int lds, const double* __restrict__ H,
-                                                             double* __restrict__ T, int ldt, double alpha) {
+                                                             double* __restrict__ T, int ldt, double alpha, int kslab) {
   constexpr int RP = kThreads / KP;
   extern __shared__ double Hs[];  // ns * k
   for (int q = threadIdx.x; q < ns * k; q += kThreads) Hs[q] = H[q];
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void stack_axpy_kernel(int n, int k, int 
   const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
   if (c >= k) return;
   for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
-    const double* sp = S + r * lds + c;
+    const double* sp = S + r * lds + (c >= kslab ? c - kslab : c);
     double s = 0.0;
     int j = 0;
     for (; j + 8 <= ns; j += 8) {
@@ -138,7 +140,7 @@ template <int KP, int JMAX>
 __global__ __launch_bounds__(kThreads) void stack_axpy_dot_kernel(int n, int k, int ns, const double* __restrict__ S,
                                                                  int64_t slab, int lds, const double* __restrict__ H1,
                                                                  double* __restrict__ T, int ldt, double alpha,
-                                                                 double* __restrict__ partial) {
+                                                                 double* __restrict__ partial, int kslab) {
   constexpr int RP = kThreads / KP;
   extern __shared__ double Hs[];  // ns * k
   __shared__ double red[kThreads];
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(kThreads) void stack_axpy_dot_kernel(int n, int k, 
     for (int j = 0; j < JMAX; ++j) hc[j] = (j < ns) ? alpha * Hs[j * k + c] : 0.0;
     for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
       // uniform slab base + one 32-bit lane offset (the host checks n * lds < 2^31): no 64-bit address per slab in VGPRs
-      const unsigned off = static_cast<unsigned>(r * lds + c);
+      const unsigned off = static_cast<unsigned>(r * lds + (c >= kslab ? c - kslab : c));
       double sv[JMAX];
 #pragma unroll
       for (int j = 0; j < JMAX; ++j) sv[j] = (j < ns) ? (S + j * slab)[off] : 0.0;
@@ -222,6 +224,47 @@ __global__ __launch_bounds__(kThreads) void scale_inv_norm_kernel(int n, int k, 
   const double sc = (m.skip[c] != 0 || n2 == 0.0) ? 0.0 : 1.0 / sqrt(n2);
   for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP)
     out[r * ldo + c] = sc * x[r * ldx + c];
+}
+
+// Two-step Krylov cycle, the pair [T1 | T2] after its Gram-Schmidt step against the stack and the projection:
+//   W1 = T1 / |T1|,   T2 <- T2 - (T1.T2 / |T1|^2) T1   (in place),
+// and per column the partial sums of |T2|^2 (new) and of W1 . T2 (new; what one Gram-Schmidt pass inside the pair left).
+// |T1|^2 (norm2[c]) and T1.T2 (gamma[c]) live on the device: no host synchronisation between the passes.
+template <int KP>
+__global__ __launch_bounds__(kThreads) void pair_apply_kernel(int n, int k, double* __restrict__ T, int ldt,
+                                                             const double* __restrict__ norm2,
+                                                             const double* __restrict__ gamma, double* __restrict__ W1,
+                                                             int ldw1, SkipMask m, double* __restrict__ partial) {
+  constexpr int RP = kThreads / KP;
+  __shared__ double red[kThreads];
+  const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
+  double s2 = 0.0, sd = 0.0;
+  if (c < k) {
+    const double n1 = norm2[c];
+    const bool dead = m.skip[c] != 0 || n1 == 0.0;
+    const double inv = dead ? 0.0 : 1.0 / sqrt(n1);
+    const double coef = dead ? 0.0 : gamma[c] / n1;
+    for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
+      const double t1 = T[r * ldt + c];
+      const double t2 = T[r * ldt + k + c];
+      const double w1 = inv * t1;
+      const double t2n = dead ? 0.0 : t2 - coef * t1;
+      W1[r * ldw1 + c] = w1;
+      T[r * ldt + k + c] = t2n;
+      s2 += t2n * t2n;
+      sd += w1 * t2n;
+    }
+  }
+  for (int q = 0; q < 2; ++q) {
+    red[threadIdx.x] = (q == 0) ? s2 : sd;
+    __syncthreads();
+    if (rr == 0 && c < k) {
+      double t = 0.0;
+      for (int z = 0; z < RP; ++z) t += red[z * KP + c];
+      partial[(static_cast<int64_t>(blockIdx.x) * 2 + q) * k + c] = t;
+    }
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -735,6 +778,7 @@ int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_
                    slab >= static_cast<int64_t>(n - 1) * lds + k && static_cast<int64_t>(n) * lds < (int64_t(1) << 31),
                "bad shape n=%d k=%d ns=%d (a slab must hold fewer than 2^31 doubles)", n, k, ns);
   constexpr int JB = 16;
+  const int kslab = k;
   const int kp = next_pow2(k);
   const int nb = grid_for_rows(n, (kThreads / kp) * 8);
   int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) * JB * k + static_cast<size_t>(ns) * k));
@@ -745,7 +789,7 @@ int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_
     const int nj = std::min(JB, ns - j0);
     rc = dispatch_kp(k, [&](auto KP) {
       hipLaunchKernelGGL((stack_dot_kernel<decltype(KP)::value, JB>), dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, nj,
-                         dS + j0 * slab, slab, lds, dT, ldt, partial);
+                         dS + j0 * slab, slab, lds, dT, ldt, partial, kslab);
     });
     if (rc) return rc;
     EIGD_LAUNCH_CHECK();
@@ -758,7 +802,7 @@ int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_
 }
 
 static int stack_dot_device(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* dT,
-                            int ldt, double** dres) {
+                            int ldt, double** dres, int kslab) {
   constexpr int JB = 16;
   const int kp = next_pow2(k);
   const int nb = grid_for_rows(n, (kThreads / kp) * 8);
@@ -770,7 +814,7 @@ static int stack_dot_device(eigd_ctx* ctx, int n, int k, int ns, const double* d
     const int nj = std::min(JB, ns - j0);
     rc = dispatch_kp(k, [&](auto KP) {
       hipLaunchKernelGGL((stack_dot_kernel<decltype(KP)::value, JB>), dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, nj,
-                         dS + j0 * slab, slab, lds, dT, ldt, partial);
+                         dS + j0 * slab, slab, lds, dT, ldt, partial, kslab);
     });
     if (rc) return rc;
     EIGD_LAUNCH_CHECK();
@@ -782,12 +826,12 @@ static int stack_dot_device(eigd_ctx* ctx, int n, int k, int ns, const double* d
 }
 
 static int stack_axpy_device(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* dH,
-                             double* dT, int ldt, double alpha) {
+                             double* dT, int ldt, double alpha, int kslab) {
   const int kp = next_pow2(k);
   const int nb = grid_for_rows(n, (kThreads / kp) * 8);
   int rc = dispatch_kp(k, [&](auto KP) {
     hipLaunchKernelGGL(stack_axpy_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), sizeof(double) * ns * k,
-                       ctx->stream, n, k, ns, dS, slab, lds, dH, dT, ldt, alpha);
+                       ctx->stream, n, k, ns, dS, slab, lds, dH, dT, ldt, alpha, kslab);
   });
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();
@@ -795,7 +839,7 @@ static int stack_axpy_device(eigd_ctx* ctx, int n, int k, int ns, const double* 
 }
 
 static int stack_axpy_dot_device(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds,
-                                 const double* dH1, double* dT, int ldt, double alpha, double** dres) {
+                                 const double* dH1, double* dT, int ldt, double alpha, double** dres, int kslab) {
   const int kp = next_pow2(k);
   const int nb = grid_for_rows(n, (kThreads / kp) * 8);
   int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) + 1) * ns * k);
@@ -807,13 +851,13 @@ static int stack_axpy_dot_device(eigd_ctx* ctx, int n, int k, int ns, const doub
     constexpr int kpv = decltype(KP)::value;
     if (ns <= 8)
       hipLaunchKernelGGL((stack_axpy_dot_kernel<kpv, 8>), dim3(nb), dim3(kThreads), shm, ctx->stream, n, k, ns, dS, slab,
-                         lds, dH1, dT, ldt, alpha, partial);
+                         lds, dH1, dT, ldt, alpha, partial, kslab);
     else if (ns <= 16)
       hipLaunchKernelGGL((stack_axpy_dot_kernel<kpv, 16>), dim3(nb), dim3(kThreads), shm, ctx->stream, n, k, ns, dS, slab,
-                         lds, dH1, dT, ldt, alpha, partial);
+                         lds, dH1, dT, ldt, alpha, partial, kslab);
     else
       hipLaunchKernelGGL((stack_axpy_dot_kernel<kpv, 32>), dim3(nb), dim3(kThreads), shm, ctx->stream, n, k, ns, dS, slab,
-                         lds, dH1, dT, ldt, alpha, partial);
+                         lds, dH1, dT, ldt, alpha, partial, kslab);
   });
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();
@@ -823,11 +867,11 @@ static int stack_axpy_dot_device(eigd_ctx* ctx, int n, int k, int ns, const doub
   return EIGD_OK;
 }
 
-int eigd_stack_cgs2(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, double* dT, int ldt,
-                    double tol, double* hH, int* hpasses) {
+static int stack_cgs2_impl(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, double* dT, int ldt,
+                           double tol, double* hH, int* hpasses, int kslab) {
   EIGD_REQUIRE(ctx && dS && dT && hH, "null argument");
-  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && lds >= k &&
-                   slab >= static_cast<int64_t>(n - 1) * lds + k && static_cast<int64_t>(n) * lds < (int64_t(1) << 31),
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && lds >= kslab &&
+                   slab >= static_cast<int64_t>(n - 1) * lds + kslab && static_cast<int64_t>(n) * lds < (int64_t(1) << 31),
                "bad shape n=%d k=%d ns=%d (a slab must hold fewer than 2^31 doubles)", n, k, ns);
   EIGD_REQUIRE(static_cast<size_t>(ns) * k * sizeof(double) <= 60 * 1024, "stack too deep for one pass: ns*k=%d", ns * k);
   const size_t nh = static_cast<size_t>(ns) * k;
@@ -835,12 +879,12 @@ int eigd_stack_cgs2(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
   if (rc) return rc;
   double* res = nullptr;
   // pass 1: h1 = S^T T.  It stays on the device for pass 2; the host sees it together with h2.
-  rc = stack_dot_device(ctx, n, k, ns, dS, slab, lds, dT, ldt, &res);
+  rc = stack_dot_device(ctx, n, k, ns, dS, slab, lds, dT, ldt, &res, kslab);
   if (rc) return rc;
   EIGD_HIP(hipMemcpyAsync(ctx->coef, res, sizeof(double) * nh, hipMemcpyDeviceToDevice, ctx->stream));
   int passes = 2;
   if (ns <= 32) {  // pass 2, fused: T -= S h1 and h2 = S^T T in one pass over the stack
-    rc = stack_axpy_dot_device(ctx, n, k, ns, dS, slab, lds, ctx->coef, dT, ldt, -1.0, &res);
+    rc = stack_axpy_dot_device(ctx, n, k, ns, dS, slab, lds, ctx->coef, dT, ldt, -1.0, &res, kslab);
     if (rc) return rc;
   } else {
     // more than 32 slabs: subtract the tail slabs' part first, then the fused pass over the first 32 (T is final
@@ -848,12 +892,12 @@ int eigd_stack_cgs2(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
     // first 32 slabs once
     const int nb = ns - 32;
     const size_t na_k = static_cast<size_t>(32) * k;
-    rc = stack_axpy_device(ctx, n, k, nb, dS + 32 * slab, slab, lds, ctx->coef + na_k, dT, ldt, -1.0);
+    rc = stack_axpy_device(ctx, n, k, nb, dS + 32 * slab, slab, lds, ctx->coef + na_k, dT, ldt, -1.0, kslab);
     if (rc) return rc;
-    rc = stack_axpy_dot_device(ctx, n, k, 32, dS, slab, lds, ctx->coef, dT, ldt, -1.0, &res);
+    rc = stack_axpy_dot_device(ctx, n, k, 32, dS, slab, lds, ctx->coef, dT, ldt, -1.0, &res, kslab);
     if (rc) return rc;
     EIGD_HIP(hipMemcpyAsync(ctx->coef + nh, res, sizeof(double) * na_k, hipMemcpyDeviceToDevice, ctx->stream));
-    rc = stack_dot_device(ctx, n, k, nb, dS + 32 * slab, slab, lds, dT, ldt, &res);
+    rc = stack_dot_device(ctx, n, k, nb, dS + 32 * slab, slab, lds, dT, ldt, &res, kslab);
     if (rc) return rc;
     EIGD_HIP(hipMemcpyAsync(ctx->coef + nh + na_k, res, sizeof(double) * nb * k, hipMemcpyDeviceToDevice, ctx->stream));
     res = ctx->coef + nh;  // h2 assembled in place
@@ -888,7 +932,7 @@ int eigd_stack_cgs2(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
     if (std::sqrt(n2) > tol * std::sqrt(n1)) again = true;
   }
   if (again) {
-    rc = stack_axpy_device(ctx, n, k, ns, dS, slab, lds, ctx->coef + nh, dT, ldt, -1.0);
+    rc = stack_axpy_device(ctx, n, k, ns, dS, slab, lds, ctx->coef + nh, dT, ldt, -1.0, kslab);
     if (rc) return rc;
     for (size_t q = 0; q < nh; ++q) h1[q] += h2[q];
     passes += 1;
@@ -896,6 +940,17 @@ int eigd_stack_cgs2(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
   std::memcpy(hH, h1, sizeof(double) * nh);
   if (hpasses) *hpasses = passes;
   return EIGD_OK;
+}
+
+int eigd_stack_cgs2(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, double* dT, int ldt,
+                    double tol, double* hH, int* hpasses) {
+  return stack_cgs2_impl(ctx, n, k, ns, dS, slab, lds, dT, ldt, tol, hH, hpasses, k);
+}
+
+int eigd_stack_cgs2_pair(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, double* dT, int ldt,
+                         double tol, double* hH, int* hpasses) {
+  EIGD_REQUIRE(k >= 1 && 2 * k <= kMaxK, "a pair of blocks holds at most %d columns each", kMaxK / 2);
+  return stack_cgs2_impl(ctx, n, 2 * k, ns, dS, slab, lds, dT, ldt, tol, hH, hpasses, k);
 }
 
 int eigd_colnorm2_dev(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, double* dOut) {
@@ -955,6 +1010,40 @@ int eigd_scale_inv_norm(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, 
   return EIGD_OK;
 }
 
+int eigd_pair_orthonormalise(eigd_ctx* ctx, int n, int k, double* dT, int ldt, const double* dNorm2, double* dW1, int ldw1,
+                             double* dW2, int ldw2, const unsigned char* hskip, double* dOut) {
+  EIGD_REQUIRE(ctx && dT && dNorm2 && dW1 && dW2 && dOut, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && 4 * k <= 2 * kMaxK && ldt >= 2 * k && ldw1 >= k && ldw2 >= k, "bad shape n=%d k=%d", n, k);
+  SkipMask m;
+  for (int c = 0; c < kMaxK; ++c) m.skip[c] = (hskip && c < k) ? hskip[c] : 0;
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 8);
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) + 1) * 2 * k);
+  if (rc) return rc;
+  double* partial = ctx->scratch + 2 * k;
+  // dOut = [ |T1|^2 (k) | T1.T2 (k) | |T2 new|^2 (k) | W1.T2 new (k) ]
+  EIGD_HIP(hipMemcpyAsync(dOut, dNorm2, sizeof(double) * k, hipMemcpyDeviceToDevice, ctx->stream));
+  rc = dispatch_kp(k, [&](auto KP) {
+    hipLaunchKernelGGL(coldot_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dT, ldt, dT + k,
+                       ldt, partial);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  rc = reduce_to_host(ctx, partial, nb, k, dOut + k, nullptr);
+  if (rc) return rc;
+  rc = dispatch_kp(k, [&](auto KP) {
+    hipLaunchKernelGGL(pair_apply_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dT, ldt, dOut,
+                       dOut + k, dW1, ldw1, m, partial);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  rc = reduce_to_host(ctx, partial, nb, 2 * k, dOut + 2 * k, nullptr);
+  if (rc) return rc;
+  rc = eigd_scale_inv_norm(ctx, n, k, dT + k, ldt, dW2, ldw2, dOut + 2 * k, hskip);
+  if (rc) return rc;
+  return publish_norm2(ctx, dOut, 4 * k);
+}
+
 int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* hH,
                     double* dT, int ldt, double alpha) {
   EIGD_REQUIRE(ctx && dS && dT && hH, "null argument");
@@ -970,7 +1059,7 @@ int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
   const int nb = grid_for_rows(n, (kThreads / kp) * 4);
   rc = dispatch_kp(k, [&](auto KP) {
     hipLaunchKernelGGL(stack_axpy_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), sizeof(double) * ns * k,
-                       ctx->stream, n, k, ns, dS, slab, lds, ctx->coef, dT, ldt, alpha);
+                       ctx->stream, n, k, ns, dS, slab, lds, ctx->coef, dT, ldt, alpha, k);
   });
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();
@@ -998,13 +1087,13 @@ int eigd_stack_axpy_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, i
     constexpr int kpv = decltype(KP)::value;
     if (ns <= 8)
       hipLaunchKernelGGL((stack_axpy_dot_kernel<kpv, 8>), dim3(nb), dim3(kThreads), shm, ctx->stream, n, k, ns, dS, slab,
-                         lds, ctx->coef, dT, ldt, alpha, partial);
+                         lds, ctx->coef, dT, ldt, alpha, partial, k);
     else if (ns <= 16)
       hipLaunchKernelGGL((stack_axpy_dot_kernel<kpv, 16>), dim3(nb), dim3(kThreads), shm, ctx->stream, n, k, ns, dS, slab,
-                         lds, ctx->coef, dT, ldt, alpha, partial);
+                         lds, ctx->coef, dT, ldt, alpha, partial, k);
     else
       hipLaunchKernelGGL((stack_axpy_dot_kernel<kpv, 32>), dim3(nb), dim3(kThreads), shm, ctx->stream, n, k, ns, dS, slab,
-                         lds, ctx->coef, dT, ldt, alpha, partial);
+                         lds, ctx->coef, dT, ldt, alpha, partial, k);
   });
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();

@@ -283,6 +283,20 @@ class DeviceBlock:
         call("eigd_scale_inv_norm", self.ctx.h, self.n, self.k, src.ptr, src.ld, self.ptr, self.ld, norm2_dev.ptr, hptr(mask))
         return self
 
+    def pair_orthonormalise(self, norm2_dev, W1, W2, skip):
+        """
+        self = [T1 | T2] (n x 2k): W1 = T1/|T1|, T2 <- T2 - (T1.T2/|T1|^2) T1 (in place), W2 = T2/|T2|, all on the device.
+        norm2_dev: the 2k squared column norms of self (project_norm2).  Returns the device block
+        [|T1|^2 | T1.T2 | |T2|^2 | W1.T2] (4k); ctx.fetch_colnorm2(4k) collects its host copy.
+        """
+        k = W1.k
+        assert self.k == 2 * k and W2.k == k and 4 * k <= 128
+        mask = np.ascontiguousarray(np.asarray(skip, dtype=bool)[:k], dtype=np.uint8)
+        out = self.ctx.empty(1, 4 * k)
+        call("eigd_pair_orthonormalise", self.ctx.h, self.n, k, self.ptr, self.ld, norm2_dev.ptr, W1.ptr, W1.ld, W2.ptr,
+             W2.ld, hptr(mask), out.ptr)
+        return out
+
     def tdot(self, X):
         """self^T X  -> host (self.k x X.k)"""
         out = np.empty((self.k, X.k))
@@ -408,6 +422,16 @@ class DeviceStack:
         H = np.empty((ns, T.k))
         passes = C.c_int(0)
         call("eigd_stack_cgs2", self.ctx.h, self.n, T.k, ns, c_vp(self.buf.ptr + 8 * c0), self.slab, self.k, T.ptr, T.ld,
+             float(tol), hptr(H), C.byref(passes))
+        return H, passes.value
+
+    def cgs2_pair(self, T, ns, c0=0, tol=1e-13):
+        """Gram-Schmidt step of the pair T = [T1 | T2] (n x 2k) against columns c0..c0+k-1 of slabs [0, ns): both blocks in
+        the same two passes over the stack.  Returns (coefficients ns x 2k, passes)"""
+        k = T.k // 2
+        H = np.empty((ns, T.k))
+        passes = C.c_int(0)
+        call("eigd_stack_cgs2_pair", self.ctx.h, self.n, k, ns, c_vp(self.buf.ptr + 8 * c0), self.slab, self.k, T.ptr, T.ld,
              float(tol), hptr(H), C.byref(passes))
         return H, passes.value
 

@@ -176,6 +176,16 @@ int eigd_stack_axpy_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, i
  * One host synchronisation instead of one per pass. */
 int eigd_stack_cgs2(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, double* dT, int ldt,
                     double tol, double* hH, int* hpasses);
+/* Two Krylov steps per Gram-Schmidt pass (the loops of 1254-1260 for the vectors of steps j+1 and j+2 together): dT
+ * holds the pair [T1 | T2] (n x 2k, T2 = OP T1 before either is orthogonalised), both blocks meet columns 0..k-1 of the
+ * slabs in the same two passes over the stack; hH is ns x 2k.  eigd_pair_orthonormalise finishes the pair on the
+ * device: W1 = T1/|T1|, T2 <- T2 - (T1.T2/|T1|^2) T1, W2 = T2/|T2|; dNorm2 = the 2k squared column norms that
+ * eigd_project_norm2 left on the device; dOut (device, 4k) = [|T1|^2 | T1.T2 | |T2|^2 | W1.T2] with a pinned copy for
+ * eigd_colnorm2_fetch(ctx, hout, 4k); columns with hskip[c] != 0 become zero */
+int eigd_stack_cgs2_pair(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, double* dT, int ldt,
+                         double tol, double* hH, int* hpasses);
+int eigd_pair_orthonormalise(eigd_ctx* ctx, int n, int k, double* dT, int ldt, const double* dNorm2, double* dW1, int ldw1,
+                             double* dW2, int ldw2, const unsigned char* hskip, double* dOut);
 /* squared column norms into device memory (no host synchronisation) and the normalisation that consumes them:
  * Out[:, c] = X[:, c] / sqrt(dNorm2[c]), zero where hskip[c] != 0 or the norm is zero (1259-1260, 1233-1234) */
 int eigd_colnorm2_dev(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, double* dOut);
