@@ -650,6 +650,13 @@ def _sstep_default():
     return int(os.environ.get("EIGD_SSTEP", "2"))
 
 
+def _pair_defect_tol():
+    import os
+
+    # w_{j+1} . w_{j+2} above which a two-step solve is abandoned for the one-step form (a test sets it to -1)
+    return float(os.environ.get("EIGD_SSTEP_DEFECT_TOL", "1e-10"))
+
+
 def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     """
     The lock-step solver with TWO Krylov steps per Gram-Schmidt pass.  Same Krylov spaces, same Hessenberg matrices
@@ -734,7 +741,7 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
             steps = (j + 1, j + 2)
             if b1 > 0.0:
                 b2 = np.sqrt(n2sq[q])
-                if abs(defect[q]) > 1e-10 * max(b2, np.finfo(float).tiny):
+                if abs(defect[q]) > _pair_defect_tol() * max(b2, np.finfo(float).tiny):
                     ok = False                            # (never seen: the pair was not orthogonalised well enough)
                 colv = np.zeros(ns + 2)
                 colv[:ns] = g1

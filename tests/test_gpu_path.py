@@ -933,3 +933,58 @@ def test_column_compaction_of_the_krylov_stacks_changes_no_column():
     assert len(out[True][2]) == len(out[False][2]) and np.allclose(out[True][2], out[False][2], rtol=1e-6, atol=1e-14)
     assert out[True][3] == out[False][3]
     assert relerr(out[True][0], g["normal_sibk_psi"]) < 1e-8
+
+
+@pytest.mark.parametrize("mode", ["buckling", "normal"])
+def test_two_krylov_steps_per_gram_schmidt_pass_match_the_one_step_solver(monkeypatch, mode):
+    """
+    The lock-step sibk with two operator applications per Gram-Schmidt pass (EIGD_SSTEP=2, the default) against the
+    one-step form (the reference's loop order, eigenvector_derivatives.py:1246-1260): same iteration count for every
+    mode, same residual histories, psi equal far below the 1e-8 of north_star -- odd and even stopping steps, modes that
+    are converged before the first step, a maxiter that cuts a cycle in two, more than 32 modes (chunks), and the
+    fall-back to the one-step form when the orthogonality measured inside a pair is not accepted.
+    """
+    import eigd_amd as eg
+    from eigd_amd.device import default_context
+    from eigd_amd.problems import BucklingColumn, ThermalPlate
+
+    ctx = default_context()
+    rng = np.random.default_rng(7)
+    if mode == "buckling":
+        col = BucklingColumn(90, 90, seed=2)
+        K = col.stiffness()
+        u = col.full_vector(eg.SpLuOperator(K, ctx=ctx, check_symmetry=False)(col.f[col.reduced]))
+        A, B, sigma, N = col.geometric_stiffness(u), K, 1.0, 40
+    else:
+        pl = ThermalPlate(90, epsilon=1e-7)                    # nearly repeated pairs: index sets with partners
+        A, B, sigma, N = pl.stiffness(), pl.mass(), -0.1, 12
+    n = B.shape[0]
+    P = (B + sigma * A) if mode == "buckling" else (A - sigma * B)
+    fac = eg.SpLuOperator(P.tocsr(), ctx=ctx, check_symmetry=False)
+    s = eg.IRAM(N=N, m=2 * N + 1, mode=mode, ctx=ctx)
+    lam, Phi = s.solve(A, B, fac, sigma)
+    Phib = rng.uniform(-1, 1, size=(n, N))
+    Phib[:, 3] = 0.0                                           # a right-hand side that needs no Krylov step at all
+    runs = {}
+    for name, env in (("one", {"EIGD_SSTEP": "1"}), ("two", {"EIGD_SSTEP": "2"}),
+                      ("fallback", {"EIGD_SSTEP": "2", "EIGD_SSTEP_DEFECT_TOL": "-1"})):
+        for kname, v in env.items():
+            monkeypatch.setenv(kname, v)
+        hist = []
+        psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, callback=hist.append)
+        runs[name] = (psi, data, list(s.last_info), hist)
+        monkeypatch.delenv("EIGD_SSTEP_DEFECT_TOL", raising=False)
+    psi1, data1, info1, hist1 = runs["one"]
+    psi2, data2, info2, hist2 = runs["two"]
+    assert info2 == info1 and len(set(i % 2 for i in info1 if i)) == 2          # odd and even stopping steps
+    assert len(hist2) == len(hist1) and np.allclose(hist2, hist1, rtol=1e-6, atol=1e-300)
+    assert relerr(psi2, psi1) < 1e-11
+    assert index_sets(data2) == index_sets(data1)
+    psi3, _, info3, _ = runs["fallback"]
+    assert info3 == info1 and np.array_equal(psi3, psi1)                       # the one-step form took over
+    # a maxiter inside a cycle: both forms keep the same best iterates
+    monkeypatch.setenv("EIGD_SSTEP", "1")
+    pa, _ = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, maxiter=7, nrestart=0)
+    monkeypatch.setenv("EIGD_SSTEP", "2")
+    pb, _ = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, maxiter=7, nrestart=0)
+    assert relerr(pb, pa) < 1e-10
