@@ -771,10 +771,11 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
                     done[c] = True
                     break
 
-    lo, hi = _active_range(done)
+    rng = _active_range(done)
     j = 0
-    enqueue_cycle(0, lo, hi)
+    enqueue_cycle(0, *rng)
     while True:
+        lo, hi = rng                                      # a cycle keeps the column range it was launched with
         kk = hi - lo
         TPv = TP.cols(0, 2 * kk)
         h, _ = W.cgs2_pair(TPv, j + 1, c0=lo, tol=_REORTH_TOL)      # ref 1254-1256 for both vectors; one host sync
@@ -782,22 +783,17 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
         TPv.pair_orthonormalise(n2, W[j + 1].cols(lo, hi), W[j + 2].cols(lo, hi), done[lo:hi])   # ref 1260
         more = j + 2 < maxiter
         if more:
-            enqueue_cycle(j + 2, lo, hi)                  # the next cycle is in flight while the host solves this one
+            # the next cycle is in flight while the host solves this one; it runs on the columns that were unfinished
+            # after the cycle before (a mode that finishes now rides along once more with zero coefficients)
+            nrng = _active_range(done)
+            enqueue_cycle(j + 2, *nrng)
         vals = ctx.fetch_colnorm2(4 * kk)
         small_solves(j, lo, hi, h, vals)
         jlast = min(j + 2, maxiter)
         if done.all() or not more or not ok:
             break
         j += 2
-        nlo, nhi = _active_range(done)
-        if (nlo, nhi) != (lo, hi):
-            # the cycle in flight was launched on the old range: move its pair to the layout of the new one
-            nk = nhi - nlo
-            T1n = ctx.empty(n, nk).copy_from(TP.cols(nlo - lo, nlo - lo + nk))
-            T2n = ctx.empty(n, nk).copy_from(TP.cols(kk + nlo - lo, kk + nlo - lo + nk))
-            TP.cols(0, nk).copy_from(T1n)
-            TP.cols(nk, 2 * nk).copy_from(T2n)
-            lo, hi = nlo, nhi
+        rng = nrng
     if prob.fac.native:                                   # one factor application per Krylov step and mode (ref 1248)
         with prob.fac.factor._count_lock:
             prob.fac.factor.count += int(sum((i if i is not None else maxiter) for i in info))
