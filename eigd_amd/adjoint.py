@@ -456,10 +456,26 @@ def laa(Phib, B, factor, sigma, lam, V, Y, theta, indices, D0=None, b_ortho=Fals
 # shift-invert block Krylov, lock-step batched form (ref 1052-1328)
 # ---------------------------------------------------------------------------
 def solve_shifted_lstsq(alpha, H, r):
-    """min || (I - alpha H) y - r ||  (ref 1043-1049)"""
-    H0 = np.eye(H.shape[0], H.shape[1]) - alpha * H
+    """
+    min || (I - alpha H) y - r ||  (ref 1043-1049: numpy's lstsq there).  Householder QR instead of lstsq's SVD: the
+    same minimiser to rounding for the full-rank Hessenberg systems of the Krylov loops at a fifth of the host time
+    (the lock-step solver does two of these per mode and cycle while the next cycle's sweeps are in flight; with the SVD
+    the host was the slower side of that overlap in a quarter of the cycles).  Rank-deficient systems (an exhausted
+    Krylov space) go to lstsq as in the reference.
+    """
+    m, n = H.shape
+    H0 = -alpha * H
+    H0[np.arange(min(m, n)), np.arange(min(m, n))] += 1.0
+    if n > 0 and m >= n:
+        qr, x, info = _dgels(H0, r)                       # one LAPACK call: QR, Q^T r, back substitution
+        d = np.abs(qr.diagonal())
+        if info == 0 and d.min() > 1e-13 * d.max():
+            return x[:n], float(np.linalg.norm(x[n:]))    # (the tail of Q^T r is the residual of the minimiser)
     y = np.linalg.lstsq(H0, r, rcond=None)[0]
     return y, np.linalg.norm(H0 @ y - r)
+
+
+from scipy.linalg.lapack import dgels as _dgels  # noqa: E402
 
 
 _REORTH_TOL = 1e-13
