@@ -573,6 +573,7 @@ def main():
         "accuracy": accuracy,
         "preamble_s": {k: round(v, 3) for k, v in timing.items()},
         "factor_sweeps_per_step": int(adj_count),
+        "sibk_iterations": [int(i) for i in solver.last_info],
         "eigensolve_sweeps": int(eig_count),
     }
     print(json.dumps(out), flush=True)
