@@ -658,6 +658,9 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist, compa
     return dpsi, converged, info
 
 
+LAST_ROUND = {"steps_per_pass": None}   # what the last lock-step round of the two-step solver ran with (tests)
+
+
 def _sstep_default():
     import os
 
@@ -818,6 +821,8 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
         upd = ctx.zeros(n, k)
         Z.axpy_into(upd, Ycoef[:jlast], alpha=1.0)       # ref 1277 / 1313: psi += Z y
         dpsi.copy_from(upd)
+    if ok:
+        LAST_ROUND["steps_per_pass"] = 2
     return dpsi, converged, info, ok
 
 
@@ -860,6 +865,7 @@ def _run_groups(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist, s
                 return upd, conv, inf
             for hh, h0 in zip(sub_hist, keep):            # (a pair lost orthogonality: the one-step form decides)
                 hh[:] = h0
+        LAST_ROUND["steps_per_pass"] = 1
         return _sibk_round(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist)
     import threading
 

@@ -975,6 +975,9 @@ def test_two_krylov_steps_per_gram_schmidt_pass_match_the_one_step_solver(monkey
         hist = []
         psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, callback=hist.append)
         runs[name] = (psi, data, list(s.last_info), hist)
+        from eigd_amd import adjoint as _adj
+
+        assert _adj.LAST_ROUND["steps_per_pass"] == (2 if name == "two" else 1), name   # the form asked for (or the fall-back) ran
         monkeypatch.delenv("EIGD_SSTEP_DEFECT_TOL", raising=False)
     psi1, data1, info1, hist1 = runs["one"]
     psi2, data2, info2, hist2 = runs["two"]
