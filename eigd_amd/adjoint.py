@@ -669,6 +669,34 @@ def _sstep_default():
     return int(os.environ.get("EIGD_SSTEP", "2"))
 
 
+def pair_arnoldi_columns(Hc, Czc, j, h1, g1, b1, gamma, b2):
+    """
+    Host algebra of one two-step cycle for one mode (see _sibk_round_pair).  Given the Gram-Schmidt coefficients of the
+    raw pair against W_0..W_j (v1 = OP w_j: h1, v2 = OP v1: g1) and what the orthonormalisation inside the pair measured
+    (b1 = |v1'|, gamma = v1'.v2', b2 = |v2' - (w_{j+1}.v2') w_{j+1}|), fills
+      * columns j and j+1 of the Arnoldi matrix Hc (OP W = W H):  H[:, j] = [h1; b1],
+        H[:, j+1] = ([g1; gamma/b1; b2] - H[:, :j+1] h1) / b1;
+      * columns j and j+1 of Czc, the coordinates of factor(w_i) in the STORED slabs (slab j = factor(w_j),
+        slab j+1 = factor(v1)):  factor(w_{j+1}) = (slab_{j+1} - sum_i h1[i] factor(w_i)) / b1.
+    b1 == 0 (the Krylov space is exhausted): only column j is filled.
+    """
+    ns = j + 1
+    Hc[:ns, j] = h1
+    Hc[ns, j] = b1
+    Czc[j, j] = 1.0
+    if not b1 > 0.0:
+        return
+    colv = np.zeros(ns + 2)
+    colv[:ns] = g1
+    colv[ns] = gamma / b1
+    colv[ns + 1] = b2
+    colv[: ns + 1] -= Hc[: ns + 1, :ns] @ h1
+    Hc[: ns + 2, j + 1] = colv / b1
+    Czc[:, j + 1] = 0.0
+    Czc[j + 1, j + 1] = 1.0 / b1
+    Czc[:ns, j + 1] -= (Czc[:ns, :ns] @ h1) / b1
+
+
 def _pair_defect_tol():
     import os
 
@@ -752,27 +780,14 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
             if done[c]:
                 continue
             Hc, Czc = H[c], Cz[c]
-            h1, g1 = h[:, q], h[:, kk + q]
-            b1 = np.sqrt(n1sq[q])
-            Hc[:ns, j] = h1
-            Hc[ns, j] = b1
-            Czc[j, j] = 1.0                               # slab j holds factor(w_j) itself
+            b1, b2 = np.sqrt(n1sq[q]), np.sqrt(n2sq[q])
             steps = (j + 1, j + 2)
             if b1 > 0.0:
-                b2 = np.sqrt(n2sq[q])
                 if abs(defect[q]) > _pair_defect_tol() * max(b2, np.finfo(float).tiny):
                     ok = False                            # (never seen: the pair was not orthogonalised well enough)
-                colv = np.zeros(ns + 2)
-                colv[:ns] = g1
-                colv[ns] = gam[q] / b1
-                colv[ns + 1] = b2
-                colv[: ns + 1] -= Hc[: ns + 1, :ns] @ h1
-                Hc[: ns + 2, j + 1] = colv / b1
-                Czc[:, j + 1] = 0.0
-                Czc[j + 1, j + 1] = 1.0 / b1
-                Czc[:ns, j + 1] -= (Czc[:ns, :ns] @ h1) / b1
             else:
                 steps = (j + 1,)                          # breakdown: the Krylov space is exhausted at step j+1
+            pair_arnoldi_columns(Hc, Czc, j, h[:, q], h[:, kk + q], b1, gam[q], b2)
             for jj in steps:
                 if jj > maxiter:
                     break
