@@ -60,33 +60,89 @@ def estimate_first_buckling_load(ctx, dK, dG, Kfac, n, iters=40):
     return 1.0 / mu
 
 
-def launch_ranks(nranks):
+def _tail(path, nbytes=4000):
+    try:
+        with open(path, "rb") as fh:
+            fh.seek(0, os.SEEK_END)
+            fh.seek(max(0, fh.tell() - nbytes))
+            return fh.read().decode("utf-8", "replace")
+    except OSError:
+        return ""
+
+
+def launch_ranks(nranks, argv=None, limit_s=None, poll_s=0.05):
     """
     ``python bench.py --gpus N`` without a launcher: start N rank processes (fresh interpreters; this parent makes no
-    HIP call before or after), one per GPU, relay their stderr and rank 0's stdout, exit non-zero if any rank fails.
+    HIP call before or after), one per GPU, and watch ALL of them: the first rank that exits non-zero ends the launch
+    -- the others would wait for it in the collective for ever -- its stderr tail is relayed, the rest are terminated
+    (their own process groups; nothing that touched a GPU is ever re-executed) and the exit code is non-zero.  The whole
+    launch has a wall-clock limit (``EIGD_LAUNCH_TIMEOUT``, default 1500 s).  Rank 0's stdout (the JSON line) and
+    stderr pass through.
     """
+    import signal
+
+    argv = sys.argv[1:] if argv is None else list(argv)
+    limit_s = float(os.environ.get("EIGD_LAUNCH_TIMEOUT", "1500")) if limit_s is None else float(limit_s)
     rdv = tempfile.mkdtemp(prefix="eigd_comm_")
-    procs = []
+    procs, logs = [], []
+    out0_path = os.path.join(rdv, "rank0.out")
     for r in range(nranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), EIGD_COMM_DIR=rdv,
                    EIGD_DEVICE=str(r), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+        err_path = os.path.join(rdv, f"rank{r}.err")
+        logs.append(err_path)
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + argv, env=env, start_new_session=True,
+            stdout=open(out0_path, "wb") if r == 0 else subprocess.DEVNULL,
+            stderr=None if r == 0 else open(err_path, "wb")))
+
+    def stop_all():
+        for sig, grace in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+            live = [p for p in procs if p.poll() is None]
+            if not live:
+                return
+            for p in live:
+                try:
+                    os.killpg(p.pid, sig)          # the rank's own session: exactly the processes it started
+                except (ProcessLookupError, PermissionError):
+                    pass
+            t_end = time.monotonic() + grace
+            while time.monotonic() < t_end and any(p.poll() is None for p in live):
+                time.sleep(poll_s)
+
+    t0 = time.monotonic()
+    verdict = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            r, c = bad[0]
+            print(f"[bench] rank {r} of {nranks} exited with code {c}; stopping the other ranks", file=sys.stderr)
+            if r != 0:
+                sys.stderr.write(_tail(logs[r]))
+            stop_all()
+            verdict = 1
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() - t0 > limit_s:
+            print(f"[bench] launch of {nranks} ranks exceeded {limit_s:.0f} s; stopping "
+                  f"{[r for r, c in enumerate(codes) if c is None]}", file=sys.stderr)
+            stop_all()
+            verdict = 1
+            break
+        time.sleep(poll_s)
+    if verdict == 0:
+        sys.stdout.write(_tail(out0_path, 1 << 22))
+        sys.stdout.flush()
+    sys.stderr.flush()
     try:
         for fn in os.listdir(rdv):
             os.unlink(os.path.join(rdv, fn))
         os.rmdir(rdv)
     except OSError:
         pass
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        return 1
-    return 0
+    return verdict
 
 
 def measured_traffic(entry, sources):
@@ -223,6 +279,7 @@ def main():
     ap.add_argument("--emulate-rank", default=None, help="r/P: time the mode share of rank r of P on this GPU (development aid)")
     ap.add_argument("--trace", default=None, help="write the per-iteration host timeline of one extra step to this file")
     ap.add_argument("--no-fd-check", action="store_true", help="skip the directional finite-difference check of df/dx")
+    ap.add_argument("--dump-dfdx", default=None, help="rank 0 saves the df/dx of the last timed step to this .npy file")
     ap.add_argument("--force-launch", action="store_true",
                     help="start the rank processes through the launcher even for --gpus 1 (test of the launcher)")
     args = ap.parse_args()
@@ -263,6 +320,8 @@ def main():
     from eigd_amd.problems import BucklingColumn
 
     ctx = default_context()
+    if os.environ.get("EIGD_TEST_FAIL_RANK") == str(rank):   # launcher test: this rank dies before the communicator
+        raise SystemExit(f"rank {rank}: EIGD_TEST_FAIL_RANK set, leaving before eigd_comm_init")
     if world > 1:
         from eigd_amd.comm import RcclComm
 
@@ -357,6 +416,8 @@ def main():
 
     if rank != 0:
         return
+    if args.dump_dfdx:
+        np.save(args.dump_dfdx, dfdx)
     if args.trace:
         import eigd_amd.adjoint as adj
 

@@ -828,8 +828,8 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
             break
         j += 2
         rng = nrng
-    if prob.fac.native:                                   # one factor application per Krylov step and mode (ref 1248)
-        with prob.fac.factor._count_lock:
+    if prob.fac.native and ok:                            # one factor application per Krylov step and mode (ref 1248);
+        with prob.fac.factor._count_lock:                 # an abandoned attempt is counted by the one-step form that redoes it
             prob.fac.factor.count += int(sum((i if i is not None else maxiter) for i in info))
     fin = np.flatnonzero(done)
     if len(fin) and jlast > 0:
@@ -857,7 +857,11 @@ def _run_groups(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist, s
     k = Rc.k
     groups = max(1, min(int(streams), k))
     if groups == 1:
-        if _sstep_default() == 2:
+        # the pair form orthogonalises 2 x min(k, 32) columns against up to maxiter slabs in one coefficient block of the
+        # Gram-Schmidt kernels (60 KB of LDS): deeper histories (maxiter > 120 at 32 columns) take the one-step form,
+        # whose Gram-Schmidt goes pass by pass beyond that depth
+        fits = maxiter * 2 * min(k, 32) * 8 <= 60 * 1024
+        if _sstep_default() == 2 and fits:
             keep = [list(hh) for hh in sub_hist]
             if 2 * k <= 64:
                 upd, conv, inf, ok = _sibk_round_pair(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist)
@@ -880,6 +884,8 @@ def _run_groups(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist, s
                 return upd, conv, inf
             for hh, h0 in zip(sub_hist, keep):            # (a pair lost orthogonality: the one-step form decides)
                 hh[:] = h0
+            for tag in ("krylov_W2", "krylov_Z2"):        # its stacks go before the one-step stacks are allocated
+                prob.ctx.__dict__.get("_ws", {}).pop(tag, None)
         LAST_ROUND["steps_per_pass"] = 1
         return _sibk_round(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist)
     import threading

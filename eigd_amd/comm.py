@@ -38,9 +38,9 @@ class SerialComm:
 def rendezvous_dir():
     """
     Directory through which the rank processes of ONE launch find each other: ``EIGD_COMM_DIR`` if the launcher set
-    it (bench.py --gpus N does), else a name made of the launcher's pid and start time (all ranks of a
-    ``torch.distributed.run`` launch share the parent process; the start time keeps a recycled pid apart) and the
-    rendezvous port.
+    it (bench.py --gpus N does: a fresh mkdtemp), else a name made of the launcher's pid and start time (all ranks of a
+    ``torch.distributed.run`` launch share the parent process; the start time keeps a recycled pid apart), the
+    rendezvous port and the elastic run id.
     """
     d = os.environ.get("EIGD_COMM_DIR")
     if d:
@@ -52,15 +52,47 @@ def rendezvous_dir():
     except OSError:
         start = "0"
     port = os.environ.get("MASTER_PORT", "0")
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"eigd_comm_{ppid}_{start}_{port}")
+    run = "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "") if ch.isalnum())[:32]
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"eigd_comm_{os.getuid()}_{ppid}_{start}_{port}_{run}")
+
+
+def _process_start_time():
+    """wall-clock start of this process (a unique id older than every rank of this launch belongs to another launch)"""
+    try:
+        with open("/proc/self/stat") as fh:
+            ticks = int(fh.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as fh:
+            up = float(fh.read().split()[0])
+        return time.time() - (up - ticks / os.sysconf("SC_CLK_TCK"))
+    except (OSError, ValueError, IndexError):
+        return time.time()
+
+
+_STALE_SLACK_S = 120.0   # ranks of one launch start within this window of each other
+
+
+def _own_private_dir(d):
+    """create the rendezvous directory for this user only; refuse one that somebody else prepared"""
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError(f"rendezvous directory {d} is not private to this user")
 
 
 def exchange_unique_id(rank, size, make_id, tag="uid", timeout=300.0):
-    """rank 0 calls ``make_id()`` and publishes the bytes (atomic rename); the other ranks wait for the file"""
+    """
+    rank 0 calls ``make_id()`` and publishes the bytes (atomic rename; whatever an earlier launch left under the same
+    name is removed first); the other ranks wait for a file that is not older than this launch.  ``retire_unique_id``
+    removes it once every rank has used it.
+    """
     d = rendezvous_dir()
     path = os.path.join(d, f"{tag}.bin")
     if rank == 0:
-        os.makedirs(d, exist_ok=True)
+        _own_private_dir(d)
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
         uid = make_id()
         tmp = path + f".tmp{os.getpid()}"
         with open(tmp, "wb") as fh:
@@ -68,17 +100,54 @@ def exchange_unique_id(rank, size, make_id, tag="uid", timeout=300.0):
         os.replace(tmp, path)
         return uid
     t0 = time.monotonic()
+    oldest = _process_start_time() - _STALE_SLACK_S
     while True:
         try:
-            with open(path, "rb") as fh:
-                uid = fh.read()
-            if len(uid) > 0:
-                return uid
+            if os.stat(path).st_mtime >= oldest:
+                with open(path, "rb") as fh:
+                    uid = fh.read()
+                if len(uid) > 0:
+                    return uid
         except OSError:
             pass
         if time.monotonic() - t0 > timeout:
             raise TimeoutError(f"rank {rank}: no unique id from rank 0 under {d} after {timeout:.0f} s")
         time.sleep(0.02)
+
+
+def retire_unique_id(rank, tag="uid"):
+    """after a collective that every rank has passed: rank 0 removes the published id (nothing stale for a later launch)"""
+    if rank != 0:
+        return
+    d = rendezvous_dir()
+    try:
+        os.unlink(os.path.join(d, f"{tag}.bin"))
+    except OSError:
+        pass
+    if not os.environ.get("EIGD_COMM_DIR"):
+        try:
+            os.rmdir(d)
+        except OSError:
+            pass
+
+
+def _init_watchdog(rank, size, seconds):
+    """
+    ncclCommInitRank waits for every rank and has no timeout of its own: if a peer died before it got there this
+    process would wait for ever.  A timer thread (the ctypes call releases the GIL) ends the process instead.
+    """
+    import sys
+    import threading
+
+    def fire():
+        print(f"[eigd_amd.comm] rank {rank} of {size}: communicator not up after {seconds:.0f} s "
+              "(a peer never reached eigd_comm_init?) -- giving up", file=sys.stderr, flush=True)
+        os._exit(3)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 class RcclComm:
@@ -98,6 +167,8 @@ class RcclComm:
         self.size = int(os.environ.get("WORLD_SIZE", "1")) if size is None else int(size)
         self.backend = "rccl"
         uid = None
+        tag = None
+        watchdog = None
         if self.size > 1:
             def make_id():
                 buf = C.create_string_buffer(128)
@@ -105,10 +176,20 @@ class RcclComm:
                 return buf.raw
 
             RcclComm._generation += 1
-            uid = exchange_unique_id(self.rank, self.size, make_id, tag=f"uid{RcclComm._generation}")
+            tag = f"uid{RcclComm._generation}"
+            limit = float(os.environ.get("EIGD_COMM_INIT_TIMEOUT", "600"))
+            uid = exchange_unique_id(self.rank, self.size, make_id, tag=tag, timeout=min(300.0, limit))
+            watchdog = _init_watchdog(self.rank, self.size, limit)
         h = c_vp()
-        call("eigd_comm_init", ctx.h, self.size, self.rank, uid, C.byref(h))
+        try:
+            call("eigd_comm_init", ctx.h, self.size, self.rank, uid, C.byref(h))
+        finally:
+            if watchdog is not None:
+                watchdog.cancel()
         self.h = h
+        if self.size > 1:
+            self.barrier()                 # every rank holds the communicator: the published id can go
+            retire_unique_id(self.rank, tag)
 
     def close(self):
         from . import _ffi
@@ -124,11 +205,15 @@ class RcclComm:
             pass
 
     def allreduce_sum_device(self, blk):
-        """in place on a contiguous device block; ordered on the block's context stream"""
+        """in place on a contiguous device block of the communicator's context (ordered on that context's stream)"""
         from ._ffi import call
 
         if blk.ld != blk.k:
             raise ValueError("contiguous block expected")
+        if blk.ctx is not self.ctx:
+            # the collective is enqueued on the communicator's context stream: a block of another (forked) context
+            # would be reduced without ordering against the work that produced it
+            raise ValueError("the block belongs to another context than the communicator")
         call("eigd_allreduce_sum", self.h, blk.ptr, blk.n * blk.k)
         return blk
 

@@ -512,6 +512,65 @@ def test_bench_launcher_starts_rank_processes(tmp_path):
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["modes"] == 4
 
 
+_SMALL_BENCH = ["--nx", "60", "--ny", "60", "--modes", "4", "--m", "20", "--steps", "1", "--warmup", "0", "--cpu-sample",
+                "none", "--no-fd-check", "--numpy-steps", "0", "--spmv-reps", "4"]
+
+
+def test_bench_launcher_ends_when_a_rank_dies_before_the_communicator():
+    """
+    Two rank processes, rank 1 leaves before eigd_comm_init: rank 0 would wait in ncclCommInitRank for ever.  The
+    launcher has to notice the dead rank, stop the other one and exit non-zero -- within seconds of the failure, not at
+    some time limit -- and say which rank failed.
+    """
+    import os
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EIGD_TEST_FAIL_RANK="1", EIGD_LAUNCH_TIMEOUT="900")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + _SMALL_BENCH, env=env,
+                         capture_output=True, text=True, timeout=600)
+    took = time.monotonic() - t0
+    assert out.returncode != 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "rank 1 of 2 exited with code" in out.stderr, out.stderr[-3000:]
+    assert "EIGD_TEST_FAIL_RANK" in out.stderr          # the dead rank's own message is relayed
+    assert out.stdout.strip() == ""                     # no half-finished JSON line
+    assert took < 240, f"launcher needed {took:.0f} s to give up"   # (interpreter + library start-up of the ranks, not a timeout)
+
+
+def test_bench_two_ranks_over_rccl_match_one_rank(tmp_path):
+    """
+    bench.py --gpus 2 on a small problem: unique-id exchange between the rank processes, ncclCommInitRank, the in-place
+    fp64 ncclAllReduce of the partial df/dx vectors and the sharded total derivative, against the one-rank df/dx.
+    Needs two devices (RCCL refuses two ranks on one device): skipped on a one-GPU box.
+    """
+    import ctypes
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from eigd_amd._ffi import call
+
+    cnt = ctypes.c_int()
+    call("eigd_device_count", ctypes.byref(cnt))
+    if cnt.value < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for g in (1, 2):
+        dump = str(tmp_path / f"dfdx{g}.npy")
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(g), "--dump-dfdx", dump]
+                             + _SMALL_BENCH, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == g
+        res[g] = np.load(dump)
+    assert np.linalg.norm(res[2] - res[1]) <= 1e-10 * np.linalg.norm(res[1])
+
+
 def _fd_functional(lam, Phi, lamb, Phib, Phi_ref, mode):
     """
     f = lamb . g(lam) + sum_i Phib_i . phi_i with the eigenvector signs aligned to the base point.
@@ -973,23 +1032,31 @@ def test_two_krylov_steps_per_gram_schmidt_pass_match_the_one_step_solver(monkey
         for kname, v in env.items():
             monkeypatch.setenv(kname, v)
         hist = []
+        fac.count = 0
         psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, callback=hist.append)
-        runs[name] = (psi, data, list(s.last_info), hist)
+        runs[name] = (psi, data, list(s.last_info), hist, fac.count)
         from eigd_amd import adjoint as _adj
 
         assert _adj.LAST_ROUND["steps_per_pass"] == (2 if name == "two" else 1), name   # the form asked for (or the fall-back) ran
         monkeypatch.delenv("EIGD_SSTEP_DEFECT_TOL", raising=False)
-    psi1, data1, info1, hist1 = runs["one"]
-    psi2, data2, info2, hist2 = runs["two"]
+    psi1, data1, info1, hist1, count1 = runs["one"]
+    psi2, data2, info2, hist2, count2 = runs["two"]
     assert info2 == info1 and len(set(i % 2 for i in info1 if i)) == 2          # odd and even stopping steps
     assert len(hist2) == len(hist1) and np.allclose(hist2, hist1, rtol=1e-6, atol=1e-300)
     assert relerr(psi2, psi1) < 1e-11
     assert index_sets(data2) == index_sets(data1)
-    psi3, _, info3, _ = runs["fallback"]
+    psi3, _, info3, _, count3 = runs["fallback"]
     assert info3 == info1 and np.array_equal(psi3, psi1)                       # the one-step form took over
+    assert count1 == count2 == count3, (count1, count2, count3)               # applications per mode (ref 19-22): an
+    # abandoned two-step attempt is not counted on top of the one-step solve that replaces it
     # a maxiter inside a cycle: both forms keep the same best iterates
     monkeypatch.setenv("EIGD_SSTEP", "1")
     pa, _ = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, maxiter=7, nrestart=0)
     monkeypatch.setenv("EIGD_SSTEP", "2")
     pb, _ = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, maxiter=7, nrestart=0)
     assert relerr(pb, pa) < 1e-10
+    # a Krylov history deeper than one coefficient block of the pair kernels (maxiter > 120 at 32 columns): the one-step
+    # form is chosen up front, nothing raises in mid-solve
+    pc, _ = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, maxiter=130)
+    assert _adj.LAST_ROUND["steps_per_pass"] == (1 if N >= 32 else 2)
+    assert relerr(pc, psi1) < 1e-10
