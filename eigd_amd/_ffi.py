@@ -74,6 +74,7 @@ _SIGNATURES = {
     "eigd_project": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_project_norm2": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp],
     "eigd_coldot": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp],
+    "eigd_coldot_dd": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp],
     "eigd_lincomb": [c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp],
     "eigd_stack_dot": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_int, c_vp],
     "eigd_stack_axpy": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_dbl],

@@ -152,22 +152,79 @@ def _emit(callback, histories, order):
 # ---------------------------------------------------------------------------
 # correction along the eigenvectors (ref 303-391)
 # ---------------------------------------------------------------------------
-def correction_coefficients(lam, G, eig_atol=1e-5, mode="normal"):
+def repeated_pairs(lam, eig_atol=1e-5):
+    """the pairs (i, j), j < i, that the reference treats as numerically repeated (ref 370-372), in its loop order"""
+    N = len(lam)
+    return [(i, j) for i in range(N) for j in range(i) if _is_close(lam[i], lam[j], atol=eig_atol)]
+
+
+def compensated_entries(dU, dX, rows, cols, sign=1.0):
+    """
+    sign * U[:, rows[q]] . X[:, cols[q]] accumulated in twice the working precision (eigd_coldot_dd): (hi, lo) arrays
+    with hi + lo = the dot products to ~1e-30 of sum |u x|.
+    """
+    hi, lo = dU.gather_cols(np.asarray(rows)).coldot_dd(dX.gather_cols(np.asarray(cols)))
+    return sign * hi, sign * lo
+
+
+def refine_repeated_entries(G, lam, dU, dX, eig_atol=1e-5, sign=-1.0, col_of=None):
+    """
+    The entries G[j, i], G[i, j] of numerically repeated pairs recomputed with compensated dot products, in place; the
+    low-order parts come back in a second matrix (None when no pair is repeated).
+
+    xi and eta (ref 373-383) divide the DIFFERENCE of two n-term dot products by the gap of the pair -- 1e-7 for the
+    thermal plate at epsilon = 1e-8 -- so the rounding of a plain dot product, a few 1e-16 of |phi| |Phib|, arrives
+    in df/dx seven digits larger.  The reference's own value carries that noise (1.4e-9 of df/dx under a change of
+    summation order); ours carries the noise of whatever reduction tree the GEMM kernel uses.  Two exact-to-rounding
+    entries per pair remove our share, which keeps the repeated branch inside the 1e-8 of north_star.
+    ``col_of``: global mode -> column of dX / G (mode-sharded solvers hold a subset of the columns); pairs with a
+    missing column are skipped.
+    """
+    pairs = repeated_pairs(lam, eig_atol)
+    if not pairs:
+        return None
+    rows, cols = [], []
+    for i, j in pairs:
+        rows += [j, i]
+        cols += [i, j]
+    Glo = np.zeros_like(G)
+    if col_of is not None:
+        keep = [q for q in range(len(rows)) if cols[q] in col_of]
+        rows, cols = [rows[q] for q in keep], [col_of[cols[q]] for q in keep]
+        if not rows:
+            return Glo         # (not None: whether a low-order matrix exists is the same decision on every rank)
+    hi, lo = compensated_entries(dU, dX, rows, cols, sign)
+    G[rows, cols] = hi
+    Glo[rows, cols] = lo
+    return Glo
+
+
+def correction_coefficients(lam, G, eig_atol=1e-5, mode="normal", Glo=None):
     """
     Host part of generate_adjoint_correction: the N x N matrix Cc with psi += Phi @ Cc for the
     distinct pairs (ref 385-389) and the dict of (j, xi, eta) tuples of the repeated pairs
     (ref 373-383).  Loop order and formulas are the reference's, so index sets are identical.
+    ``Glo``: low-order parts of the entries of repeated pairs (refine_repeated_entries); xi and eta are then formed in
+    extended precision from hi + lo, so the division by the gap magnifies no rounding of ours.
     """
     N = len(lam)
     G0 = G if mode == "normal" else np.diag(lam) @ G
     Cc = np.zeros((N, N))
     data = {}
+    ld = np.longdouble
     for i in range(N):
         for j in range(i):
             gap = lam[j] - lam[i]
             if _is_close(lam[i], lam[j], atol=eig_atol):
-                xi = 0.5 * (G0[j, i] - G0[i, j]) / gap
-                eta = 0.5 * (lam[i] * G0[j, i] - lam[j] * G0[i, j]) / gap
+                if Glo is None:
+                    xi = 0.5 * (G0[j, i] - G0[i, j]) / gap
+                    eta = 0.5 * (lam[i] * G0[j, i] - lam[j] * G0[i, j]) / gap
+                else:
+                    gji, gij = ld(G[j, i]) + ld(Glo[j, i]), ld(G[i, j]) + ld(Glo[i, j])
+                    if mode != "normal":                      # G0 = diag(lam) G
+                        gji, gij = ld(lam[j]) * gji, ld(lam[i]) * gij
+                    xi = float(ld(0.5) * (gji - gij) / ld(gap))
+                    eta = float(ld(0.5) * (ld(lam[i]) * gji - ld(lam[j]) * gij) / ld(gap))
                 data.setdefault(i, [])
                 data.setdefault(j, [])
                 data[i].append((j, xi, eta))
@@ -204,9 +261,12 @@ def generate_adjoint_correction(lam, Phi, psi, G=None, Phib=None, eig_atol=1e-5,
             raise ValueError(f"Phi must have dimensions ({n},{N})")
     ctx = _ctx_of(None, ctx)
     dPhi = ctx.from_host(Phi)
+    Glo = None
     if G is None:
-        G = -dPhi.tdot(ctx.from_host(Phib))
-    Cc, data = correction_coefficients(lam, G, eig_atol, mode)
+        dPhib = ctx.from_host(Phib)
+        G = -dPhi.tdot(dPhib)
+        Glo = refine_repeated_entries(G, lam, dPhi, dPhib, eig_atol)
+    Cc, data = correction_coefficients(lam, G, eig_atol, mode, Glo)
     dpsi = ctx.from_host(psi)
     _apply_correction(dpsi, dPhi, Cc)
     psi[:] = dpsi.get()  # in place, as ref 386-389
@@ -1078,12 +1138,13 @@ def sibk(Phib, A, B, lam, Phi, mode="normal", psi=None, sigma=None, factor=None,
     dPhib = ctx.from_host(Phib)
     lam = np.asarray(lam, dtype=float)
     G = -prob.Phi.tdot(dPhib)                            # ref 1180
+    Glo = refine_repeated_entries(G, lam, prob.Phi, dPhib, eig_atol)
     if bs_target == 1 and not update_guess:
         info = _sibk_device(prob, dPhib, dpsi, lam, sigma, rtol, atol, maxiter, nrestart, callback)
     else:
         info = _sibk_sequential(prob, dPhib, dpsi, lam, sigma, rtol, atol, maxiter, bs_target, update_guess,
                                 callback, nrestart)
-    Cc, data = correction_coefficients(lam, G, eig_atol, mode)  # ref 1324-1326
+    Cc, data = correction_coefficients(lam, G, eig_atol, mode, Glo)  # ref 1324-1326
     _apply_correction(dpsi, prob.Phi, Cc)
     _psi[:] = dpsi.get()
     return _psi, data, info
@@ -1092,7 +1153,7 @@ def sibk(Phib, A, B, lam, Phi, mode="normal", psi=None, sigma=None, factor=None,
 # ---------------------------------------------------------------------------
 # PGMRES, lock-step batched (ref 872-1040)
 # ---------------------------------------------------------------------------
-def _pgmres_device(prob, dPhib, dpsi, lam_c, rtol, atol, maxiter, callback, rnorm0=None):
+def _pgmres_device(prob, dPhib, dpsi, lam_c, rtol, atol, maxiter, callback, rnorm0=None, refine=None):
     ctx = prob.ctx
     k = dPhib.k
     lam_c = np.asarray(lam_c, dtype=float)
@@ -1100,6 +1161,7 @@ def _pgmres_device(prob, dPhib, dpsi, lam_c, rtol, atol, maxiter, callback, rnor
         rnorm0 = _rnorm0(dPhib)
     R = prob.residual(dPhib, dpsi, lam_c)
     Gc = prob.Phi.tdot(R)                                # ref 989: G[:, i] = Phi^T R
+    Gclo = refine(Gc, R) if refine is not None else None
     R.add_product(prob.BPhi, Gc, alpha=-1.0, beta=1.0)   # ref 990
     beta = R.colnorms()
     hist = [[float(beta[c])] for c in range(k)]
@@ -1155,7 +1217,7 @@ def _pgmres_device(prob, dPhib, dpsi, lam_c, rtol, atol, maxiter, callback, rnor
             W[j + 1].cols(lo, hi).assign_lincomb([(scale, Ta)])
         Z.axpy_into(dpsi, Ycoef[:jlast], alpha=1.0)      # ref 1028 / 1032
     _emit(callback, hist, range(k))
-    return Gc, info
+    return (Gc, Gclo), info
 
 
 def pgmres(Phib, A, B, lam, Phi, mode="normal", psi=None, sigma=None, factor=None, rtol=1e-10, atol=1e-30,
@@ -1169,8 +1231,9 @@ def pgmres(Phib, A, B, lam, Phi, mode="normal", psi=None, sigma=None, factor=Non
     _psi = psi if psi is not None else np.zeros((n, N), dtype=Phib.dtype)
     dpsi = ctx.from_host(_psi)
     lam = np.asarray(lam, dtype=float)
-    G, info = _pgmres_device(prob, ctx.from_host(Phib), dpsi, lam, rtol, atol, maxiter, callback)
-    Cc, data = correction_coefficients(lam, G, eig_atol, mode)
+    (G, Glo), info = _pgmres_device(prob, ctx.from_host(Phib), dpsi, lam, rtol, atol, maxiter, callback,
+                                    refine=lambda Gm, R: refine_repeated_entries(Gm, lam, prob.Phi, R, eig_atol, sign=1.0))
+    Cc, data = correction_coefficients(lam, G, eig_atol, mode, Glo)
     _apply_correction(dpsi, prob.Phi, Cc)
     _psi[:] = dpsi.get()
     return _psi, data, info
@@ -1179,7 +1242,7 @@ def pgmres(Phib, A, B, lam, Phi, mode="normal", psi=None, sigma=None, factor=Non
 # ---------------------------------------------------------------------------
 # PCPG, lock-step batched (ref 699-869)
 # ---------------------------------------------------------------------------
-def _pcpg_device(prob, dPhib, dpsi, lam_c, rtol, atol, maxiter, reset, callback, rnorm0=None):
+def _pcpg_device(prob, dPhib, dpsi, lam_c, rtol, atol, maxiter, reset, callback, rnorm0=None, refine=None):
     ctx = prob.ctx
     k = dPhib.k
     lam_c = np.asarray(lam_c, dtype=float)
@@ -1187,6 +1250,7 @@ def _pcpg_device(prob, dPhib, dpsi, lam_c, rtol, atol, maxiter, reset, callback,
         rnorm0 = _rnorm0(dPhib)
     R = prob.residual(dPhib, dpsi, lam_c)
     Gc = prob.Phi.tdot(R)                                # ref 810
+    Gclo = refine(Gc, R) if refine is not None else None
     R.add_product(prob.BPhi, Gc, alpha=-1.0, beta=1.0)   # ref 811
     hist = [[] for _ in range(k)]
     conv = [False] * k
@@ -1225,7 +1289,7 @@ def _pcpg_device(prob, dPhib, dpsi, lam_c, rtol, atol, maxiter, reset, callback,
         R.assign_lincomb([(1.0, R), (-alpha, Q)])        # ref 855 / 857
         P0.copy_from(P)
     _emit(callback, hist, range(k))
-    return Gc, conv
+    return (Gc, Gclo), conv
 
 
 def pcpg(Phib, A, B, lam, Phi, mode="normal", psi=None, sigma=None, factor=None, rtol=1e-10, atol=1e-30,
@@ -1239,8 +1303,9 @@ def pcpg(Phib, A, B, lam, Phi, mode="normal", psi=None, sigma=None, factor=None,
     _psi = psi if psi is not None else np.zeros((n, N), dtype=Phib.dtype)
     dpsi = ctx.from_host(_psi)
     lam = np.asarray(lam, dtype=float)
-    G, info = _pcpg_device(prob, ctx.from_host(Phib), dpsi, lam, rtol, atol, maxiter, reset, callback)
-    Cc, data = correction_coefficients(lam, G, eig_atol, mode)
+    (G, Glo), info = _pcpg_device(prob, ctx.from_host(Phib), dpsi, lam, rtol, atol, maxiter, reset, callback,
+                                  refine=lambda Gm, R: refine_repeated_entries(Gm, lam, prob.Phi, R, eig_atol, sign=1.0))
+    Cc, data = correction_coefficients(lam, G, eig_atol, mode, Glo)
     _apply_correction(dpsi, prob.Phi, Cc)
     _psi[:] = dpsi.get()
     return _psi, data, info
@@ -1259,9 +1324,10 @@ def _dl_device(prob, dPhib, lam, sigma, indices, Vst, m, T, Y, theta, eig_atol, 
     lam = np.asarray(lam, dtype=float)
     repeated = are_eigenvalues_repeated(lam, atol=eig_atol)
     sel = np.asarray(indices[:N])
-    G = None
+    G = Glo = None
     if repeated:                                          # ref 607-617
         G = -prob.Phi.tdot(dPhib)
+        Glo = refine_repeated_entries(G, lam, prob.Phi, dPhib, eig_atol)
         Rb = dPhib.copy().add_product(prob.BPhi, G, alpha=1.0, beta=1.0)
     else:
         Rb = dPhib
@@ -1328,7 +1394,7 @@ def _dl_device(prob, dPhib, lam, sigma, indices, Vst, m, T, Y, theta, eig_atol, 
     data = {}
     if repeated:                                          # ref 682-694
         prob.project_s(psi)
-        Cc, data = correction_coefficients(lam, G, eig_atol, mode)
+        Cc, data = correction_coefficients(lam, G, eig_atol, mode, Glo)
         _apply_correction(psi, prob.Phi, Cc)
     return psi, data
 

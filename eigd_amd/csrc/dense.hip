@@ -63,6 +63,65 @@ __global__ __launch_bounds__(kThreads) void coldot_kernel(int n, int k, const do
 }
 
 // ---------------------------------------------------------------------------
+// column-wise dot products accumulated in twice the working precision (Ogita-Rump-Oishi "Dot2": error-free
+// product by FMA, error-free sum, the errors carried in a second double).  For the handful of entries of
+// G = -Phi^T Phib that belong to numerically repeated eigenvalue pairs: xi, eta divide their DIFFERENCE by the gap
+// (reference eigenvector_derivatives.py:373-383), so the rounding of an n-term dot product shows up 1/gap times larger.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void dd_two_sum(double a, double b, double& s, double& e) {
+  s = a + b;
+  const double bb = s - a;
+  e = (a - (s - bb)) + (b - bb);
+}
+
+__device__ __forceinline__ void dd_add(double& hi, double& lo, double bh, double bl) {
+  double s, e;
+  dd_two_sum(hi, bh, s, e);
+  e += lo + bl;
+  hi = s + e;
+  lo = e - (hi - s);
+}
+
+template <int KP>
+__global__ __launch_bounds__(kThreads) void coldot_dd_kernel(int n, int k, const double* __restrict__ X, int ldx,
+                                                            const double* __restrict__ Y, int ldy,
+                                                            double* __restrict__ partial /* [block][2][k] */) {
+  constexpr int RP = kThreads / KP;
+  __shared__ double red_hi[kThreads], red_lo[kThreads];
+  const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
+  double hi = 0.0, lo = 0.0;
+  if (c < k)
+    for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
+      const double x = X[r * ldx + c], y = Y[r * ldy + c];
+      const double p = x * y;
+      const double pe = __fma_rn(x, y, -p);     // x*y = p + pe exactly
+      double s, e;
+      dd_two_sum(hi, p, s, e);                  // hi + p = s + e exactly
+      hi = s;
+      lo += e + pe;
+    }
+  red_hi[threadIdx.x] = hi;
+  red_lo[threadIdx.x] = lo;
+  __syncthreads();
+  if (rr == 0 && c < k) {
+    double th = 0.0, tl = 0.0;
+    for (int q = 0; q < RP; ++q) dd_add(th, tl, red_hi[q * KP + c], red_lo[q * KP + c]);
+    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * k + c] = th;
+    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * k + c] = tl;
+  }
+}
+
+__global__ void reduce_dd_kernel(const double* __restrict__ partial, int nblocks, int k, double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  double th = 0.0, tl = 0.0;
+  for (int b = 0; b < nblocks; ++b)
+    dd_add(th, tl, partial[(static_cast<int64_t>(b) * 2 + 0) * k + c], partial[(static_cast<int64_t>(b) * 2 + 1) * k + c]);
+  out[c] = th;
+  out[k + c] = tl;
+}
+
+// ---------------------------------------------------------------------------
 // stack_dot: H[j][c] = sum_r S_j[r][c] * T[r][c] for JB slabs per launch
 // ---------------------------------------------------------------------------
 template <int KP, int JB>
@@ -746,6 +805,28 @@ int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const do
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();
   return reduce_to_host(ctx, partial, nb, k, res, hout);
+}
+
+int eigd_coldot_dd(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout) {
+  EIGD_REQUIRE(ctx && dX && dY && hout, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldx >= k && ldy >= k, "bad shape n=%d k=%d", n, k);
+  const int kp = next_pow2(k);
+  const int nb = std::min(grid_for_rows(n, (kThreads / kp) * 8), 2048);
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) + 1) * 2 * k);
+  if (rc) return rc;
+  double* res = ctx->scratch;
+  double* partial = ctx->scratch + 2 * k;
+  rc = dispatch_kp(k, [&](auto KP) {
+    hipLaunchKernelGGL(coldot_dd_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dX, ldx, dY,
+                       ldy, partial);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_dd_kernel, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, partial, nb, k, res);
+  EIGD_LAUNCH_CHECK();
+  EIGD_HIP(hipMemcpyAsync(hout, res, sizeof(double) * 2 * k, hipMemcpyDeviceToHost, ctx->stream));
+  EIGD_HIP(hipStreamSynchronize(ctx->stream));
+  return EIGD_OK;
 }
 
 int eigd_lincomb(eigd_ctx* ctx, int n, int k, double* dOut, int ldo, int nterms, const double* const* dXs,

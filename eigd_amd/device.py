@@ -266,6 +266,17 @@ class DeviceBlock:
             out[c0:c1] = tmp
         return out
 
+    def coldot_dd(self, other):
+        """column-wise dots in twice the working precision: (hi, lo) arrays with hi + lo = the dot products"""
+        hi, lo = np.empty(self.k), np.empty(self.k)
+        for c0 in range(0, self.k, 64):
+            c1 = min(self.k, c0 + 64)
+            tmp = np.empty(2 * (c1 - c0))
+            call("eigd_coldot_dd", self.ctx.h, self.n, c1 - c0, self.cols(c0, c1).ptr, self.ld,
+                 other.cols(c0, c1).ptr, other.ld, hptr(tmp))
+            hi[c0:c1], lo[c0:c1] = tmp[: c1 - c0], tmp[c1 - c0:]
+        return hi, lo
+
     def colnorms(self):
         return np.sqrt(self.coldot(self))
 
@@ -849,17 +860,28 @@ class ElementAssembler:
         call("eigd_assembler_pattern", self.h, hptr(ip), hptr(ix))
         return sparse.csr_matrix((np.zeros(self.nnz), ix[: self.nnz], ip), shape=(self.n, self.n))
 
-    def _upload(self, key, arr, dtype=np.float64):
-        """element matrices / scale factors are uploaded once per distinct host array"""
-        ent = self._cache.get(key)
+    def _upload(self, key, arr, dtype=np.float64, hold=None):
+        """
+        element matrices / scale factors are uploaded once per distinct host array.  The cache is least-recently-used
+        (a hit moves the entry to the end); ``hold`` collects the buffers of the call in progress so that none of them
+        is released -- by an eviction or by a replaced entry -- before the launch that reads it has been enqueued.
+        """
+        ent = self._cache.pop(key, None)
         if ent is None or ent[0] is not arr:
             a = np.ascontiguousarray(arr, dtype=dtype)
             buf = _Buffer(self.ctx, max(a.nbytes, 8))
             call("eigd_h2d", self.ctx.h, c_vp(buf.ptr), hptr(a), a.nbytes)
+            if ent is not None and hold is not None:
+                hold.append(ent[1])                        # (the replaced buffer may be an operand of this very call)
             ent = (arr, buf)
-            if len(self._cache) >= 8:  # a handful of distinct operands per assembler (K, G, their parts): drop the oldest
-                self._cache.pop(next(iter(self._cache)))
-            self._cache[key] = ent
+        self._cache[key] = ent                             # most recently used: last
+        if hold is not None:
+            hold.append(ent[1])
+        while len(self._cache) > 8:  # a handful of distinct operands per assembler (K, G, their parts): drop the oldest
+            old_key = next(iter(self._cache))
+            old = self._cache.pop(old_key)
+            if hold is not None:
+                hold.append(old[1])
         return ent[1]
 
     def assemble(self, Me, scale=None, out=None, etype=None):
@@ -867,11 +889,12 @@ class ElementAssembler:
         CSR values (device block nnz x 1) of sum_e scale[e] P_e^T Me P_e; Me: (nd, nd) shared or (nelem, nd, nd) numpy
         array, or a device block of nelem * nd * nd doubles (per-element matrices made on the device)
         """
+        hold = []  # every cached operand of this call stays alive until its launch is enqueued
         if isinstance(Me, DeviceBlock):
             if Me.n * Me.k != self.nelem * self.nd * self.nd:
                 raise ValueError("element matrix block does not match the dof list")
             sp = scale.ptr if isinstance(scale, DeviceBlock) else (
-                c_vp(None) if scale is None else c_vp(self._upload("scale", scale).ptr))
+                c_vp(None) if scale is None else c_vp(self._upload("scale", scale, hold=hold).ptr))
             vals = out if out is not None else self.ctx.empty(max(self.nnz, 1), 1)
             call("eigd_assemble", self.h, Me.ptr, 1, c_vp(None), sp, vals.ptr)
             return vals
@@ -883,7 +906,7 @@ class ElementAssembler:
             if Me.ndim != 3 or et.shape != (self.nelem,) or et.min() < 0 or et.max() >= Me.shape[0]:
                 raise ValueError("element types do not match the matrices")
             per_elem = 2
-            tp = c_vp(self._upload("etype", etype, np.int32).ptr)
+            tp = c_vp(self._upload("etype", etype, np.int32, hold=hold).ptr)
         if Me.shape[-2:] != (self.nd, self.nd) or (per_elem == 1 and Me.shape[0] != self.nelem):
             raise ValueError("element matrix shape does not match the dof list")
         if isinstance(scale, DeviceBlock):
@@ -893,9 +916,11 @@ class ElementAssembler:
         else:
             if np.shape(scale) != (self.nelem,):
                 raise ValueError("one scale factor per element expected")
-            sp = c_vp(self._upload("scale", scale).ptr)
+            sp = c_vp(self._upload("scale", scale, hold=hold).ptr)
         vals = out if out is not None else self.ctx.empty(max(self.nnz, 1), 1)
-        call("eigd_assemble", self.h, c_vp(self._upload(("Me", id(Me)), Me).ptr), per_elem, tp, sp, vals.ptr)
+        mp = c_vp(self._upload(("Me", id(Me)), Me, hold=hold).ptr)
+        call("eigd_assemble", self.h, mp, per_elem, tp, sp, vals.ptr)
+        del hold
         return vals
 
     def values_to_host(self, vals):

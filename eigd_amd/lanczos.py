@@ -265,7 +265,13 @@ class _AdjointAPI:
         kw = dict(kwargs)
         callback = kw.pop("callback", None)
         rnorm0 = adj._rnorm0(dPhib)
-        G = None
+        G = Glo = None
+
+        def refine_cols(Gm, R):
+            """compensated entries of the repeated pairs in G[:, sel] = Phi^T R (pgmres / pcpg; R holds the columns sel)"""
+            return adj.refine_repeated_entries(Gm, lam, prob.Phi, R, eig_atol, sign=1.0,
+                                               col_of={int(c): q for q, c in enumerate(sel)})
+
         if method == "sibk":
             maxiter = kw.pop("maxiter", 50)
             nrestart = kw.pop("nrestart", 2)
@@ -276,6 +282,7 @@ class _AdjointAPI:
             if kw:
                 raise TypeError(f"sibk() got unexpected keyword arguments {sorted(kw)}")
             G = -prob.Phi.tdot(dPhib)
+            Glo = adj.refine_repeated_entries(G, lam, prob.Phi, dPhib, eig_atol)
             if seq_sibk:
                 self.last_info = adj._sibk_sequential(prob, dPhib_c, psi_c, lam_c, self.sigma, rtol, atol, maxiter,
                                                       bs_target, update_guess, callback, nrestart)
@@ -286,26 +293,27 @@ class _AdjointAPI:
             maxiter = kw.pop("maxiter", 50)
             if kw:
                 raise TypeError(f"pgmres() got unexpected keyword arguments {sorted(kw)}")
-            Gc, self.last_info = adj._pgmres_device(prob, dPhib_c, psi_c, lam_c, rtol, atol, maxiter, callback,
-                                                    rnorm0=rnorm0)
-            G = self._assemble_G(Gc, sel, N, comm)
+            (Gc, Gclo), self.last_info = adj._pgmres_device(prob, dPhib_c, psi_c, lam_c, rtol, atol, maxiter, callback,
+                                                            rnorm0=rnorm0, refine=refine_cols)
+            G, Glo = self._assemble_G(Gc, sel, N, comm), self._assemble_G(Gclo, sel, N, comm, optional=True)
         elif method == "pcpg":
             maxiter = kw.pop("maxiter", 100)
             reset = kw.pop("reset", 25)
             if kw:
                 raise TypeError(f"pcpg() got unexpected keyword arguments {sorted(kw)}")
-            Gc, self.last_info = adj._pcpg_device(prob, dPhib_c, psi_c, lam_c, rtol, atol, maxiter, reset, callback,
-                                                  rnorm0=rnorm0)
-            G = self._assemble_G(Gc, sel, N, comm)
+            (Gc, Gclo), self.last_info = adj._pcpg_device(prob, dPhib_c, psi_c, lam_c, rtol, atol, maxiter, reset,
+                                                          callback, rnorm0=rnorm0, refine=refine_cols)
+            G, Glo = self._assemble_G(Gc, sel, N, comm), self._assemble_G(Gclo, sel, N, comm, optional=True)
         elif method == "laa":
             G = -prob.Phi.tdot(dPhib)                      # ref 1772-1779 / 2109-2116 (G from Phib)
+            Glo = adj.refine_repeated_entries(G, lam, prob.Phi, dPhib, eig_atol)
         elif method == "dl":
             if self.T is None:
                 raise ValueError("dl needs the Lanczos matrix T")
             psi_c, data = adj._dl_device(prob, dPhib, lam, self.sigma, indices, self._dev.V, self._m,
                                          np.asarray(self.T), Y, theta, eig_atol, self.mode)
         if G is not None:
-            Cc, data = adj.correction_coefficients(lam, G, eig_atol, self.mode)
+            Cc, data = adj.correction_coefficients(lam, G, eig_atol, self.mode, Glo)
             adj._apply_correction(psi_c, prob.Phi, Cc, cols=cols)
         if cols is None:
             dpsi = psi_c
@@ -317,7 +325,11 @@ class _AdjointAPI:
         return dpsi.get(), data
 
     @staticmethod
-    def _assemble_G(Gc, sel, N, comm):
+    def _assemble_G(Gc, sel, N, comm, optional=False):
+        """the rank's columns of G put in place and summed over the ranks; ``optional``: Gc may be None (no repeated pair:
+        decided from the replicated eigenvalues, so every rank takes the same branch)"""
+        if Gc is None and optional:
+            return None
         G = np.zeros((N, N))
         G[:, sel] = Gc
         if comm is not None and comm.size > 1:

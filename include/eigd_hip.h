@@ -154,6 +154,10 @@ int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, i
 /* column-wise dots  out[c] = sum_r X[r,c] Y[r,c]  (HOST out, length k); inner products / norms
  * of 1157-1158, 1219, 1233, 1259, 1504, 1537 batched over the modes                     */
 int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout);
+/* the same dots accumulated in twice the working precision (error-free products and sums, errors carried in a second
+ * double): hout[c] + hout[k + c] = sum_r X[r,c] Y[r,c] to ~1e-30 of sum |X Y|.  For the entries of G = -Phi^T Phib
+ * (345, 1180) of numerically repeated pairs, whose DIFFERENCE is divided by the eigenvalue gap in xi, eta (373-383) */
+int eigd_coldot_dd(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout);
 /* out[r,c] = sum_t coef[t*k + c] * X_t[r,c], nterms <= 4, out may alias any X_t
  * (the w-vector / residual assembly of 96-134, 807-809, 1189-1192, axpys 851-860)      */
 int eigd_lincomb(eigd_ctx* ctx, int n, int k, double* dOut, int ldo, int nterms, const double* const* dXs,

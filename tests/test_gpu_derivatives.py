@@ -190,22 +190,11 @@ def test_g3_thermal_repeated_branch_rhoEb(name):
     rhoEb2 = s.add_total_derivative(g["lamb"], g["Qb"], psi_d, dAdx, dBdx, np.zeros(el.nelems), adj_corr_data=data,
                                     deriv_type="tensor")
     # xi = (G0[j,i] - G0[i,j]) / (2 gap) divides the rounding error of two n-term dot products by the gap of a
-    # numerically repeated pair (1e-7 at epsilon = 1e-8): ANY change of summation order moves df/dx by
-    # |d xi| * |dAdx(phi_j, phi_i)| (the reference's own result moves by 1e-8 under such a change:
-    # tests/test_oracle_harness_golden.py::test_g3_noise_floor_of_the_repeated_branch).  The device result is held to
-    # 1e-8 plus exactly that first-order term of the measured xi / eta differences, and those to the dot-product bound.
-    slack = np.zeros(el.nelems)
-    lam_r, Phi_r = g["lam"], g["Phi"]
-    for i in ref_data:
-        for (j, xi, eta), (_, xir, etar) in zip(data[i], ref_data[i]):
-            gap = abs(lam_r[j] - lam_r[i])
-            dot_noise = 64 * np.finfo(float).eps * (np.linalg.norm(Phi_r[:, j]) * np.linalg.norm(g["Qb"][:, i])
-                                                     + np.linalg.norm(Phi_r[:, i]) * np.linalg.norm(g["Qb"][:, j]))
-            assert abs(xi - xir) * gap <= dot_noise
-            assert abs(eta - etar) * gap <= dot_noise * max(abs(lam_r[i]), abs(lam_r[j]), 1.0)
-            slack += abs(xi - xir) * np.abs(dAdx(Phi_r[:, [j]], Phi_r[:, [i]])) + abs(eta - etar) * np.abs(dBdx(Phi_r[:, [j]], Phi_r[:, [i]]))
-    assert np.linalg.norm(rhoEb2 - g["rhoEb"]) <= TOL * np.linalg.norm(g["rhoEb"]) + np.linalg.norm(slack)
-    assert relerr(rhoEb2, g["rhoEb"]) < 1e-7
+    # numerically repeated pair (1e-7 at epsilon = 1e-8).  The device forms the entries of repeated pairs with
+    # compensated dot products (eigd_coldot_dd) and xi, eta in extended precision: its own xi / eta carry no rounding of
+    # that kind, what is left against the reference is the reference's own noise (1.4e-9 of df/dx under a change of
+    # summation order: tests/test_oracle_harness_golden.py::test_g3_noise_floor_of_the_repeated_branch).  Plain 1e-8.
+    assert relerr(rhoEb2, g["rhoEb"]) < TOL
     flt = design.NodeFilter(g["conn"], g["X"], r0=float(g["r0"]), dvmap=g["dvmap"], num_design_vars=int(g["num_design_vars"]),
                             ctx=ctx)
     xb = flt.apply_gradient_device(design.element_average(ctx, g["conn"], el.nnodes).apply_t(ctx.from_host(rhoEb_x))).get()[:, 0]
@@ -368,12 +357,12 @@ def test_g2_natural_frequency_from_the_design_variables(solver):
     assert relerr(out["xb"], g["xb"]) < TOL
 
 
-@pytest.mark.parametrize("name,tol", [("g3_thermal32_eps1e-1_basiclanczos", 1e-8), ("g3_thermal32_eps1e-8_basiclanczos", 1e-7),
-                                      ("g3_thermal32_eps1e-8_iram", 1e-7)])
+@pytest.mark.parametrize("name,tol", [("g3_thermal32_eps1e-1_basiclanczos", 1e-8), ("g3_thermal32_eps1e-8_basiclanczos", 1e-8),
+                                      ("g3_thermal32_eps1e-8_iram", 1e-8)])
 def test_g3_thermal_from_the_design_variables(name, tol):
     """examples/thermal.py end to end on the device (1 dof / node, K and M both design dependent): compliance value and
-    df/dx against the reference.  epsilon = 1e-8: the repeated-pair terms carry the 1e-8-level noise of xi / eta
-    (test_g3_thermal_repeated_branch_rhoEb) -- held to 1e-7 here, where nothing of the reference's eigen data is adopted."""
+    df/dx against the reference, nothing of the reference's eigen data adopted.  epsilon = 1e-8: xi / eta of the repeated
+    pairs come from compensated dot products (test_g3_thermal_repeated_branch_rhoEb): 1e-8 like everything else."""
     from eigd_amd import design
     from eigd_amd.device import default_context
 

@@ -106,6 +106,43 @@ def test_column_kernels(ctx, n, k):
     assert relerr(dX.get(), 2.0 * X + Y) < 1e-15
 
 
+@pytest.mark.parametrize("n,k", [(1, 1), (1000, 3), (40001, 6), (7001, 64)])
+def test_compensated_column_dots_are_exact_to_rounding(ctx, n, k):
+    """
+    eigd_coldot_dd (the entries of G = -Phi^T Phib of numerically repeated pairs, reference 373-383): hi + lo against the
+    exactly rounded sum (math.fsum over error-free products), on ill-conditioned data -- a huge cancelling pair inside
+    each column makes a plain dot product lose ten digits.
+    """
+    import math
+
+    rng = np.random.default_rng(3 * n + k)
+    X, Y = rng.normal(size=(n, k)), rng.normal(size=(n, k))
+    if n > 2:
+        X[0], Y[0] = 1e10, 1.0 + rng.uniform(size=k)
+        X[n // 2], Y[n // 2] = -1e10, Y[0]                       # cancels row 0 exactly in exact arithmetic
+    hi, lo = ctx.from_host(X).coldot_dd(ctx.from_host(Y))
+
+    def two_prod_terms(x, y):
+        # Veltkamp / Dekker: x*y = p + e exactly, in pure Python floats
+        out = []
+        for a, b in zip(x.tolist(), y.tolist()):
+            p = a * b
+            sa = a * 134217729.0
+            ah = sa - (sa - a)
+            al = a - ah
+            sb = b * 134217729.0
+            bh = sb - (sb - b)
+            bl = b - bh
+            out += [p, ((ah * bh - p) + ah * bl + al * bh) + al * bl]
+        return out
+
+    for c in range(k):
+        exact = math.fsum(two_prod_terms(X[:, c], Y[:, c]))
+        scale = float(np.abs(X[:, c] * Y[:, c]).sum())
+        assert abs((hi[c] + lo[c]) - exact) <= 2 * np.finfo(float).eps * abs(exact) + 1e-28 * scale
+        assert abs(lo[c]) <= np.finfo(float).eps * abs(hi[c]) + 1e-300
+
+
 @pytest.mark.parametrize("n,ku,kx", [(3000, 1, 1), (20011, 6, 6), (70001, 32, 32), (5003, 13, 64), (9001, 64, 5), (3001, 70, 33)])
 def test_tall_skinny_products_and_projection(ctx, n, ku, kx):
     rng = np.random.default_rng(ku * 100 + kx)

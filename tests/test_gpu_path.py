@@ -105,16 +105,28 @@ def test_g3_repeated_eigenvalue_index_sets(name):
     assert index_sets(data) == index_sets(ref)                     # bit-exact index sets
     if "eps1e-8" in name:
         assert index_sets(data) == {1: [2], 2: [1], 4: [5], 5: [4], 6: [7], 7: [6]}
-    # xi, eta divide O(1e-16 |G|) differences by the gap of a numerically repeated pair (1e-7 here):
-    # they are pinned through the well-conditioned products xi * gap, eta * gap
-    lam = g["lam"]
-    gscale = np.abs(g["Phi"].T @ g["Qb"]).max()
+    # xi, eta divide the difference of two n-term dot products by the gap of a numerically repeated pair (1e-7 here).
+    # The device forms those entries with compensated dot products and xi, eta in extended precision: held against the
+    # EXACT rational value computed from the same inputs (a plain double dot product misses this gate by 10-100x), and
+    # against the reference's own floating-point value within the rounding of ITS dot products.
+    from fractions import Fraction
+
+    def exact_dot(x, y):
+        return sum(Fraction(a) * Fraction(b) for a, b in zip(x.tolist(), y.tolist()))
+
+    lam, Phi_r, Qb = g["lam"], g["Phi"], g["Qb"]
+    eps = np.finfo(float).eps
     for i in ref:
         for (j, xi, eta), (jr, xir, etar) in zip(data[i], ref[i]):
-            gap = abs(lam[j] - lam[i])
-            assert abs(xi - xir) * gap <= 1e-12 * max(1.0, gscale)
-            assert abs(eta - etar) * gap <= 1e-12 * max(1.0, gscale) * max(1.0, abs(lam[i]))
-            assert abs(xi - xir) <= 1e-4 * max(1.0, abs(xir))
+            gap = lam[j] - lam[i]
+            gji, gij = -exact_dot(Phi_r[:, j], Qb[:, i]), -exact_dot(Phi_r[:, i], Qb[:, j])
+            xi_x = float(Fraction(1, 2) * (gji - gij) / Fraction(gap))
+            eta_x = float(Fraction(1, 2) * (Fraction(lam[i]) * gji - Fraction(lam[j]) * gij) / Fraction(gap))
+            norms = np.linalg.norm(Phi_r[:, j]) * np.linalg.norm(Qb[:, i]) + np.linalg.norm(Phi_r[:, i]) * np.linalg.norm(Qb[:, j])
+            floor = 1e-2 * eps * norms / abs(gap)            # 100x below what one rounding of a plain dot product costs
+            assert abs(xi - xi_x) <= 1e-10 * abs(xi_x) + floor
+            assert abs(eta - eta_x) <= 1e-10 * abs(eta_x) + floor * max(1.0, abs(lam[i]))
+            assert abs(xi - xir) * abs(gap) <= 64 * eps * norms     # the reference's value: inside its own dot-product rounding
     assert relerr(psi, g["psi"]) < RTOL
     res, ortho = s.eval_adjoint_residual_norm(g["Qb"], psi, b_ortho=True)
     assert np.allclose(res, g["res_bortho"], atol=1e-9)
