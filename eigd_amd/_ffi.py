@@ -44,6 +44,10 @@ _SIGNATURES = {
     "eigd_h2d": [c_vp, c_vp, c_vp, c_sz],
     "eigd_d2h": [c_vp, c_vp, c_vp, c_sz],
     "eigd_d2d": [c_vp, c_vp, c_vp, c_sz],
+    "eigd_host_alloc": [c_sz, P(c_vp)],
+    "eigd_host_free": [c_vp],
+    "eigd_host_register": [c_vp, c_sz],
+    "eigd_host_unregister": [c_vp],
     "eigd_mem_info": [c_vp, P(c_sz), P(c_sz)],
     "eigd_timer_start": [c_vp],
     "eigd_timer_stop_ms": [c_vp, P(c_dbl)],

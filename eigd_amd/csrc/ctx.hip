@@ -146,6 +146,36 @@ int eigd_d2h(eigd_ctx* ctx, void* hdst, const void* dptr, size_t bytes) {
   return EIGD_OK;
 }
 
+// Page-locked host memory for the numpy-facing call surface (reference callers hand numpy arrays to solve_adjoint /
+// add_total_derivative and get numpy arrays back, eigenvector_derivatives.py:1988-2134, 2167-2207): a copy from or to
+// pageable memory is staged by the runtime at roughly half the PCIe rate; eigd_h2d / eigd_d2h take the direct DMA path
+// by themselves when the host pointer is page-locked.
+int eigd_host_alloc(size_t bytes, void** hptr) {
+  EIGD_REQUIRE(hptr != nullptr, "hptr is null");
+  *hptr = nullptr;
+  if (bytes == 0) bytes = 8;
+  EIGD_HIP(hipHostMalloc(hptr, bytes, hipHostMallocPortable));
+  return EIGD_OK;
+}
+
+int eigd_host_free(void* hptr) {
+  if (!hptr) return EIGD_OK;
+  EIGD_HIP(hipHostFree(hptr));
+  return EIGD_OK;
+}
+
+int eigd_host_register(void* hptr, size_t bytes) {
+  EIGD_REQUIRE(hptr != nullptr && bytes > 0, "null or empty host range");
+  EIGD_HIP(hipHostRegister(hptr, bytes, hipHostRegisterPortable));
+  return EIGD_OK;
+}
+
+int eigd_host_unregister(void* hptr) {
+  EIGD_REQUIRE(hptr != nullptr, "hptr is null");
+  EIGD_HIP(hipHostUnregister(hptr));
+  return EIGD_OK;
+}
+
 int eigd_d2d(eigd_ctx* ctx, void* ddst, const void* dsrc, size_t bytes) {
   EIGD_REQUIRE(ctx && ddst && dsrc, "null argument");
   EIGD_HIP(hipMemcpyAsync(ddst, dsrc, bytes, hipMemcpyDeviceToDevice, ctx->stream));

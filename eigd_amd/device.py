@@ -71,7 +71,10 @@ class Context:
         return b
 
     def from_host(self, a):
+        src = a
         a = np.ascontiguousarray(a, dtype=np.float64)
+        if a is src:
+            _pinned.note_source(a)      # the caller's own buffer (no conversion copy): worth page-locking if it comes again
         if a.ndim == 1:
             b = DeviceBlock(self, a.shape[0], 1)
         elif a.ndim == 2:
@@ -129,6 +132,102 @@ def default_context():
         call("eigd_device_count", C.byref(cnt))
         _default_ctx = Context(dev % max(cnt.value, 1))
     return _default_ctx
+
+
+# ---------------------------------------------------------------------------
+# page-locked host memory for the numpy call surface
+# ---------------------------------------------------------------------------
+_PIN_MIN_BYTES = 1 << 20             # smaller blocks: the staging of a pageable copy costs nothing that matters
+_PIN_POOL_MAX_BYTES = 8 * 1024**3    # released result buffers kept for reuse (a step returns the same shapes again)
+_PIN_KEEP_PER_SIZE = 3
+
+
+class _PinnedHost:
+    """
+    Results that go back to the caller as numpy arrays (``DeviceBlock.get``) live in page-locked memory: the D2H copy
+    runs at the direct-DMA rate instead of being staged through the runtime's bounce buffers, the pages are not
+    first-touched by the copy, and when the caller hands the same array back (psi from ``solve_adjoint`` into
+    ``add_total_derivative``) the H2D copy is a direct DMA as well.  The buffer returns to a pool when the last numpy
+    view of it dies.  Arrays the caller allocated itself are page-locked in place (hipHostRegister) from the second time
+    the same buffer arrives -- the right-hand sides of a design loop are handed in again every step -- and released when
+    the array is garbage collected.
+    """
+
+    def __init__(self):
+        self.free = {}            # nbytes -> [host pointers]
+        self.held = 0
+        self.seen = {}            # (address, nbytes) -> sightings of a caller-owned buffer
+        self.registered = {}      # address -> nbytes
+
+    def empty(self, shape):
+        import weakref
+
+        nbytes = int(np.prod(shape)) * 8
+        lst = self.free.get(nbytes)
+        if lst:
+            ptr = lst.pop()
+            self.held -= nbytes
+        else:
+            h = c_vp()
+            try:
+                call("eigd_host_alloc", nbytes, C.byref(h))
+            except _ffi.EigdHipError:
+                return np.empty(shape)                     # no page-locked memory left: an ordinary array
+            ptr = h.value
+        buf = (C.c_char * nbytes).from_address(ptr)
+        fin = weakref.finalize(buf, self._release, ptr, nbytes)  # fires when the last view of the array is gone
+        fin.atexit = False                                  # (at interpreter exit the process gives the memory back)
+        return np.frombuffer(buf, dtype=np.float64).reshape(shape)
+
+    def _release(self, ptr, nbytes):
+        lst = self.free.setdefault(nbytes, [])
+        if len(lst) < _PIN_KEEP_PER_SIZE and self.held + nbytes <= _PIN_POOL_MAX_BYTES:
+            lst.append(ptr)
+            self.held += nbytes
+        else:
+            try:
+                _ffi.lib().eigd_host_free(c_vp(ptr))
+            except Exception:
+                pass
+
+    def note_source(self, a):
+        """a large caller-owned array is about to be uploaded: page-lock it in place from its second upload on"""
+        import weakref
+
+        if a.nbytes < _PIN_MIN_BYTES or not a.flags.owndata:
+            return
+        addr = a.ctypes.data
+        if addr in self.registered:
+            return
+        key = (addr, a.nbytes)
+        self.seen[key] = self.seen.get(key, 0) + 1
+        if self.seen[key] < 2:
+            if len(self.seen) > 64:
+                self.seen.clear()
+            return
+        try:
+            call("eigd_host_register", c_vp(addr), a.nbytes)
+        except (_ffi.EigdHipError, ValueError):
+            self.seen[key] = -(1 << 30)                    # (cannot be locked: do not try again)
+            return
+        self.registered[addr] = a.nbytes
+        self.seen.pop(key, None)
+        weakref.finalize(a, self._unregister, addr).atexit = False
+
+    def _unregister(self, addr):
+        if self.registered.pop(addr, None) is not None:
+            try:
+                _ffi.lib().eigd_host_unregister(c_vp(addr))
+            except Exception:
+                pass
+
+
+_pinned = _PinnedHost()
+
+
+def pinned_empty(shape):
+    """numpy float64 array in page-locked memory (uploads and downloads of it run at the direct-DMA rate)"""
+    return _pinned.empty(tuple(int(v) for v in np.atleast_1d(shape)))
 
 
 _POOL_KEEP_PER_SIZE = 6           # blocks of one size kept for reuse
@@ -216,8 +315,9 @@ class DeviceBlock:
 
     def get(self):
         if self.ld == self.k:
-            out = np.empty((self.n, self.k))
-            call("eigd_d2h", self.ctx.h, hptr(out), self.ptr, 8 * self.n * self.k)
+            nbytes = 8 * self.n * self.k
+            out = _pinned.empty((self.n, self.k)) if nbytes >= _PIN_MIN_BYTES else np.empty((self.n, self.k))
+            call("eigd_d2h", self.ctx.h, hptr(out), self.ptr, nbytes)
             return out
         tmp = self.ctx.empty(self.n, self.k)
         tmp.copy_from(self)

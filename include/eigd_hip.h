@@ -63,6 +63,13 @@ int eigd_memset(eigd_ctx* ctx, void* dptr, int value, size_t bytes);
 int eigd_h2d(eigd_ctx* ctx, void* dptr, const void* hsrc, size_t bytes);
 int eigd_d2h(eigd_ctx* ctx, void* hdst, const void* dptr, size_t bytes);
 int eigd_d2d(eigd_ctx* ctx, void* ddst, const void* dsrc, size_t bytes);
+/* page-locked host memory for callers that keep the reference's numpy call surface (solve_adjoint(Phib) -> psi,
+ * add_total_derivative(..., psi, ...), 1988-2134 / 2167-2207): eigd_h2d / eigd_d2h run at the direct-DMA rate when the
+ * host pointer was obtained from eigd_host_alloc or covered by eigd_host_register */
+int eigd_host_alloc(size_t bytes, void** hptr);
+int eigd_host_free(void* hptr);
+int eigd_host_register(void* hptr, size_t bytes);
+int eigd_host_unregister(void* hptr);
 int eigd_mem_info(eigd_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* HIP-event stopwatch on the ctx stream (bench.py roofline timing) */
 int eigd_timer_start(eigd_ctx* ctx);

@@ -106,6 +106,50 @@ def test_column_kernels(ctx, n, k):
     assert relerr(dX.get(), 2.0 * X + Y) < 1e-15
 
 
+def test_numpy_surface_uses_page_locked_memory(ctx):
+    """
+    Large results come back in page-locked memory that outlives the device block and returns to a pool with the last
+    view; a caller-owned array is page-locked in place from its second upload and released with the array; values are
+    those of the plain copies.
+    """
+    import gc
+
+    from eigd_amd import device as dv
+
+    rng = np.random.default_rng(5)
+    n, k = 70000, 8                                      # 4.5 MB: above the threshold
+    X = rng.normal(size=(n, k))
+    blk = ctx.from_host(X)
+    out = blk.get()
+    assert not out.flags.owndata and out.flags.writeable and np.array_equal(out, X)
+    view = out[:, 2:5]
+    del blk, out
+    gc.collect()
+    assert np.array_equal(view, X[:, 2:5])               # the buffer lives as long as any view of it
+    held0 = dv._pinned.held
+    del view
+    gc.collect()
+    assert dv._pinned.held == held0 + 8 * n * k          # back in the pool
+    again = ctx.from_host(X).get()                       # ... and handed out again
+    assert dv._pinned.held == held0 and np.array_equal(again, X)
+    back = ctx.from_host(again)                          # a page-locked array as the source of an upload
+    assert np.array_equal(back.get(), X)
+    # caller-owned buffer: registered at the second sighting, unregistered when it dies
+    addr = X.ctypes.data
+    assert addr not in dv._pinned.registered
+    ctx.from_host(X)
+    assert addr in dv._pinned.registered
+    assert np.array_equal(ctx.from_host(X).get(), X)
+    del X
+    gc.collect()
+    assert addr not in dv._pinned.registered
+    small = ctx.from_host(rng.normal(size=(100, 3))).get()
+    assert small.flags.owndata                            # small blocks stay ordinary arrays
+    P = dv.pinned_empty((1 << 18, 2))
+    P[:] = 1.5
+    assert np.array_equal(ctx.from_host(P).get(), P)
+
+
 @pytest.mark.parametrize("n,k", [(1, 1), (1000, 3), (40001, 6), (7001, 64)])
 def test_compensated_column_dots_are_exact_to_rounding(ctx, n, k):
     """
