@@ -135,12 +135,14 @@ def test_numpy_surface_uses_page_locked_memory(ctx):
     back = ctx.from_host(again)                          # a page-locked array as the source of an upload
     assert np.array_equal(back.get(), X)
     # caller-owned buffer: registered at the second sighting, unregistered when it dies
-    addr = X.ctypes.data
+    Xc = rng.normal(size=(n, k))
+    addr = Xc.ctypes.data
+    ctx.from_host(Xc)
     assert addr not in dv._pinned.registered
-    ctx.from_host(X)
+    ctx.from_host(Xc)
     assert addr in dv._pinned.registered
-    assert np.array_equal(ctx.from_host(X).get(), X)
-    del X
+    assert np.array_equal(ctx.from_host(Xc).get(), Xc)
+    del Xc
     gc.collect()
     assert addr not in dv._pinned.registered
     small = ctx.from_host(rng.normal(size=(100, 3))).get()
