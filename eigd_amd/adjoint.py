@@ -53,6 +53,11 @@ class DeviceProblem:
         self.n = self.opB.shape[0]
         self.Phi = None
         self.BPhi = None
+        # converged eigenpairs beyond the N requested ones (from the eigensolver's basis): the projected Krylov solvers
+        # may deflate them as well -- [Phi | Phix] in the projectors -- and add their share of psi in closed form
+        self.Phix = self.BPhix = self.lam_x = None
+        self.PhiD = self.BPhiD = None
+        self.use_extra = False
 
     def on(self, ctx):
         """the same problem (shared device data) with work enqueued on another context / stream of the device"""
@@ -65,18 +70,57 @@ class DeviceProblem:
     def set_phi(self, Phi_host=None, Phi_dev=None):
         self.Phi = Phi_dev if Phi_dev is not None else self.ctx.from_host(Phi_host)
         self.BPhi = self.opB.apply(self.Phi)
+        self._rebuild_deflation()
+
+    def set_extra(self, Phix_dev, lam_x):
+        """eigenvectors (B-orthonormal, B-orthogonal to Phi) and eigenvalues of further converged pairs; None clears"""
+        self.Phix, self.lam_x = Phix_dev, (None if lam_x is None else np.asarray(lam_x, dtype=float))
+        self.BPhix = None if Phix_dev is None else self.opB.apply(Phix_dev)
+        self._rebuild_deflation()
+
+    def _rebuild_deflation(self):
+        self.PhiD = self.BPhiD = None
+        if self.Phix is None or self.Phi is None or self.Phix.k == 0:
+            return
+        # the caller may have replaced Phi (signs, rotations inside a cluster, another set altogether): the extra vectors
+        # stay in use only while they are B-orthogonal to it
+        if np.max(np.abs(self.BPhix.tdot(self.Phi))) > 1e-9:
+            return
+        N, nx = self.Phi.k, self.Phix.k
+        self.PhiD, self.BPhiD = self.ctx.empty(self.n, N + nx), self.ctx.empty(self.n, N + nx)
+        for dst, a, b in ((self.PhiD, self.Phi, self.Phix), (self.BPhiD, self.BPhi, self.BPhix)):
+            dst.cols(0, N).copy_from(a)
+            dst.cols(N, N + nx).copy_from(b)
+
+    def _projector(self):
+        if self.use_extra and self.PhiD is not None:
+            return self.BPhiD, self.PhiD
+        return self.BPhi, self.Phi
 
     def project_r(self, X):
         """X <- X - BPhi (Phi^T X)   (residual-side projector P)"""
-        return X.project(self.BPhi, self.Phi)
+        U, V = self._projector()
+        return X.project(U, V)
 
     def project_r_norm2(self, X):
         """project_r followed by the squared column norms of the result (device block; see DeviceBlock.project_norm2)"""
-        return X.project_norm2(self.BPhi, self.Phi)
+        U, V = self._projector()
+        return X.project_norm2(U, V)
 
     def project_s(self, X):
         """X <- X - Phi (BPhi^T X)   (solution-side projector P^T)"""
-        return X.project(self.Phi, self.BPhi)
+        U, V = self._projector()
+        return X.project(V, U)
+
+    def extra_correction_coefficients(self, dPhib, lam):
+        """
+        Share of psi along the extra eigenvectors, in closed form as for the pairs j <= N of reference 385-389:
+        psi_i += phi_j G0[j, i] / (lam_j - lam_i) with G = -Phix^T Phib (buckling: G0 = diag(lam_x) G).  nx x N.
+        """
+        Gx = -self.Phix.tdot(dPhib)
+        if self.mode != "normal":
+            Gx = self.lam_x[:, None] * Gx
+        return Gx / (self.lam_x[:, None] - np.asarray(lam, dtype=float)[None, :])
 
     def adjoint_operator(self, X, lam_cols, out=None):
         """(A - lam B) X or (B + lam A) X, column-wise lam"""

@@ -190,6 +190,209 @@ class _LanczosDevice:
         return np.ascontiguousarray(Vt.T)
 
 
+def _svqb(gram):
+    """
+    Orthonormalising transform of a block from its Gram matrix (Stathopoulos & Wu's SVQB): gram = U diag(w) U^T,
+    X U diag(w)^-1/2 is orthonormal and X = (X U w^-1/2) C with C = diag(w)^1/2 U^T.  Returns (transform, C, rank
+    deficient flags): directions whose eigenvalue is below 1e-28 of the largest carry nothing but rounding.
+    """
+    d = np.sqrt(np.maximum(np.diag(gram), np.finfo(float).tiny))
+    w, U = np.linalg.eigh(gram / np.outer(d, d))           # scaled: equilibrates columns of very different length
+    bad = w <= 1e-28 * max(w.max(), np.finfo(float).tiny)
+    wi = np.where(bad, 1.0, w)
+    Tr = (U / np.sqrt(wi)) / d[:, None]
+    C = (np.sqrt(wi)[:, None] * U.T) * d[None, :]
+    C[bad, :] = 0.0
+    return Tr, C, bad
+
+
+def ritz_bounds(C_last, S, p):
+    """residual norms of the Ritz pairs of a block Lanczos basis: |C S[last p rows, j]|"""
+    return np.linalg.norm(C_last @ S[-p:, :], axis=0)
+
+
+def arpack_converged(bounds, theta, tol, beta_scale):
+    """
+    ARPACK's test (dsconv): bound_i <= tol * max(eps^(2/3), |theta_i|).  The bounds are the coupling block times the
+    last components of the eigenvectors of T, which LAPACK delivers with ABSOLUTE accuracy eps: below ~eps * |coupling|
+    a computed bound is rounding noise (with tol = eps the test would never be met for a cluster of Ritz values), so
+    that level counts as converged -- but never more than the value's own size allows: the floor of pair i is
+    64 eps max(|coupling|, |theta_i|), not the largest Ritz value's.
+    """
+    eps = np.finfo(float).eps
+    floor = 64.0 * eps * np.maximum(abs(beta_scale), np.abs(theta))
+    return bounds <= np.maximum(tol * np.maximum(eps ** (2.0 / 3.0), np.abs(theta)), floor)
+
+
+def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=None):
+    """
+    Thick-restart Lanczos with blocks of p vectors on the operator the backend ``be`` applies (shift-invert, B inner
+    product), full reorthogonalisation.  p = 1 is the single-vector thick-restart Lanczos (= ARPACK's implicitly
+    restarted Lanczos with exact shifts, in its explicit form).
+
+    Backend (device: _BlockLanczosDevice; a numpy twin lives in the CPU tests):
+        be.expand(c, p) -> (H (c x p), C (p x p)): W = OP basis[:, c-p:c], orthogonalised against basis[:, :c] with
+                           coefficients H, W' = Q C with Q B-orthonormal, stored as basis[:, c:c+p]
+        be.restart(S, c, keep, p): basis[:, :keep] = basis[:, :c] S, basis[:, keep:keep+p] = basis[:, c:c+p]
+    The basis holds p start vectors when this is called.  Returns (T (c x c), C_last, c, nconv, n_restarts): the
+    projected matrix of the final basis of c vectors, the coupling to the residual block basis[:, c:c+p] --
+    OP basis[:, :c] = basis[:, :c] T + basis[:, c:c+p] C_last E_last^T -- and how many of the k_want wanted
+    (largest |theta|) Ritz pairs pass ARPACK's test.
+    """
+    c = p
+    T = np.zeros((m_int, m_int))
+    n_restarts = 0
+    while True:
+        while True:
+            H, C = be.expand(c, p)
+            T[:c, c - p:c] = H
+            T[c - p:c, :c] = H.T
+            T[c - p:c, c - p:c] = 0.5 * (H[c - p:, :] + H[c - p:, :].T)
+            if c + p > m_int:
+                break
+            T[c:c + p, c - p:c] = C
+            T[c - p:c, c:c + p] = C.T
+            c += p
+        theta, S = np.linalg.eigh(T[:c, :c])
+        bounds = ritz_bounds(C, S, p)
+        order = np.argsort(-np.abs(theta))              # which = "LM"
+        wanted = order[:k_want]
+        conv = arpack_converged(bounds[wanted], theta[wanted], tol, np.linalg.norm(C, 2))
+        nconv = int(np.count_nonzero(conv))
+        if trace is not None:
+            trace(n_restarts, nconv, k_want, float(np.max(bounds[wanted] / np.abs(theta[wanted]))))
+        if nconv >= k_want or n_restarts >= max_restarts:
+            return T[:c, :c].copy(), C, c, nconv, n_restarts
+        # thick restart: the wanted pairs plus part of the unwanted ones as ARPACK's dsaup2 does (more of them as more
+        # have converged); a whole number of blocks has to fit behind the kept vectors
+        keep = k_want + min(nconv, (c - k_want) // 2)
+        keep = max(min(keep, c - p), min(k_want + 1, c - p))
+        keep = max(c - p * (-(-(c - keep) // p)), 1)
+        selk = order[:keep]
+        selk = selk[np.argsort(-theta[selk])]
+        be.restart(S[:, selk], c, keep, p)
+        T[:, :] = 0.0
+        T[np.arange(keep), np.arange(keep)] = theta[selk]
+        # (the next expansion recomputes the block column behind the kept vectors in full -- arrow + diagonal block --
+        # by Gram-Schmidt)
+        c = keep + p
+        n_restarts += 1
+
+
+def compress_to_single_vector_basis(be, T, C, c, p, m, tol):
+    """
+    The contract of the reference's IRAM (what eigsh_mod extracts from ARPACK's work arrays and laa uses) is
+    a basis of exactly m vectors with a rank-ONE residual, OP V = V T + f e_m^T.  A block run ends with a residual of
+    rank p and a basis of another size: keep the converged Ritz vectors (their residuals vanish to rounding, so any
+    basis that holds them satisfies the relation in their columns), put one vector of the residual block behind them
+    and finish with single-vector Lanczos steps up to m.  Returns (T (m x m), beta_m).
+    """
+    theta, S = np.linalg.eigh(T)
+    bounds = ritz_bounds(C, S, p)
+    ok = arpack_converged(bounds, theta, tol, np.linalg.norm(C, 2))
+    sel = np.flatnonzero(ok)
+    sel = sel[np.argsort(-np.abs(theta[sel]))][: m - 1]
+    sel = sel[np.argsort(-theta[sel])]
+    kc = len(sel)
+    be.restart(S[:, sel], c, kc, 1)
+    Tm = np.zeros((m, m))
+    Tm[np.arange(kc), np.arange(kc)] = theta[sel]
+    cc = kc + 1
+    beta = 0.0
+    while True:
+        H, Cb = be.expand(cc, 1)
+        Tm[:cc, cc - 1] = H[:, 0]
+        Tm[cc - 1, :cc] = H[:, 0]
+        if cc == m:
+            beta = float(Cb[0, 0])
+            break
+        Tm[cc, cc - 1] = Tm[cc - 1, cc] = Cb[0, 0]
+        cc += 1
+    return Tm, beta
+
+
+class _BlockLanczosDevice(_LanczosDevice):
+    """device backend of thick_restart_block_lanczos: the basis V and B V as k=1 stacks, blocks as n x p row-major"""
+
+    def __init__(self, prob, nvec):
+        super().__init__(prob, nvec)
+        self.scratch = None
+        self.sweeps = 0
+        self.reorth_passes = 0
+
+    def _block_from(self, st, j0, p):
+        """n x p row-major copy of slabs [j0, j0+p) of a k=1 stack"""
+        X = self.ctx.empty(self.n, p)
+        adj._StackView(st, j0).times_into(X, np.eye(p), ns=p)
+        return X
+
+    def _store(self, X, st, j0):
+        for q in range(X.k):
+            st[j0 + q].copy_from(X.cols(q, q + 1))
+
+    def _orthonormalise(self, X):
+        """B-orthonormalise the block in place (SVQB, twice); returns (B X, C) with X_in = X_out C"""
+        p = X.k
+        Ctot = np.eye(p)
+        BX = None
+        for _ in range(2):
+            BX = self.prob.opB.apply(X)
+            gram = X.tdot(BX)
+            gram = 0.5 * (gram + gram.T)
+            Tr, C, bad = _svqb(gram)
+            if bad.any():
+                raise np.linalg.LinAlgError("Lanczos breakdown: the new block is linearly dependent on the basis "
+                                            "(an invariant subspace was found)")
+            Xn = self.ctx.empty(self.n, p).add_product(X, Tr, alpha=1.0, beta=0.0)
+            X.copy_from(Xn)
+            Ctot = C @ Ctot
+        BX = self.prob.opB.apply(X)
+        return BX, Ctot
+
+    def start(self, V0):
+        X = self.ctx.from_host(V0)
+        BX, _ = self._orthonormalise(X)
+        self._store(X, self.V, 0)
+        self._store(BX, self.BV, 0)
+
+    def expand(self, c, p):
+        X = self._block_from(self.BV, c - p, p)
+        self.prob.fac(X)                                  # W = factor(B V_last): one p-column sweep
+        self.sweeps += 1
+        H = self.BV.tdot_block(X, ns=c)
+        self.V.times_into(X, H, ns=c, alpha=-1.0, beta=1.0)
+        H2 = self.BV.tdot_block(X, ns=c)                   # what one pass left along the basis: measured ...
+        n1, n2 = np.linalg.norm(H, axis=0), np.linalg.norm(H2, axis=0)
+        if np.any(n2 > 1e-13 * np.maximum(n1, np.finfo(float).tiny)):
+            self.V.times_into(X, H2, ns=c, alpha=-1.0, beta=1.0)   # ... and removed where it matters
+            H = H + H2
+            self.reorth_passes += 1
+        BX, C = self._orthonormalise(X)
+        self._store(X, self.V, c)
+        self._store(BX, self.BV, c)
+        return H, C
+
+    def restart(self, S, c, keep, p):
+        ctx, n = self.ctx, self.n
+        if self.scratch is None or self.scratch[0].ns < self.V.ns:
+            self.scratch = (ctx.stack(self.V.ns, n, 1), ctx.stack(self.V.ns, n, 1))
+        for src, dst in zip((self.V, self.BV), self.scratch):
+            for a in range(0, keep, 64):                   # new basis = V S: one product per block of kept vectors
+                b = min(keep, a + 64)
+                blk = ctx.empty(n, b - a)
+                src.times_into(blk, S[:, a:b], ns=c)
+                for q in range(b - a):
+                    dst[a + q].copy_from(blk.cols(q, q + 1))
+            for q in range(p):
+                dst[keep + q].copy_from(src[c + q])
+        nV, nBV = self.scratch
+        from ._ffi import call
+
+        nbytes = 8 * n * (keep + p)
+        call("eigd_d2d", ctx.h, self.V.ptr, nV.ptr, nbytes)
+        call("eigd_d2d", ctx.h, self.BV.ptr, nBV.ptr, nbytes)
+
+
 class _AdjointAPI:
     """solve_adjoint / eval_adjoint_residual_norm / add_total_derivative (ref 1652-1870, 1988-2207)"""
 
@@ -214,6 +417,39 @@ class _AdjointAPI:
             nv = min(Vh.shape[1], self._dev.V.ns)
             Vt = np.ascontiguousarray(Vh[:, :nv].T)
             call("eigd_h2d", self._dev.ctx.h, self._dev.V.ptr, hptr(Vt), 8 * self._dev.n * nv)
+
+    n_extra = 0
+
+    def _set_extra_pairs(self, prob, dev, eigs, bounds, tol, beta_scale, m, extra_max, absolute_tol=None):
+        """
+        Ritz pairs of the final basis beyond the N requested ones, in the reference's sort order, that pass the
+        eigensolver's own convergence test (ARPACK's for IRAM, |beta y_last| < tol for BasicLanczos): handed to the
+        device problem for the adjoint stage's deflation.  None if the cut N | N+1 runs through a numerically repeated
+        cluster (the reference warns there; nothing is added to what it does).
+        """
+        import os
+
+        N = self.N
+        self.n_extra = 0
+        prob.set_extra(None, None)
+        if extra_max <= 0 or os.environ.get("EIGD_DEFLATE_EXTRA", "1") == "0":
+            return
+        idx = []
+        for q in range(N, min(N + extra_max, m)):
+            j = self.indices[q]
+            if absolute_tol is not None:
+                good = bounds[j] < absolute_tol
+            else:
+                good = bool(arpack_converged(bounds[j:j + 1], self.theta[j:j + 1], tol, beta_scale)[0])
+            if not good:
+                break
+            idx.append(j)
+        if not idx or _is_close(eigs[self.indices[N - 1]], eigs[idx[0]], self.eig_atol):
+            return
+        Phix = prob.ctx.empty(prob.n, len(idx))
+        dev.V.times_into(Phix, self.Y[:, idx], ns=m)
+        prob.set_extra(Phix, eigs[idx])
+        self.n_extra = len(idx)
 
     def _sync_phi(self):
         """the eigenvectors used by the adjoint stage are whatever self.Phi holds now"""
@@ -283,12 +519,25 @@ class _AdjointAPI:
                 raise TypeError(f"sibk() got unexpected keyword arguments {sorted(kw)}")
             G = -prob.Phi.tdot(dPhib)
             Glo = adj.refine_repeated_entries(G, lam, prob.Phi, dPhib, eig_atol)
-            if seq_sibk:
-                self.last_info = adj._sibk_sequential(prob, dPhib_c, psi_c, lam_c, self.sigma, rtol, atol, maxiter,
-                                                      bs_target, update_guess, callback, nrestart)
-            else:
-                self.last_info = adj._sibk_device(prob, dPhib_c, psi_c, lam_c, self.sigma, rtol, atol, maxiter,
-                                                  nrestart, callback, rnorm0=rnorm0, streams=streams)
+            # Converged eigenpairs beyond N (the eigensolver's basis holds some): deflated like the N requested ones --
+            # the projectors of 1193 / 1232 / 1250-1257 take [Phi | Phix] -- and their share of psi added in closed form
+            # below, as 385-389 does for j <= N.  psi is unique, the Krylov solve just no longer has to resolve the
+            # eigenvalues closest above lam_N, which are what makes the high modes slow.
+            prob.use_extra = prob.PhiD is not None
+            try:
+                if prob.use_extra:
+                    psi_c.project(prob.Phix, prob.BPhix)      # the guess gives up its share along Phix
+                if seq_sibk:
+                    self.last_info = adj._sibk_sequential(prob, dPhib_c, psi_c, lam_c, self.sigma, rtol, atol, maxiter,
+                                                          bs_target, update_guess, callback, nrestart)
+                else:
+                    self.last_info = adj._sibk_device(prob, dPhib_c, psi_c, lam_c, self.sigma, rtol, atol, maxiter,
+                                                      nrestart, callback, rnorm0=rnorm0, streams=streams)
+                if prob.use_extra:
+                    Cx = prob.extra_correction_coefficients(dPhib, lam)
+                    psi_c.add_product(prob.Phix, Cx if cols is None else Cx[:, cols], alpha=1.0, beta=1.0)
+            finally:
+                prob.use_extra = False
         elif method == "pgmres":
             maxiter = kw.pop("maxiter", 50)
             if kw:
@@ -483,6 +732,11 @@ class BasicLanczos(_AdjointAPI):
         prob.set_phi(Phi_dev=dPhi)
         self.Phi = dPhi.get()
         self._phi_token = self.Phi
+        # Ritz pairs beyond N that pass the solver's own test |beta y_last| < tol: deflated by the adjoint stage too
+        if self.tol > 0:
+            bounds = np.abs(self.beta[self.m - 1] * self.Y[self.m - 1, :])
+            self._set_extra_pairs(prob, dev, self.lam, bounds, None, None, self.m, max(0, min(self.N // 4, 64 - self.N)),
+                                  absolute_tol=self.tol)
         self._m = self.m
         self._nV = self.m_max + 1
         self._V_host = None
@@ -598,8 +852,9 @@ class IRAM(_AdjointAPI):
     ARPACK's convention (dsaupd).
     """
 
-    def __init__(self, N=10, m=None, eig_atol=1e-5, tol=0.0, mode="normal", maxiter=None, ctx=None):
+    def __init__(self, N=10, m=None, eig_atol=1e-5, tol=0.0, mode="normal", maxiter=None, ctx=None, extra=None):
         self.N = N
+        self.extra = extra   # converged eigenpairs beyond N kept for the adjoint stage's deflation (None: automatic)
         self.m = int(max(20, 2 * N + 1) if m is None else max(20, 2 * N + 1, m))
         self.tol = tol
         self.eig_atol = eig_atol
@@ -617,6 +872,29 @@ class IRAM(_AdjointAPI):
     def _warn_dl(self):
         warnings.warn('Adjoint method "dl" is not recommended for the ARPACK IRAM eigenvalue sovler.')
 
+    def _block_plan(self, n):
+        """
+        (block size p, extra pairs to converge, internal basis size).  A triangular sweep of 4-8 columns costs what a
+        one-column sweep costs (it is bound by the latency chain through the tree levels, not by bytes), so large
+        problems run the restarted Lanczos with blocks: several new basis vectors per sweep.  EIGD_IRAM_BLOCK /
+        EIGD_IRAM_EXTRA override (1 / 0 = the single-vector solver on exactly m vectors).
+        """
+        import os
+
+        N, m = self.N, self.m
+        p = int(os.environ.get("EIGD_IRAM_BLOCK", "0")) or (8 if n >= 200_000 else (4 if n >= 50_000 else 1))
+        extra = os.environ.get("EIGD_IRAM_EXTRA")
+        extra = int(extra) if extra is not None else (self.extra if self.extra is not None else (0 if p == 1 else N // 4))
+        extra = max(0, min(extra, m - 2 - N, 64 - N))   # room in the m-vector contract basis; one fused projector call
+        if p == 1:
+            return 1, extra, m
+        k_want = N + extra
+        m_int = max(m, 2 * k_want + p)
+        m_int = p * (-(-m_int // p))
+        if m_int + p > n:
+            return 1, min(extra, max(0, m - 2 - N)), m
+        return p, extra, m_int
+
     def solve(self, A, B, factor, sigma):
         n = _check_shapes(A, B, factor)
         if np.issubdtype(np.dtype(A.dtype), np.complexfloating):
@@ -631,79 +909,39 @@ class IRAM(_AdjointAPI):
         m, k = self.m, self.N
         if not (k < m <= n):
             raise ValueError("ncv must be k<ncv<=n")  # scipy's message for the same condition
-        dev = _LanczosDevice(prob, m + 1)
+        p, extra, m_int = self._block_plan(n)
+        k_want = k + extra
+        dev = _BlockLanczosDevice(prob, m_int + p)
         self._dev = dev
         eps = np.finfo(float).eps
         tol = self.tol if self.tol > 0 else eps
-        eps23 = eps ** (2.0 / 3.0)
-        maxiter = self.maxiter if self.maxiter is not None else 10 * n  # scipy's default for eigsh
+        max_restarts = self.maxiter if self.maxiter is not None else 10 * n  # scipy's default for eigsh
 
-        v0 = np.random.default_rng(12345).uniform(size=n, low=-1.0, high=1.0)
-        v = ctx.from_host(v0)
-        dev.normalize_into(v, 0)
-        T = np.zeros((m, m))
-        j0 = 0          # first step to run
-        beta_m = 0.0
-        self.n_restarts = 0
-        scratch = None
-        while True:
-            for j in range(j0, m):
-                dev.apply_op(j, v)
-                h = dev.orthogonalize(v, j + 1)
-                T[: j + 1, j] = h
-                T[j, : j + 1] = h
-                beta = dev.normalize_into(v, j + 1)
-                if j + 1 < m:
-                    T[j + 1, j] = T[j, j + 1] = beta
-                else:
-                    beta_m = beta
-            # keep exactly the structure the recurrence implies: entries above the arrow/tridiagonal are round-off
-            theta, S = np.linalg.eigh(T)
-            order = np.argsort(-np.abs(theta))          # which = "LM"
-            bounds = np.abs(beta_m * S[m - 1, :])
-            wanted = order[:k]
-            # ARPACK's test (dsconv): bound_i <= tol * max(eps^(2/3), |theta_i|).  The bounds are beta_m times the last
-            # components of the eigenvectors of T, which LAPACK delivers with ABSOLUTE accuracy eps: below
-            # ~eps * beta_m the computed bound is rounding noise (it hovers at 1e-15..1e-14 |theta| and a tol of eps is
-            # never met for all of 64 clustered Ritz values), so that level counts as converged
-            floor = 64.0 * eps * max(abs(beta_m), np.max(np.abs(theta)))
-            conv = bounds[wanted] <= np.maximum(tol * np.maximum(eps23, np.abs(theta[wanted])), floor)
-            nconv = int(np.count_nonzero(conv))
+        V0 = np.random.default_rng(12345).uniform(size=(n, p), low=-1.0, high=1.0)
+        dev.start(V0)
+
+        def trace(r, nconv, kw, worst):
             if _TRACE:
-                print(f"[iram] restart {self.n_restarts}: {nconv}/{k} converged, worst bound / |theta| "
-                      f"{np.max(bounds[wanted] / np.abs(theta[wanted])):.2e}", flush=True)
-            if nconv >= k or self.n_restarts >= maxiter:
-                break
-            # thick restart: keep the wanted pairs plus part of the converged unwanted ones (ARPACK dsaup2)
-            keep = min(k + min(nconv, (m - k) // 2), m - 1)
-            keep = max(keep, min(k + 1, m - 1))
-            selk = order[:keep]
-            selk = selk[np.argsort(-theta[selk])]
-            Sk = S[:, selk]
-            if scratch is None:
-                scratch = (ctx.stack(m, n, 1), ctx.stack(m, n, 1))
-            nV, nBV = scratch
-            # new basis = V S_k (column-major k=1 stacks): one product per kept vector block
-            for src, dst in ((dev.V, nV), (dev.BV, nBV)):
-                blk = ctx.empty(n, keep)
-                src.times_into(blk, Sk, ns=m)
-                for q in range(keep):
-                    dst[q].copy_from(blk.cols(q, q + 1))
-            for q in range(keep):
-                dev.V[q].copy_from(nV[q])
-                dev.BV[q].copy_from(nBV[q])
-            dev.V[keep].copy_from(dev.V[m])
-            dev.BV[keep].copy_from(dev.BV[m])
-            T = np.zeros((m, m))
-            T[np.arange(keep), np.arange(keep)] = theta[selk]
-            # the next step recomputes column `keep` in full (arrow beta_m * S[m-1, sel] + diagonal) by Gram-Schmidt
-            j0 = keep
-            self.n_restarts += 1
-        if nconv < k:
-            from scipy.sparse.linalg import ArpackNoConvergence
+                print(f"[iram] restart {r}: {nconv}/{kw} converged (block {p}, basis {m_int}), worst bound / |theta| "
+                      f"{worst:.2e}", flush=True)
 
-            raise ArpackNoConvergence(f"No convergence ({self.n_restarts} restarts, {nconv}/{k} eigenvectors converged)",
-                                      None, None)
+        T, C, c, nconv, self.n_restarts = thick_restart_block_lanczos(dev, k_want, m_int, p, tol, max_restarts, trace)
+        if nconv < k_want:
+            # the extra pairs are an internal acceleration of the adjoint stage: only the N requested ones decide
+            theta_c, S_c = np.linalg.eigh(T)
+            order = np.argsort(-np.abs(theta_c))[:k]
+            okN = arpack_converged(ritz_bounds(C, S_c, p)[order], theta_c[order], tol, np.linalg.norm(C, 2))
+            if not okN.all():
+                from scipy.sparse.linalg import ArpackNoConvergence
+
+                raise ArpackNoConvergence(f"No convergence ({self.n_restarts} restarts, {int(okN.sum())}/{k} eigenvectors "
+                                          "converged)", None, None)
+        if p == 1 and c == m:
+            beta_m = float(C[0, 0])
+        else:
+            T, beta_m = compress_to_single_vector_basis(dev, T, C, c, p, m, tol)
+        self.block_size, self.internal_basis = p, m_int
+        self.sweeps = dev.sweeps
         self.T = T
         self.theta, self.Y = np.linalg.eigh(self.T)                        # ref 1958
         eigs, self.indices = ritz_to_eigs(self.theta, sigma, self.mode)    # ref 1960-1965
@@ -716,12 +954,16 @@ class IRAM(_AdjointAPI):
         prob.set_phi(Phi_dev=dPhi)
         self.Phi = dPhi.get()
         self._phi_token = self.Phi
-        self.eig_res = np.abs(beta_m * self.Y[m - 1, sel])
+        bounds = np.abs(beta_m * self.Y[m - 1, :])
+        self.eig_res = bounds[sel]
         if np.any(self.eig_res > 1e-6 * np.maximum(np.abs(self.theta[sel]), 1.0)):
             # the restarts converge the Ritz values of largest magnitude; the reference then selects by eigenvalue order
             # (1960-1965): with a shift on the wrong side of the wanted eigenvalues these are different pairs
             warnings.warn("IRAM: the selected Ritz pairs are not the converged ones (largest residual "
                           f"{self.eig_res.max():.1e}): the shift is not next to the wanted eigenvalues")
+        # converged pairs beyond the N requested ones (the next eigenvalues in the reference's sort order): the adjoint
+        # stage deflates them too (solve_adjoint) -- they are what makes the high modes of the block slow to converge
+        self._set_extra_pairs(prob, dev, eigs, bounds, tol, abs(beta_m), m, extra)
         self._m = m
         self._nV = m
         self._V_host = None

@@ -34,6 +34,54 @@ def corr_from(g, prefix):
     return data
 
 
+def exact_pair_coefficients(lam, Phi, Phib, data, mode="normal"):
+    """
+    xi, eta of the repeated pairs (reference eigenvector_derivatives.py:373-383) in EXACT rational arithmetic from the
+    given floating-point inputs: the same dict layout as ``data`` (whose index sets are kept).  What a floating-point
+    evaluation of those formulas deviates from this by is its own rounding: xi, eta divide the difference of two n-term
+    dot products by the eigenvalue gap of the pair.
+    """
+    from fractions import Fraction
+
+    def dot(x, y):
+        return sum(Fraction(a) * Fraction(b) for a, b in zip(x.tolist(), y.tolist()))
+
+    cache = {}
+
+    def g0(j, i):
+        if (j, i) not in cache:
+            v = -dot(Phi[:, j], Phib[:, i])
+            cache[(j, i)] = v if mode == "normal" else Fraction(lam[j]) * v
+        return cache[(j, i)]
+
+    out = {}
+    for i, lst in data.items():
+        for tup in lst:
+            j = tup[0]
+            hi, lo = max(i, j), min(i, j)             # the reference's loop forms the pair as (i, j) with j < i
+            gap = Fraction(lam[lo]) - Fraction(lam[hi])
+            xi = Fraction(1, 2) * (g0(lo, hi) - g0(hi, lo)) / gap
+            eta = Fraction(1, 2) * (Fraction(lam[hi]) * g0(lo, hi) - Fraction(lam[lo]) * g0(hi, lo)) / gap
+            out.setdefault(i, []).append((j, float(xi), float(eta)))
+    return out
+
+
+def pair_rounding_in_dfdx(data_a, data_b, Phi, dAdx, dBdx, mode="normal"):
+    """
+    first-order change of df/dx when the (xi, eta) of ``data_a`` are replaced by those of ``data_b`` (same index sets):
+    the weight vectors are linear in them (reference 96-111 / 118-132), dfdx = dAdx(WA, Phi) -+ dBdx(WB, Phi)
+    """
+    delta = 0.0
+    sB = -1.0 if mode == "normal" else 1.0
+    ia, ib = (1, 2) if mode == "normal" else (2, 1)
+    for i in data_a:
+        for ta, tb in zip(data_a[i], data_b[i]):
+            assert ta[0] == tb[0]
+            j = ta[0]
+            delta = delta + (tb[ia] - ta[ia]) * dAdx(Phi[:, [j]], Phi[:, [i]]) + sB * (tb[ib] - ta[ib]) * dBdx(Phi[:, [j]], Phi[:, [i]])
+    return delta
+
+
 def index_sets(data):
     return {i: [t[0] for t in lst] for i, lst in data.items()}
 

@@ -164,6 +164,39 @@ def test_g3_noise_floor_of_the_repeated_branch():
     assert 1e-10 < spread < 1e-6
 
 
+@pytest.mark.parametrize("name", ["g3_thermal32_eps1e-8_basiclanczos", "g3_thermal32_eps1e-8_iram"])
+def test_g3_reference_rounding_of_the_repeated_branch_in_exact_arithmetic(name):
+    """
+    How far the reference's own df/dx of the epsilon = 1e-8 case is from the exact value of its own formulas: xi, eta
+    (eigenvector_derivatives.py:373-383) recomputed in exact rational arithmetic from the fixture's (lam, Phi, Qb)
+    differ from the stored double-precision ones by 1e-7 ... 1e-5 relative, and that alone moves df/dx by more than 1e-8
+    -- which is why the GPU tests of this branch compare with the reference value AFTER that rounding is taken out
+    (tests/test_gpu_derivatives.py), and what the helpers they use for it are checked against here.
+    """
+    from conftest import exact_pair_coefficients, pair_rounding_in_dfdx
+
+    g = load_golden(name)
+    tab = fe.Q4Tables(g["conn"], g["X"])
+    rhoE, p = g["rhoE"], float(g["p"])
+    kappa, beta, hc, dens = float(g["kappa"]), float(g["th_beta"]), float(g["heat_capacity"]), float(g["density"])
+    cbA = lambda w, v: fe.thermal_stiffness_deriv(tab, rhoE, p, kappa, beta, w, v)  # noqa: E731
+    cbB = lambda w, v: fe.thermal_mass_deriv(tab, hc, dens, beta, w, v)              # noqa: E731
+    ref = corr_from(g, "corr")
+    exact = exact_pair_coefficients(g["lam"], g["Phi"], g["Qb"], ref)
+    rel = [abs(tr[1] - tx[1]) / abs(tx[1]) for i in ref for tr, tx in zip(ref[i], exact[i])]
+    print(f"reference xi vs exact: relative differences {min(rel):.1e} ... {max(rel):.1e}")
+    assert 1e-8 < max(rel) < 1e-3
+    args = (g["lam"], g["Phi"], g["lamb"], g["Qb"], g["psi"], cbA, cbB)
+    with_exact = orc.add_eig_total_derivative(*args, np.zeros(tab.nelems), adj_corr_data=exact, mode="normal",
+                                              deriv_type="tensor")
+    moved = relerr(with_exact, g["rhoEb"])
+    print(f"df/dx with exact xi / eta differs from the reference's by {moved:.2e}")
+    assert 1e-9 < moved < 1e-6
+    # first-order bookkeeping used by the GPU tests: reference value + effect of (exact - reference) xi / eta
+    corrected = g["rhoEb"] + pair_rounding_in_dfdx(ref, exact, g["Phi"], cbA, cbB)
+    assert relerr(corrected, with_exact) < 1e-10
+
+
 @pytest.mark.parametrize("solver", ["basiclanczos", "iram"])
 def test_g2_min_frequency_ks_and_its_seeds(solver):
     """MinFreqOpt (natural_frequency.py:700-807): the KS value and the adjoint seeds Q0b / lamb0 the fixture was solved for"""
