@@ -497,9 +497,14 @@ class ModalAnalysis:
 
     def __init__(self, conn, X, kind="natural_frequency", fltr=None, N=10, m=None, sigma=None, solver_type="IRAM",
                  tol=None, rtol=1e-10, eig_atol=1e-5, Ntarget=None, E=1.0, nu=0.3, p=3.0, rho0_K=1e-6, density=1.0,
-                 kappa=1.0, heat_capacity=1.0, beta=1e-6, adjoint_method="sibk", adjoint_options=None, ctx=None):
+                 kappa=1.0, heat_capacity=1.0, beta=1e-6, adjoint_method="sibk", adjoint_options=None, ctx=None,
+                 unit_mass=False):
         if kind not in ("natural_frequency", "thermal"):
             raise ValueError(f"Unknown kind {kind!r}")
+        # unit_mass: the symmetric STANDARD eigenproblem K phi = lam phi (B = I, independent of the design) on the same
+        # mesh and sparsity pattern -- BASELINE configs[3] as it is worded; the reference's thermal example itself is
+        # generalized (consistent capacity matrix, thermal.py:192-214)
+        self.unit_mass = bool(unit_mass)
         self.ctx = ctx = ctx if ctx is not None else default_context()
         self.kind, self.fltr = kind, fltr
         self.el = el = Q4Elements(conn, X)
@@ -561,7 +566,13 @@ class ModalAnalysis:
         self.rhoE = self.avg.apply(self.rho)
         sK, sM, self._dKs, self._dMs = self._scales(self.rhoE)
         vK = self.asm.assemble(self.Ke0, sK)
-        vM = self.asm.assemble(self.Me0, sM)
+        if self.unit_mass:
+            pat = self.asm.pattern()
+            rows = np.repeat(np.arange(self.n), np.diff(pat.indptr))
+            vM = ctx.from_host((pat.indices == rows).astype(np.float64).reshape(-1, 1))   # identity in the assembled pattern
+            self._dMs = ctx.zeros(self.nelems, 1)                                       # d I / d rho = 0
+        else:
+            vM = self.asm.assemble(self.Me0, sM)
         self.dK.update_values_device(vK)
         self.dM.update_values_device(vM)
         vS = ctx.empty(vK.n, 1).assign_lincomb([(1.0, vK), (-float(self.sigma), vM)])

@@ -588,6 +588,91 @@ class DeviceStack:
         return X
 
 
+class DevicePanels:
+    """
+    A tall basis of up to ncols columns stored as row-major panels of 64 columns (n x 64, leading dimension 64): the
+    layout the tall-skinny MFMA kernels stream best (a row of a panel is 512 contiguous bytes; eigd_gemm_tn /
+    eigd_gemm_nn take their operand fragments straight from it).  The restarted block Lanczos keeps V and B V this way:
+    its Gram-Schmidt step against c basis vectors is ceil(c / 64) products per pass instead of c dependent axpys.
+    Same small interface as a k = 1 DeviceStack where the adjoint stage reads the basis (tdot_block / times_into).
+    """
+
+    PW = 64
+
+    def __init__(self, ctx, ncols, n):
+        self.ctx, self.n = ctx, int(n)
+        self.npanels = max(1, -(-int(ncols) // self.PW))
+        self.ncols = self.npanels * self.PW
+        self.buf = _Buffer(ctx, 8 * self.npanels * self.n * self.PW)
+
+    def view(self, j0, j1):
+        """columns [j0, j1) of ONE panel as a strided block"""
+        q = j0 // self.PW
+        assert 0 <= j0 < j1 <= self.ncols and (j1 - 1) // self.PW == q
+        return DeviceBlock(self.ctx, self.n, j1 - j0, self.buf, q * self.n * self.PW + (j0 - q * self.PW), self.PW)
+
+    def pieces(self, j0, j1):
+        """[(view, a, b)]: the panels' shares of columns [j0, j1); a, b count from j0"""
+        out = []
+        j = j0
+        while j < j1:
+            e = min(j1, (j // self.PW + 1) * self.PW)
+            out.append((self.view(j, e), j - j0, e - j0))
+            j = e
+        return out
+
+    def tdot_block(self, X, ns=None, j0=0):
+        """V[:, j0:j0+ns]^T X -> host (ns x X.k)"""
+        ns = self.ncols - j0 if ns is None else ns
+        out = np.empty((ns, X.k))
+        for blk, a, b in self.pieces(j0, j0 + ns):
+            out[a:b] = blk.tdot(X)
+        return out
+
+    def times_into(self, X, Cmat, ns=None, alpha=1.0, beta=0.0, j0=0):
+        """X = beta X + alpha V[:, j0:j0+ns] @ C"""
+        ns = self.ncols - j0 if ns is None else ns
+        Cmat = np.ascontiguousarray(Cmat, dtype=np.float64).reshape(ns, X.k)
+        bb = beta
+        for blk, a, b in self.pieces(j0, j0 + ns):
+            X.add_product(blk, Cmat[a:b], alpha=alpha, beta=bb)
+            bb = 1.0
+        return X
+
+    def get_block(self, j0, p, out=None):
+        """contiguous n x p copy of columns [j0, j0+p)"""
+        X = out if out is not None else self.ctx.empty(self.n, p)
+        for blk, a, b in self.pieces(j0, j0 + p):
+            X.cols(a, b).copy_from(blk)
+        return X
+
+    def set_block(self, j0, X):
+        for blk, a, b in self.pieces(j0, j0 + X.k):
+            blk.copy_from(X.cols(a, b))
+
+    def to_host(self, m):
+        out = np.empty((self.n, m))
+        for blk, a, b in self.pieces(0, m):
+            out[:, a:b] = blk.get()
+        return out
+
+    def from_host(self, V):
+        V = np.asarray(V, dtype=np.float64)
+        for blk, a, b in self.pieces(0, V.shape[1]):
+            blk.set(np.ascontiguousarray(V[:, a:b]))
+
+    def as_stack(self, m):
+        """the first m columns as a k = 1 stack (column-major n x m): for consumers written against that layout"""
+        st = DeviceStack(self.ctx, m, self.n, 1)
+        for blk, a, b in self.pieces(0, m):
+            for q in range(b - a):
+                st[a + q].copy_from(blk.cols(q, q + 1))
+        return st
+
+    def swap(self, other):
+        self.buf, other.buf = other.buf, self.buf
+
+
 class CSRMatrix:
     """device copy of a scipy CSR matrix"""
 

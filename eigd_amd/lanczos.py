@@ -311,52 +311,51 @@ def compress_to_single_vector_basis(be, T, C, c, p, m, tol):
     return Tm, beta
 
 
-class _BlockLanczosDevice(_LanczosDevice):
-    """device backend of thick_restart_block_lanczos: the basis V and B V as k=1 stacks, blocks as n x p row-major"""
+class _BlockLanczosDevice:
+    """
+    device backend of thick_restart_block_lanczos: the basis V and B V as row-major 64-column panels
+    (device.DevicePanels), blocks as n x p row-major
+    """
 
     def __init__(self, prob, nvec):
-        super().__init__(prob, nvec)
+        from .device import DevicePanels
+
+        self.prob, self.ctx, self.n = prob, prob.ctx, prob.n
+        self.V = DevicePanels(self.ctx, nvec, self.n)
+        self.BV = DevicePanels(self.ctx, nvec, self.n)
         self.scratch = None
         self.sweeps = 0
         self.reorth_passes = 0
 
-    def _block_from(self, st, j0, p):
-        """n x p row-major copy of slabs [j0, j0+p) of a k=1 stack"""
-        X = self.ctx.empty(self.n, p)
-        adj._StackView(st, j0).times_into(X, np.eye(p), ns=p)
-        return X
-
-    def _store(self, X, st, j0):
-        for q in range(X.k):
-            st[j0 + q].copy_from(X.cols(q, q + 1))
+    def basis_to_host(self, m):
+        return self.V.to_host(m)
 
     def _orthonormalise(self, X):
         """B-orthonormalise the block in place (SVQB, twice); returns (B X, C) with X_in = X_out C"""
         p = X.k
         Ctot = np.eye(p)
-        BX = None
-        for _ in range(2):
-            BX = self.prob.opB.apply(X)
+        BX = self.prob.opB.apply(X)
+        for it in range(2):
             gram = X.tdot(BX)
             gram = 0.5 * (gram + gram.T)
             Tr, C, bad = _svqb(gram)
             if bad.any():
                 raise np.linalg.LinAlgError("Lanczos breakdown: the new block is linearly dependent on the basis "
                                             "(an invariant subspace was found)")
-            Xn = self.ctx.empty(self.n, p).add_product(X, Tr, alpha=1.0, beta=0.0)
-            X.copy_from(Xn)
+            for blk in (X, BX):                            # B (X Tr) = (B X) Tr: no further product with B
+                blk.copy_from(self.ctx.empty(self.n, p).add_product(blk, Tr, alpha=1.0, beta=0.0))
             Ctot = C @ Ctot
-        BX = self.prob.opB.apply(X)
+        BX = self.prob.opB.apply(X)                        # recomputed from the final X (not carried through two products)
         return BX, Ctot
 
     def start(self, V0):
         X = self.ctx.from_host(V0)
         BX, _ = self._orthonormalise(X)
-        self._store(X, self.V, 0)
-        self._store(BX, self.BV, 0)
+        self.V.set_block(0, X)
+        self.BV.set_block(0, BX)
 
     def expand(self, c, p):
-        X = self._block_from(self.BV, c - p, p)
+        X = self.BV.get_block(c - p, p)
         self.prob.fac(X)                                  # W = factor(B V_last): one p-column sweep
         self.sweeps += 1
         H = self.BV.tdot_block(X, ns=c)
@@ -368,29 +367,25 @@ class _BlockLanczosDevice(_LanczosDevice):
             H = H + H2
             self.reorth_passes += 1
         BX, C = self._orthonormalise(X)
-        self._store(X, self.V, c)
-        self._store(BX, self.BV, c)
+        self.V.set_block(c, X)
+        self.BV.set_block(c, BX)
         return H, C
 
     def restart(self, S, c, keep, p):
+        from .device import DevicePanels
+
         ctx, n = self.ctx, self.n
-        if self.scratch is None or self.scratch[0].ns < self.V.ns:
-            self.scratch = (ctx.stack(self.V.ns, n, 1), ctx.stack(self.V.ns, n, 1))
+        if self.scratch is None:
+            self.scratch = (DevicePanels(ctx, self.V.ncols, n), DevicePanels(ctx, self.V.ncols, n))
+        S = np.ascontiguousarray(S)
         for src, dst in zip((self.V, self.BV), self.scratch):
-            for a in range(0, keep, 64):                   # new basis = V S: one product per block of kept vectors
+            for a in range(0, keep, 64):                   # new basis = V S, one 64-column panel of it at a time
                 b = min(keep, a + 64)
                 blk = ctx.empty(n, b - a)
                 src.times_into(blk, S[:, a:b], ns=c)
-                for q in range(b - a):
-                    dst[a + q].copy_from(blk.cols(q, q + 1))
-            for q in range(p):
-                dst[keep + q].copy_from(src[c + q])
-        nV, nBV = self.scratch
-        from ._ffi import call
-
-        nbytes = 8 * n * (keep + p)
-        call("eigd_d2d", ctx.h, self.V.ptr, nV.ptr, nbytes)
-        call("eigd_d2d", ctx.h, self.BV.ptr, nBV.ptr, nbytes)
+                dst.set_block(a, blk)
+            dst.set_block(keep, src.get_block(c, p))       # the residual block follows the kept vectors
+            src.swap(dst)
 
 
 class _AdjointAPI:
@@ -413,7 +408,11 @@ class _AdjointAPI:
             # a caller replaced the basis: mirror it on the device
             Vh = np.asarray(value)
             from ._ffi import call, hptr
+            from .device import DevicePanels
 
+            if isinstance(self._dev.V, DevicePanels):
+                self._dev.V.from_host(Vh[:, : min(Vh.shape[1], self._dev.V.ncols)])
+                return
             nv = min(Vh.shape[1], self._dev.V.ns)
             Vt = np.ascontiguousarray(Vh[:, :nv].T)
             call("eigd_h2d", self._dev.ctx.h, self._dev.V.ptr, hptr(Vt), 8 * self._dev.n * nv)
@@ -559,7 +558,8 @@ class _AdjointAPI:
         elif method == "dl":
             if self.T is None:
                 raise ValueError("dl needs the Lanczos matrix T")
-            psi_c, data = adj._dl_device(prob, dPhib, lam, self.sigma, indices, self._dev.V, self._m,
+            Vst = self._dev.V.as_stack(self._m) if hasattr(self._dev.V, "as_stack") else self._dev.V
+            psi_c, data = adj._dl_device(prob, dPhib, lam, self.sigma, indices, Vst, self._m,
                                          np.asarray(self.T), Y, theta, eig_atol, self.mode)
         if G is not None:
             Cc, data = adj.correction_coefficients(lam, G, eig_atol, self.mode, Glo)
