@@ -755,15 +755,35 @@ int eigd_gemm_nn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t
   return gemm_nn_device(ctx, n, ku, kx, dU, rsu, csu, ctx->coef, dX, ldx, alpha, beta);
 }
 
+// C = V^T X for up to 2 * kMaxK columns of V, left on the device in ctx->coef (ku x kx): the product kernel forms at
+// most kMaxK x kMaxK entries per launch, a wider V goes in two column halves (no host round trip in between)
+static int project_coefficients(eigd_ctx* ctx, int n, int ku, int kx, const double* dV, int ldv, const double* dX, int ldx) {
+  int rc = ctx->ensure_coef(sizeof(double) * static_cast<size_t>(ku) * kx);
+  if (rc) return rc;
+  for (int a0 = 0; a0 < ku; a0 += kMaxK) {
+    const int ka = std::min(kMaxK, ku - a0);
+    double* dC = nullptr;
+    rc = gemm_tn_device(ctx, n, ka, kx, dV + a0, ldv, 1, dX, ldx, &dC, nullptr);
+    if (rc) return rc;
+    EIGD_HIP(hipMemcpyAsync(ctx->coef + static_cast<size_t>(a0) * kx, dC, sizeof(double) * ka * kx, hipMemcpyDeviceToDevice,
+                            ctx->stream));
+  }
+  return EIGD_OK;
+}
+
 int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv, double* dX,
                  int ldx) {
   EIGD_REQUIRE(ctx && dU && dV && dX, "null argument");
-  EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx && ldu >= ku && ldv >= ku,
+  EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= 2 * kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx && ldu >= ku && ldv >= ku,
                "bad shape n=%d ku=%d kx=%d", n, ku, kx);
-  double* dC = nullptr;
-  int rc = gemm_tn_device(ctx, n, ku, kx, dV, ldv, 1, dX, ldx, &dC, nullptr);
+  int rc = project_coefficients(ctx, n, ku, kx, dV, ldv, dX, ldx);
   if (rc) return rc;
-  return gemm_nn_device(ctx, n, ku, kx, dU, ldu, 1, dC, dX, ldx, -1.0, 1.0);
+  for (int a0 = 0; a0 < ku; a0 += kMaxK) {
+    const int ka = std::min(kMaxK, ku - a0);
+    rc = gemm_nn_device(ctx, n, ka, kx, dU + a0, ldu, 1, ctx->coef + static_cast<size_t>(a0) * kx, dX, ldx, -1.0, 1.0);
+    if (rc) return rc;
+  }
+  return EIGD_OK;
 }
 
 static int publish_norm2(eigd_ctx* ctx, const double* dOut, int k);
@@ -771,19 +791,23 @@ static int publish_norm2(eigd_ctx* ctx, const double* dOut, int k);
 int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv,
                        double* dX, int ldx, double* dOut) {
   EIGD_REQUIRE(ctx && dU && dV && dX && dOut, "null argument");
-  EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx && ldu >= ku && ldv >= ku,
+  EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= 2 * kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx && ldu >= ku && ldv >= ku,
                "bad shape n=%d ku=%d kx=%d", n, ku, kx);
-  // scratch: [C (ku x kx)] [partials of C, later the partial squared norms]
+  // scratch: [C tile (<= kMaxK x kx)] [partials of C, later the partial squared norms]
   const int nbd = grid_for_rows(n, 64);
-  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(ku) * kx + static_cast<size_t>(nbd) * kx));
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(kMaxK) * kx + static_cast<size_t>(nbd) * kx));
   if (rc) return rc;
-  double* dC = nullptr;
-  rc = gemm_tn_device(ctx, n, ku, kx, dV, ldv, 1, dX, ldx, &dC, nullptr);
+  rc = project_coefficients(ctx, n, ku, kx, dV, ldv, dX, ldx);
   if (rc) return rc;
-  double* normpart = ctx->scratch + static_cast<size_t>(ku) * kx;  // (the partials of C are spent by now)
+  double* normpart = ctx->scratch + static_cast<size_t>(kMaxK) * kx;  // (the partials of C are spent by now)
   int nparts = 0;
-  rc = gemm_nn_device(ctx, n, ku, kx, dU, ldu, 1, dC, dX, ldx, -1.0, 1.0, normpart, &nparts);
-  if (rc) return rc;
+  for (int a0 = 0; a0 < ku; a0 += kMaxK) {
+    const int ka = std::min(kMaxK, ku - a0);
+    const bool last = a0 + kMaxK >= ku;                               // the norms belong to the finished block
+    rc = gemm_nn_device(ctx, n, ka, kx, dU + a0, ldu, 1, ctx->coef + static_cast<size_t>(a0) * kx, dX, ldx, -1.0, 1.0,
+                        last ? normpart : nullptr, last ? &nparts : nullptr);
+    if (rc) return rc;
+  }
   rc = reduce_to_host(ctx, normpart, nparts, kx, dOut, nullptr);
   if (rc) return rc;
   return publish_norm2(ctx, dOut, kx);

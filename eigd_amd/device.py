@@ -265,7 +265,9 @@ class _Buffer:
                 pool = self.ctx.__dict__.setdefault("_pool", {})
                 free = pool.setdefault(self.nbytes, [])
                 held = self.ctx.__dict__.get("_pool_bytes", 0)
-                if len(free) < _POOL_KEEP_PER_SIZE and held + self.nbytes <= _POOL_MAX_BYTES:
+                # (small blocks: more of one size may be in flight at once -- hipFree stalls the stream)
+                if len(free) < max(_POOL_KEEP_PER_SIZE, (1 << 30) // max(self.nbytes, 1)) \
+                        and held + self.nbytes <= _POOL_MAX_BYTES:
                     free.append(self.ptr)
                     self.ctx.__dict__["_pool_bytes"] = held + self.nbytes
                 else:
@@ -437,7 +439,7 @@ class DeviceBlock:
 
     def project(self, U, V):
         """self <- self - U (V^T self)   (reference _project, eigenvector_derivatives.py:26-30)"""
-        if U.k > 64 or self.k > 64:
+        if U.k > 128 or self.k > 64:
             t = V.tdot(self)
             return self.add_product(U, t, alpha=-1.0, beta=1.0)
         call("eigd_project", self.ctx.h, self.n, U.k, self.k, U.ptr, U.ld, V.ptr, V.ld, self.ptr, self.ld)
@@ -446,7 +448,7 @@ class DeviceBlock:
     def project_norm2(self, U, V):
         """project(U, V), then the squared column norms of the result: as colnorm2_dev (device block + pinned copy for
         ctx.fetch_colnorm2), but formed while the projection writes the block -- no extra pass over it"""
-        if U.k > 64 or self.k > 64:
+        if U.k > 128 or self.k > 64:
             return self.project(U, V).colnorm2_dev()
         out = self.ctx.empty(1, self.k)
         call("eigd_project_norm2", self.ctx.h, self.n, U.k, self.k, U.ptr, U.ld, V.ptr, V.ld, self.ptr, self.ld, out.ptr)

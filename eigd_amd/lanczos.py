@@ -206,6 +206,20 @@ def _svqb(gram):
     return Tr, C, bad
 
 
+def small_eigh(T):
+    """
+    eigh of the projected matrix (a few dozen to a few hundred rows).  On a many-core host a threaded LAPACK spends ten
+    times the arithmetic of such a matrix waking its threads (20 ms instead of 2 for 136 x 136 on 256 cores): a few
+    threads at most.
+    """
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        return np.linalg.eigh(T)
+    with threadpool_limits(limits=4):
+        return np.linalg.eigh(T)
+
+
 def ritz_bounds(C_last, S, p):
     """residual norms of the Ritz pairs of a block Lanczos basis: |C S[last p rows, j]|"""
     return np.linalg.norm(C_last @ S[-p:, :], axis=0)
@@ -253,7 +267,7 @@ def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=N
             T[c:c + p, c - p:c] = C
             T[c - p:c, c:c + p] = C.T
             c += p
-        theta, S = np.linalg.eigh(T[:c, :c])
+        theta, S = small_eigh(T[:c, :c])
         bounds = ritz_bounds(C, S, p)
         order = np.argsort(-np.abs(theta))              # which = "LM"
         wanted = order[:k_want]
@@ -287,7 +301,7 @@ def compress_to_single_vector_basis(be, T, C, c, p, m, tol):
     basis that holds them satisfies the relation in their columns), put one vector of the residual block behind them
     and finish with single-vector Lanczos steps up to m.  Returns (T (m x m), beta_m).
     """
-    theta, S = np.linalg.eigh(T)
+    theta, S = small_eigh(T)
     bounds = ritz_bounds(C, S, p)
     ok = arpack_converged(bounds, theta, tol, np.linalg.norm(C, 2))
     sel = np.flatnonzero(ok)
@@ -330,32 +344,39 @@ class _BlockLanczosDevice:
     def basis_to_host(self, m):
         return self.V.to_host(m)
 
-    def _orthonormalise(self, X):
-        """B-orthonormalise the block in place (SVQB, twice); returns (B X, C) with X_in = X_out C"""
-        p = X.k
-        Ctot = np.eye(p)
-        BX = self.prob.opB.apply(X)
-        for it in range(2):
+    def _work(self, p):
+        """work blocks of the current block size, kept between steps (no allocation inside the Lanczos loop)"""
+        w = self.__dict__.setdefault("_wk", {})
+        if p not in w:
+            w[p] = tuple(self.ctx.empty(self.n, p) for _ in range(3))
+        return w[p]
+
+    def _orthonormalise(self, X, BX, tmp):
+        """B-orthonormalise the block X in place (SVQB, twice); BX <- B X; returns C with X_in = X_out C"""
+        Ctot = np.eye(X.k)
+        self.prob.opB.apply(X, BX)
+        for _ in range(2):
             gram = X.tdot(BX)
-            gram = 0.5 * (gram + gram.T)
-            Tr, C, bad = _svqb(gram)
+            Tr, C, bad = _svqb(0.5 * (gram + gram.T))
             if bad.any():
                 raise np.linalg.LinAlgError("Lanczos breakdown: the new block is linearly dependent on the basis "
                                             "(an invariant subspace was found)")
             for blk in (X, BX):                            # B (X Tr) = (B X) Tr: no further product with B
-                blk.copy_from(self.ctx.empty(self.n, p).add_product(blk, Tr, alpha=1.0, beta=0.0))
+                blk.copy_from(tmp.add_product(blk, Tr, alpha=1.0, beta=0.0))
             Ctot = C @ Ctot
-        BX = self.prob.opB.apply(X)                        # recomputed from the final X (not carried through two products)
-        return BX, Ctot
+        self.prob.opB.apply(X, BX)                         # recomputed from the final X (not carried through two products)
+        return Ctot
 
     def start(self, V0):
-        X = self.ctx.from_host(V0)
-        BX, _ = self._orthonormalise(X)
+        X, BX, tmp = self._work(V0.shape[1])
+        X.set(V0)
+        self._orthonormalise(X, BX, tmp)
         self.V.set_block(0, X)
         self.BV.set_block(0, BX)
 
     def expand(self, c, p):
-        X = self.BV.get_block(c - p, p)
+        X, BX, tmp = self._work(p)
+        self.BV.get_block(c - p, p, out=X)
         self.prob.fac(X)                                  # W = factor(B V_last): one p-column sweep
         self.sweeps += 1
         H = self.BV.tdot_block(X, ns=c)
@@ -366,7 +387,7 @@ class _BlockLanczosDevice:
             self.V.times_into(X, H2, ns=c, alpha=-1.0, beta=1.0)   # ... and removed where it matters
             H = H + H2
             self.reorth_passes += 1
-        BX, C = self._orthonormalise(X)
+        C = self._orthonormalise(X, BX, tmp)
         self.V.set_block(c, X)
         self.BV.set_block(c, BX)
         return H, C
@@ -384,7 +405,7 @@ class _BlockLanczosDevice:
                 blk = ctx.empty(n, b - a)
                 src.times_into(blk, S[:, a:b], ns=c)
                 dst.set_block(a, blk)
-            dst.set_block(keep, src.get_block(c, p))       # the residual block follows the kept vectors
+            dst.set_block(keep, src.get_block(c, p, out=self._work(p)[2]))   # the residual block follows the kept vectors
             src.swap(dst)
 
 
@@ -735,7 +756,7 @@ class BasicLanczos(_AdjointAPI):
         # Ritz pairs beyond N that pass the solver's own test |beta y_last| < tol: deflated by the adjoint stage too
         if self.tol > 0:
             bounds = np.abs(self.beta[self.m - 1] * self.Y[self.m - 1, :])
-            self._set_extra_pairs(prob, dev, self.lam, bounds, None, None, self.m, max(0, min(self.N // 4, 64 - self.N)),
+            self._set_extra_pairs(prob, dev, self.lam, bounds, None, None, self.m, max(0, min(self.N // 4, 128 - self.N)),
                                   absolute_tol=self.tol)
         self._m = self.m
         self._nV = self.m_max + 1
@@ -884,15 +905,15 @@ class IRAM(_AdjointAPI):
         N, m = self.N, self.m
         p = int(os.environ.get("EIGD_IRAM_BLOCK", "0")) or (8 if n >= 200_000 else (4 if n >= 50_000 else 1))
         extra = os.environ.get("EIGD_IRAM_EXTRA")
-        extra = int(extra) if extra is not None else (self.extra if self.extra is not None else (0 if p == 1 else N // 4))
-        extra = max(0, min(extra, m - 2 - N, 64 - N))   # room in the m-vector contract basis; one fused projector call
+        extra = int(extra) if extra is not None else (self.extra if self.extra is not None else (0 if p == 1 else N))
+        extra = max(0, min(extra, m - 1 - N, 128 - N))  # room in the m-vector contract basis; one fused projector call
         if p == 1:
             return 1, extra, m
         k_want = N + extra
         m_int = max(m, 2 * k_want + p)
         m_int = p * (-(-m_int // p))
         if m_int + p > n:
-            return 1, min(extra, max(0, m - 2 - N)), m
+            return 1, min(extra, max(0, m - 1 - N)), m
         return p, extra, m_int
 
     def solve(self, A, B, factor, sigma):

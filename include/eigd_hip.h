@@ -151,7 +151,8 @@ int eigd_gemm_tn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t
  * sites: V @ Y0 1648, B @ V @ (...) 519, Z @ y 1028/1277/1301, Vb @ (...) 678, _project 29   */
 int eigd_gemm_nn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu, const double* hC,
                  double* dX, int ldx, double alpha, double beta);
-/* fused oblique projector X <- X - U (V^T X), coefficient matrix stays on the device (26-30) */
+/* fused oblique projector X <- X - U (V^T X), coefficient matrix stays on the device (26-30); ku <= 128: the N
+ * eigenvectors of the caller plus the further converged pairs the adjoint stage deflates */
 int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv, double* dX,
                  int ldx);
 /* the projector followed by the squared column norms of the result (1257 + 1259 of sibk in one pass over X):
