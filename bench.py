@@ -264,6 +264,9 @@ def main():
     ap.add_argument("--cpu-sample", choices=("full", "none"), default="full",
                     help="CPU baseline: SuperLU factor of the same matrix + the oracle's laa + sibk on a sample of the modes")
     ap.add_argument("--cpu-modes", type=int, default=4, help="candidate modes of the CPU sample (spread over the spectrum)")
+    ap.add_argument("--cpu-mode-list", default=None,
+                    help="comma-separated modes the CPU sample must solve whatever the budget (e.g. 0,10,31: one of the slow "
+                         "high modes, ~60 s of SuperLU solves, for the record under profiles/)")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0,
                     help="the CPU sample stops adding modes once its sibk time exceeds this (at least two modes run)")
     ap.add_argument("--numpy-steps", type=int, default=3, help="extra steps through the numpy-in / numpy-out call surface")
@@ -668,6 +671,9 @@ def cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, solver, dPhib, dp
     log(0, f"cpu: SuperLU factorisation {t_fac:.1f}s")
     ns = max(1, min(args.cpu_modes, N))
     want = sorted({int(round(q)) for q in np.linspace(0, N - 1, ns)})
+    forced = args.cpu_mode_list is not None
+    if forced:
+        want = sorted({int(q) for q in args.cpu_mode_list.split(",") if 0 <= int(q) < N})
     V, Y, theta, indices = solver.V, np.asarray(solver.Y), np.asarray(solver.theta), np.asarray(solver.indices)
     t0 = time.perf_counter()
     psi0 = orc.laa(Phib, K, fac, sigma, lam, V, Y, theta, indices, b_ortho=True, mode="buckling", cols=want)
@@ -687,7 +693,7 @@ def cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, solver, dPhib, dp
         sample.append(i)
         iters += list(info)
         log(0, f"cpu: mode {i}: {info} iterations, {time.perf_counter() - t0:.1f}s")
-        if len(sample) >= 2 and t_sibk > args.cpu_budget_s:
+        if not forced and len(sample) >= 2 and t_sibk > args.cpu_budget_s:
             break
     t_laa = t_laa_all * len(sample) / len(want)
     # total derivative of the sampled modes: the reference's weight vectors (eigenvector_derivatives.py:118-134),
@@ -715,7 +721,9 @@ def cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, solver, dPhib, dp
     err_psi = float(np.max(np.linalg.norm(psi_g - psi_c[:, sample], axis=0) / np.linalg.norm(psi_c[:, sample], axis=0)))
     log(0, f"cpu: GPU-vs-CPU on modes {sample}: psi rel-err {err_psi:.2e}, df/dx rel-err {err_df:.2e}")
     tot, t_laa, t_sibk, t_der = best
-    return {"value": round(len(sample) / tot, 5), "unit": "modes/s", "cores": 1, "host_cpus": os.cpu_count(),
+    return {"value": round(len(sample) / tot, 5), "unit": "modes/s", "cores": 1,
+            "cores_note": "1 = threads that do work: SuperLU's solve and scipy's CSR products are sequential kernels (the "
+                          "BLAS threads of numpy only see the small Hessenberg problems)", "host_cpus": os.cpu_count(),
             "thread_env": threads, "kind": "port",
             "sample": f"modes {sample} of {N} (candidates {want}, budget {args.cpu_budget_s:.0f}s) on the same 1M-dof matrices, "
                       f"eigenpairs, Lanczos basis and right-hand sides: oracle laa guess {t_laa:.1f}s + sibk {t_sibk:.1f}s "
