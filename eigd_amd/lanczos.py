@@ -392,6 +392,15 @@ class _BlockLanczosDevice:
         self.BV.set_block(c, BX)
         return H, C
 
+    def snapshot(self, c):
+        """copy of the first c basis vectors (panels)"""
+        from ._ffi import c_vp, call
+        from .device import DevicePanels
+
+        P = DevicePanels(self.ctx, c, self.n)
+        call("eigd_d2d", self.ctx.h, c_vp(P.buf.ptr), c_vp(self.V.buf.ptr), 8 * P.npanels * self.n * P.PW)
+        return P
+
     def restart(self, S, c, keep, p):
         from .device import DevicePanels
 
@@ -425,6 +434,7 @@ class _AdjointAPI:
     @V.setter
     def V(self, value):
         self._V_host = None if value is None else np.asarray(value)
+        self._guess = None   # (a caller-supplied basis: the adjoint stage works from it alone)
         if value is not None and getattr(self, "_dev", None) is not None:
             # a caller replaced the basis: mirror it on the device
             Vh = np.asarray(value)
@@ -512,8 +522,17 @@ class _AdjointAPI:
         dPhib_c = dPhib if cols is None else dPhib.gather_cols(cols)
         Y, theta, indices = np.asarray(self.Y), np.asarray(self.theta), np.asarray(self.indices)
         if lanczos_guess or method == "laa":
-            psi_c = adj._laa_device(prob, self._dev.V, self._m, dPhib, lam, self.sigma, Y, theta, indices, True,
-                                    self.mode, cols=cols)
+            g = getattr(self, "_guess", None)
+            tok = getattr(self, "_guess_token", (None, None, None))
+            if (g is not None and method != "laa" and tok[0] is self.Y and tok[1] is self.theta and tok[2] is self.indices
+                    and self._phi_token is self.Phi):
+                # the solver's own, larger basis (nobody replaced the Lanczos data since solve()): first guess only --
+                # method "laa" itself answers from the m-vector contract basis
+                Vg, mg, th_g, Y_g, idx_g = g
+                psi_c = adj._laa_device(prob, Vg, mg, dPhib, lam, self.sigma, Y_g, th_g, idx_g, True, self.mode, cols=cols)
+            else:
+                psi_c = adj._laa_device(prob, self._dev.V, self._m, dPhib, lam, self.sigma, Y, theta, indices, True,
+                                        self.mode, cols=cols)
         else:
             psi_c = ctx.zeros(n, len(sel))
         data = {}
@@ -957,9 +976,17 @@ class IRAM(_AdjointAPI):
 
                 raise ArpackNoConvergence(f"No convergence ({self.n_restarts} restarts, {int(okN.sum())}/{k} eigenvectors "
                                           "converged)", None, None)
+        self._guess = None
         if p == 1 and c == m:
             beta_m = float(C[0, 0])
         else:
+            if __import__("os").environ.get("EIGD_LAA_INTERNAL", "1") != "0":
+                # the block run's own basis (c vectors, more than the m of the contract) holds partly converged
+                # approximations of the eigenvectors beyond the converged ones: kept for the Lanczos adjoint
+                # approximation (laa's closed form only uses V^T B V = I and T = V^T B OP V), the better first guess
+                th_i, Y_i = small_eigh(T)
+                _, idx_i = ritz_to_eigs(th_i, sigma, self.mode)
+                self._guess = (dev.snapshot(c), c, th_i, Y_i, idx_i)
             T, beta_m = compress_to_single_vector_basis(dev, T, C, c, p, m, tol)
         self.block_size, self.internal_basis = p, m_int
         self.sweeps = dev.sweeps
@@ -988,6 +1015,7 @@ class IRAM(_AdjointAPI):
         self._m = m
         self._nV = m
         self._V_host = None
+        self._guess_token = (self.Y, self.theta, self.indices)
         return self.lam, self.Phi
 
 
