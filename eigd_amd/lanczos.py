@@ -238,7 +238,7 @@ def arpack_converged(bounds, theta, tol, beta_scale):
     return bounds <= np.maximum(tol * np.maximum(eps ** (2.0 / 3.0), np.abs(theta)), floor)
 
 
-def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=None):
+def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=None, k_strict=None, tol_extra=None):
     """
     Thick-restart Lanczos with blocks of p vectors on the operator the backend ``be`` applies (shift-invert, B inner
     product), full reorthogonalisation.  p = 1 is the single-vector thick-restart Lanczos (= ARPACK's implicitly
@@ -252,7 +252,14 @@ def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=N
     projected matrix of the final basis of c vectors, the coupling to the residual block basis[:, c:c+p] --
     OP basis[:, :c] = basis[:, :c] T + basis[:, c:c+p] C_last E_last^T -- and how many of the k_want wanted
     (largest |theta|) Ritz pairs pass ARPACK's test.
+    ``k_strict`` / ``tol_extra``: only the first k_strict wanted pairs (the caller's N) are held to ``tol``; the
+    further ones -- kept for the adjoint stage's deflation, which needs them to ~1e-10 -- to ``tol_extra``.  (A Ritz
+    vector next to unconverged neighbours in a cluster carries eps |T| / gap of THEIR residuals: asking machine
+    precision of the last pairs of a wanted set inside a cluster never ends.)
     """
+    tols = np.full(k_want, tol)
+    if k_strict is not None and tol_extra is not None:
+        tols[k_strict:] = max(tol, tol_extra)
     c = p
     T = np.zeros((m_int, m_int))
     n_restarts = 0
@@ -271,7 +278,7 @@ def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=N
         bounds = ritz_bounds(C, S, p)
         order = np.argsort(-np.abs(theta))              # which = "LM"
         wanted = order[:k_want]
-        conv = arpack_converged(bounds[wanted], theta[wanted], tol, np.linalg.norm(C, 2))
+        conv = arpack_converged(bounds[wanted], theta[wanted], tols, np.linalg.norm(C, 2))
         nconv = int(np.count_nonzero(conv))
         if trace is not None:
             trace(n_restarts, nconv, k_want, float(np.max(bounds[wanted] / np.abs(theta[wanted]))))
@@ -293,7 +300,7 @@ def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=N
         n_restarts += 1
 
 
-def compress_to_single_vector_basis(be, T, C, c, p, m, tol):
+def compress_to_single_vector_basis(be, T, C, c, p, m, tol, keep_first=0):
     """
     The contract of the reference's IRAM (what eigsh_mod extracts from ARPACK's work arrays and laa uses) is
     a basis of exactly m vectors with a rank-ONE residual, OP V = V T + f e_m^T.  A block run ends with a residual of
@@ -304,6 +311,7 @@ def compress_to_single_vector_basis(be, T, C, c, p, m, tol):
     theta, S = small_eigh(T)
     bounds = ritz_bounds(C, S, p)
     ok = arpack_converged(bounds, theta, tol, np.linalg.norm(C, 2))
+    ok[np.argsort(-np.abs(theta))[:keep_first]] = True     # the wanted pairs (accepted by the run's own per-pair test)
     sel = np.flatnonzero(ok)
     sel = sel[np.argsort(-np.abs(theta[sel]))][: m - 1]
     sel = sel[np.argsort(-theta[sel])]
@@ -955,7 +963,8 @@ class IRAM(_AdjointAPI):
         self._dev = dev
         eps = np.finfo(float).eps
         tol = self.tol if self.tol > 0 else eps
-        max_restarts = self.maxiter if self.maxiter is not None else 10 * n  # scipy's default for eigsh
+        max_restarts = self.maxiter if self.maxiter is not None else min(10 * n, 1000)  # (scipy's default for eigsh: 10 n)
+        tol_x = float(__import__("os").environ.get("EIGD_IRAM_EXTRA_TOL", "1e-11"))
 
         V0 = np.random.default_rng(12345).uniform(size=(n, p), low=-1.0, high=1.0)
         dev.start(V0)
@@ -965,7 +974,8 @@ class IRAM(_AdjointAPI):
                 print(f"[iram] restart {r}: {nconv}/{kw} converged (block {p}, basis {m_int}), worst bound / |theta| "
                       f"{worst:.2e}", flush=True)
 
-        T, C, c, nconv, self.n_restarts = thick_restart_block_lanczos(dev, k_want, m_int, p, tol, max_restarts, trace)
+        T, C, c, nconv, self.n_restarts = thick_restart_block_lanczos(dev, k_want, m_int, p, tol, max_restarts, trace,
+                                                                      k_strict=k, tol_extra=tol_x)
         if nconv < k_want:
             # the extra pairs are an internal acceleration of the adjoint stage: only the N requested ones decide
             theta_c, S_c = np.linalg.eigh(T)
@@ -987,7 +997,8 @@ class IRAM(_AdjointAPI):
                 th_i, Y_i = small_eigh(T)
                 _, idx_i = ritz_to_eigs(th_i, sigma, self.mode)
                 self._guess = (dev.snapshot(c), c, th_i, Y_i, idx_i)
-            T, beta_m = compress_to_single_vector_basis(dev, T, C, c, p, m, tol)
+            T, beta_m = compress_to_single_vector_basis(dev, T, C, c, p, m, max(tol, tol_x) if extra > 0 else tol,
+                                                        keep_first=min(k_want, m - 1) if nconv >= k_want else k)
         self.block_size, self.internal_basis = p, m_int
         self.sweeps = dev.sweeps
         self.T = T
@@ -1011,7 +1022,7 @@ class IRAM(_AdjointAPI):
                           f"{self.eig_res.max():.1e}): the shift is not next to the wanted eigenvalues")
         # converged pairs beyond the N requested ones (the next eigenvalues in the reference's sort order): the adjoint
         # stage deflates them too (solve_adjoint) -- they are what makes the high modes of the block slow to converge
-        self._set_extra_pairs(prob, dev, eigs, bounds, tol, abs(beta_m), m, extra)
+        self._set_extra_pairs(prob, dev, eigs, bounds, max(tol, tol_x), abs(beta_m), m, extra)
         self._m = m
         self._nV = m
         self._V_host = None
