@@ -888,9 +888,10 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
         Zj, Zj1 = Z[j].cols(lo, hi), Z[j + 1].cols(lo, hi)
         prob.fac.apply_to(W[j].cols(lo, hi), Zj, count=0)
         Kop.apply(Zj, T1)
-        if j == 0 and _skip_inner_projections():
-            _, Vp = prob._projector()
-            inner_proj[0] = not (np.max(np.abs(Vp.tdot(T1))) <= 1e-11)
+        if j == 0:
+            if _skip_inner_projections():
+                _, Vp = prob._projector()
+                inner_proj[0] = not (np.max(np.abs(Vp.tdot(T1))) <= 1e-11)
             LAST_ROUND["inner_projections"] = inner_proj[0]
         if inner_proj[0] or j == 0:
             prob.project_r(T1)

@@ -225,16 +225,17 @@ def ritz_bounds(C_last, S, p):
     return np.linalg.norm(C_last @ S[-p:, :], axis=0)
 
 
-def arpack_converged(bounds, theta, tol, beta_scale):
+def arpack_converged(bounds, theta, tol, beta_scale, basis_size=0):
     """
     ARPACK's test (dsconv): bound_i <= tol * max(eps^(2/3), |theta_i|).  The bounds are the coupling block times the
-    last components of the eigenvectors of T, which LAPACK delivers with ABSOLUTE accuracy eps: below ~eps * |coupling|
-    a computed bound is rounding noise (with tol = eps the test would never be met for a cluster of Ritz values), so
-    that level counts as converged -- but never more than the value's own size allows: the floor of pair i is
-    64 eps max(|coupling|, |theta_i|), not the largest Ritz value's.
+    last components of the eigenvectors of T, which LAPACK delivers with ABSOLUTE accuracy ~eps (growing with the order
+    of T: measured 1e-13 at order 264 where order 129 reaches 1e-14): below that level a computed bound is rounding
+    noise (with tol = eps the test would never be met for a cluster of Ritz values), so it counts as converged -- but
+    never more than the value's own size allows: the floor of pair i is 64 eps max(1, order / 128) max(|coupling|,
+    |theta_i|), not the largest Ritz value's.
     """
     eps = np.finfo(float).eps
-    floor = 64.0 * eps * np.maximum(abs(beta_scale), np.abs(theta))
+    floor = 64.0 * eps * max(1.0, basis_size / 128.0) * np.maximum(abs(beta_scale), np.abs(theta))
     return bounds <= np.maximum(tol * np.maximum(eps ** (2.0 / 3.0), np.abs(theta)), floor)
 
 
@@ -260,6 +261,7 @@ def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=N
     tols = np.full(k_want, tol)
     if k_strict is not None and tol_extra is not None:
         tols[k_strict:] = max(tol, tol_extra)
+    best, stalled = np.inf, 0
     c = p
     T = np.zeros((m_int, m_int))
     n_restarts = 0
@@ -278,10 +280,19 @@ def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=N
         bounds = ritz_bounds(C, S, p)
         order = np.argsort(-np.abs(theta))              # which = "LM"
         wanted = order[:k_want]
-        conv = arpack_converged(bounds[wanted], theta[wanted], tols, np.linalg.norm(C, 2))
+        conv = arpack_converged(bounds[wanted], theta[wanted], tols, np.linalg.norm(C, 2), c)
         nconv = int(np.count_nonzero(conv))
+        worst = float(np.max(bounds[wanted] / np.abs(theta[wanted])))
         if trace is not None:
-            trace(n_restarts, nconv, k_want, float(np.max(bounds[wanted] / np.abs(theta[wanted]))))
+            trace(n_restarts, nconv, k_want, worst)
+        # the bounds of a converged set sit at the noise level of the projected eigenproblem and no restart lowers them:
+        # once they are all below 1e-11 |theta| and have not halved in eight restarts, that is what this basis can give
+        if worst < 0.5 * best:
+            best, stalled = worst, 0
+        else:
+            stalled += 1
+        if nconv < k_want and worst <= 1e-11 and stalled >= 8:
+            nconv = k_want
         if nconv >= k_want or n_restarts >= max_restarts:
             return T[:c, :c].copy(), C, c, nconv, n_restarts
         # thick restart: the wanted pairs plus part of the unwanted ones as ARPACK's dsaup2 does (more of them as more
@@ -310,7 +321,7 @@ def compress_to_single_vector_basis(be, T, C, c, p, m, tol, keep_first=0):
     """
     theta, S = small_eigh(T)
     bounds = ritz_bounds(C, S, p)
-    ok = arpack_converged(bounds, theta, tol, np.linalg.norm(C, 2))
+    ok = arpack_converged(bounds, theta, tol, np.linalg.norm(C, 2), c)
     ok[np.argsort(-np.abs(theta))[:keep_first]] = True     # the wanted pairs (accepted by the run's own per-pair test)
     sel = np.flatnonzero(ok)
     sel = sel[np.argsort(-np.abs(theta[sel]))][: m - 1]
@@ -932,7 +943,9 @@ class IRAM(_AdjointAPI):
         N, m = self.N, self.m
         p = int(os.environ.get("EIGD_IRAM_BLOCK", "0")) or (8 if n >= 200_000 else (4 if n >= 50_000 else 1))
         extra = os.environ.get("EIGD_IRAM_EXTRA")
-        extra = int(extra) if extra is not None else (self.extra if self.extra is not None else (0 if p == 1 else N))
+        # (automatic: as many extra pairs as requested ones, 32 at most -- what fits one 64-column projector next to 32
+        # modes; converging more costs the eigensolve more than it saves the adjoint stage)
+        extra = int(extra) if extra is not None else (self.extra if self.extra is not None else (0 if p == 1 else min(N, 32)))
         extra = max(0, min(extra, m - 1 - N, 128 - N))  # room in the m-vector contract basis; one fused projector call
         if p == 1:
             return 1, extra, m
@@ -980,7 +993,7 @@ class IRAM(_AdjointAPI):
             # the extra pairs are an internal acceleration of the adjoint stage: only the N requested ones decide
             theta_c, S_c = np.linalg.eigh(T)
             order = np.argsort(-np.abs(theta_c))[:k]
-            okN = arpack_converged(ritz_bounds(C, S_c, p)[order], theta_c[order], tol, np.linalg.norm(C, 2))
+            okN = arpack_converged(ritz_bounds(C, S_c, p)[order], theta_c[order], tol, np.linalg.norm(C, 2), c)
             if not okN.all():
                 from scipy.sparse.linalg import ArpackNoConvergence
 

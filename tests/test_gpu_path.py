@@ -784,7 +784,11 @@ def test_c4_full_size_twenty_modes_and_the_derivative_through_the_repeated_branc
     assert np.abs(Q.T @ MQ - np.eye(N)).max() < 1e-9
     pairs = [(i, i + 1) for i in range(N - 1) if abs(lam[i + 1] - lam[i]) < 1e-5]      # the reference's rule (278-300)
     print(f"C4 {variant}: lam = {np.array2string(lam, precision=8)}", flush=True)
-    assert len(pairs) >= 6, lam                                              # (1,2), (4,5), (6,7), ...: both members found
+    # generalized: separable, every (i, j) / (j, i) pair coincides (8 among the 20 lowest).  B = I: not separable (the 1-D
+    # stiffness and mass factors inside K do not commute at the boundary rows), only the pairs the symmetry of the square
+    # protects (i + j odd, a two-dimensional irreducible representation) stay together: 5 among the 20 lowest; the
+    # "accidental" ones ((2,0)/(0,2), (3,1)/(1,3), (4,0)/(0,4)) split by 4e-5 ... 2e-4 and are distinct by the reference's rule
+    assert len(pairs) >= (5 if std else 8), lam
     assert all(abs(lam[b] - lam[a]) > 1e-12 * lam[b] for a, b in pairs)      # split by epsilon, not exactly repeated
     f0 = design.thermal_compliance(lam, Q, vec)
     Qb, lamb = design.thermal_compliance_seeds(lam, Q, vec)
