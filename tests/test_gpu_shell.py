@@ -191,7 +191,7 @@ def test_c5_full_size_properties():
     del a, b, psi_r
     # The whole gradient against finite differences over EVERY design variable, the two parts of
     # f = w . ln(lam) + sum_i Phib_i . phi_i separately: neighbouring loads are as close as 6e-3, so a central difference
-    # with a step that keeps the rounding of the quotient small (1e-5) carries a truncation term from mode veering
+    # with a step that keeps the rounding of the quotient small (5e-5) carries a truncation term from mode veering
     # (4e-3 on the two upper-skin groups) -- Richardson extrapolation over the steps h and 2h removes it (the h^2 term),
     # leaving h^4 / gap^4.  Eigenvalue part: eigenvalues are accurate to ~1e-12, gate 1e-6.  Eigenvector part:
     # eigenvectors accurate to ~1e-9 (cond(K) ~ 1e7) times |Phib| ~ 8e2 per mode over 2 h t: gate 1e-5.
@@ -201,7 +201,8 @@ def test_c5_full_size_properties():
     dfdx_vec = dfdx - dfdx_lam
     del zero_blk
     t_base = box.t.copy()
-    h = 1e-5
+    h = 5e-5   # (relative steps h and 2h: the loads move by ~1e-4 of themselves, a sixtieth of the closest gap; at 1e-5 the
+    # rounding of the quotient -- eigenvalues good to 1e-12 over a thickness step of 2e-7 -- was 1.5e-6 / 1.9e-5 of the two parts)
 
     def parts(t):
         dev.assemble(t)
