@@ -1074,6 +1074,77 @@ def test_column_compaction_of_the_krylov_stacks_changes_no_column():
 
 
 @pytest.mark.parametrize("mode", ["buckling", "normal"])
+def test_deflating_extra_converged_pairs_leaves_psi_unchanged(monkeypatch, mode):
+    """
+    IRAM converges pairs beyond the N requested ones and solve_adjoint(method="sibk") deflates them too (projectors on
+    [Phi | Phi_x], their share of psi in closed form, reference 385-389 extended to j > N): psi is unique, so it must
+    equal the solve with the reference's deflation set -- all three sibk forms, mode-sharded columns, fewer steps.  The
+    extra vectors go out of use when the caller replaces Phi by something they are not B-orthogonal to.
+    """
+    import eigd_amd as eg
+    from eigd_amd.device import default_context
+    from eigd_amd.problems import BucklingColumn, ThermalPlate
+
+    ctx = default_context()
+    rng = np.random.default_rng(11)
+    if mode == "buckling":
+        col = BucklingColumn(80, 80, seed=3)
+        K = col.stiffness()
+        u = col.full_vector(eg.SpLuOperator(K, ctx=ctx, check_symmetry=False)(col.f[col.reduced]))
+        A, B, sigma, N = col.geometric_stiffness(u), K, 1.0, 12
+    else:
+        pl = ThermalPlate(110, epsilon=0.13, rhoE=rng.uniform(0.3, 1.0, size=110 * 110))   # (distinct eigenvalues)
+        A, B, sigma, N = pl.stiffness(), pl.mass(), -0.1, 12
+    n = B.shape[0]
+    P = (B + sigma * A) if mode == "buckling" else (A - sigma * B)
+    fac = eg.SpLuOperator(P.tocsr(), ctx=ctx, check_symmetry=False)
+    monkeypatch.setenv("EIGD_IRAM_BLOCK", "4")            # (small problem: the block solver is not the automatic choice)
+    Phib = rng.uniform(-1, 1, size=(n, N))
+    out = {}
+    for extra in (0, 9):
+        s = eg.IRAM(N=N, m=2 * N + 13, mode=mode, ctx=ctx, extra=extra)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            lam, Phi = s.solve(A, B, fac, sigma)
+        assert s.n_extra == extra and s.block_size == 4
+        V, T = s.V, s.T
+        assert V.shape == (n, s.m) and np.linalg.norm(V.T @ (B @ V) - np.eye(s.m)) < 1e-10
+        psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-12, update_guess=False, bs_target=1)
+        res, _ = s.eval_adjoint_residual_norm(Phib, psi, b_ortho=True)
+        assert res.max() < 1e-9 * np.linalg.norm(Phib)
+        out[extra] = (s, lam, Phi, psi, list(s.last_info))
+    s0, lam0, Phi0, psi0, it0 = out[0]
+    s9, lam9, Phi9, psi9, it9 = out[9]
+    assert relerr(lam9, lam0) < 1e-12
+    sg = np.sign(np.einsum("ij,ij->j", Phi9, Phi0))
+    # psi_i is odd in phi_i only through the right-hand side b_i = -(Phib_i - B phi_i (phi_i . Phib_i)): sign free
+    assert relerr(psi9, psi0) < 1e-9
+    assert sum(it9) < sum(it0) and max(it9) <= max(it0)
+    # the other forms of sibk and a mode-sharded solve with the extra pairs
+    for kw in ({"bs_target": 2, "update_guess": False}, {"bs_target": 1, "update_guess": True}):
+        pk, _ = s9.solve_adjoint(Phib, method="sibk", rtol=1e-12, **kw)
+        assert relerr(pk, psi0) < 1e-9, kw
+
+    class OneOfThree:
+        rank, size = 1, 3
+
+        def allreduce_sum(self, a):
+            return a
+
+    pr, _ = s9.solve_adjoint(Phib, method="sibk", rtol=1e-12, comm=OneOfThree())
+    assert relerr(pr[:, 1::3], psi0[:, 1::3]) < 1e-9 and np.all(pr[:, 0::3] == 0.0)
+    # a replaced Phi the extra vectors are not orthogonal to: they go out of use, the solve is the plain one
+    Q = Phi9.copy()
+    Q[:, -1] = s9._prob.Phix.get()[:, 0]                      # (no longer an eigenvector set of the first N pairs)
+    s9.Phi = Q
+    s9._sync_phi()
+    assert s9._prob.PhiD is None
+    s9.Phi = Phi9 * sg                                          # signs flipped: still orthogonal, back in use
+    s9._sync_phi()
+    assert s9._prob.PhiD is not None and s9._prob.PhiD.k == N + 9
+
+
+@pytest.mark.parametrize("mode", ["buckling", "normal"])
 def test_two_krylov_steps_per_gram_schmidt_pass_match_the_one_step_solver(monkeypatch, mode):
     """
     The lock-step sibk with two operator applications per Gram-Schmidt pass (EIGD_SSTEP=2, the default) against the

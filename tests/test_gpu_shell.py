@@ -204,13 +204,21 @@ def test_c5_full_size_properties():
     h = 5e-5   # (relative steps h and 2h: the loads move by ~1e-4 of themselves, a sixtieth of the closest gap; at 1e-5 the
     # rounding of the quotient -- eigenvalues good to 1e-12 over a thickness step of 2e-7 -- was 1.5e-6 / 1.9e-5 of the two parts)
 
+    dKPhi0 = ctx.from_host(KP)                 # K Phi at the base point: the perturbed modes are matched to the base modes
+    # through the K inner product (modes of different symmetry classes of the box cross without veering: over a step of
+    # 1e-4 two of the 64 loads of the upper-skin groups change places, and a pairing by index then differentiates
+    # Phib_i . phi_{i+1})
+
     def parts(t):
         dev.assemble(t)
         assert dev.refactor(sigma) == 0
         s2 = eg.IRAM(N=N, m=129, mode="buckling", ctx=ctx, extra=0)   # (no adjoint stage follows: no extra pairs)
         l2, P2 = s2.solve(dev.dG, dev.dK, dev.factor, sigma)
-        sg = np.sign(np.einsum("ij,ij->j", P2, Phi))
-        return np.array([float(w @ np.log(l2)), float(np.einsum("ij,ij->", Phib, P2 * sg))])
+        O = s2._prob.Phi.tdot(dKPhi0)                                  # O[j, i] = phi'_j . K phi_i
+        match = np.argmax(np.abs(O), axis=0)
+        assert len(set(match.tolist())) == N and np.abs(O[match, np.arange(N)]).min() > 0.7
+        sg = np.sign(O[match, np.arange(N)])
+        return np.array([float(w @ np.log(l2[match])), float(np.einsum("ij,ij->", Phib, P2[:, match] * sg))])
 
     fd = np.zeros((box.ngroups, 2))
     for g in range(box.ngroups):

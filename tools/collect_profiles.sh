@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round evidence for profiles/: kernel-trace statistics of the bench command, the two PMC passes over the sweep and
+# the SpMV (separate runs: --pmc with --kernel-trace only), the per-level table.  Run on the GPU box from the repo root:
+#   tools/collect_profiles.sh r03 [stats|pmc|all]
+# Results land in gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
+tag=${1:-r03}
+what=${2:-all}
+root=$(pwd)
+out=$root/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+if [ "$what" = "stats" ] || [ "$what" = "all" ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 3 --warmup 1 \
+      --cpu-sample none --no-fd-check --numpy-steps 0 > $out/profiled_run.json 2> $out/profiled_run.log || exit 1
+  cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/bench_c3_kernel_stats.csv
+fi
+if [ "$what" = "pmc" ] || [ "$what" = "all" ]; then
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_sweep_$ctr -- python3 $root/tools/pmc_sweep.py \
+        > $out/pmc_sweep_$ctr.log 2>&1 || exit 1
+    cp $(find $out/pmc_sweep_$ctr -name "*counter_collection.csv" | head -1) $out/pmc_${ctr}_sweep_coldot.csv
+    (cd $root && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_spmv_$ctr -- python3 tools/pmc_spmv.py \
+        > $out/pmc_spmv_$ctr.log 2>&1) || exit 1
+    cp $(find $out/pmc_spmv_$ctr -name "*counter_collection.csv" | head -1) $out/pmc_${ctr}_spmv_coldot.csv
+  done
+fi
+ls -la $out | head -40
