@@ -387,8 +387,11 @@ def main():
     dAdx = ElementBilinear(ctx, col.elem_dofs, col.Ge_unit, scale=col.dG_scale())  # d(w^T G v)/d rhoE at fixed u
     ndv = col.mesh.nelems
 
+    import eigd_amd.adjoint as _adj
+
     def step():
         factor.count = 0
+        _adj.LAST_ROUND["gs_cycles"] = _adj.LAST_ROUND["gs_correcting_passes"] = 0
         dpsi, data = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1,
                                           comm=comm, streams=args.streams)
         dfdx = solver.add_total_derivative(lamb, dPhib, dpsi, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data,
@@ -646,6 +649,10 @@ def main():
         "sibk_iterations": [int(i) for i in solver.last_info],
         "eigensolve_sweeps": int(eig_count),
         "eigensolver": eig_info,
+        "lock_step": {"steps_per_gram_schmidt_pass": _adj.LAST_ROUND.get("steps_per_pass"),
+                      "inner_projections": _adj.LAST_ROUND.get("inner_projections"),
+                      "cycles": _adj.LAST_ROUND.get("gs_cycles"),
+                      "correcting_gram_schmidt_passes": _adj.LAST_ROUND.get("gs_correcting_passes")},
         # one design point of an optimisation loop as the reference's harness runs it (buckling.py:548-632, 874-986):
         # assembly + factorisation (device: K, G(u), K + sigma G, numeric factor) + eigensolve + the timed step
         "design_point_s": round(timing["device_assemble_and_refactor_s"] + timing["eigensolve_s"] + ms_per_step * 1e-3, 4),
