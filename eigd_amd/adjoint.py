@@ -804,10 +804,12 @@ def pair_arnoldi_columns(Hc, Czc, j, h1, g1, b1, gamma, b2):
 def _skip_inner_projections():
     import os
 
-    # EIGD_INNER_PROJ=0: one projection of the raw pair in place of the two behind the operator applications (see
-    # _sibk_round_pair.enqueue_cycle).  Measured at C3: 87.8 against 87.9 ms per step -- the 64-column projection of the
-    # pair costs what the two 32-column ones cost -- so the reference's placement (1250-1252) is the default.
-    return os.environ.get("EIGD_INNER_PROJ", "1") == "0"
+    # one projection of the raw pair in place of the two behind the operator applications (see
+    # _sibk_round_pair.enqueue_cycle).  Measured at C3: 87.8 against 87.9 ms per step with 32 columns (the 64-column
+    # projection of the pair costs what the two 32-column ones cost), 40.3 against 43.8 ms for the four modes of rank 7 of
+    # 8 (narrow blocks: a projection is the stream of Phi and B Phi whatever its width).  EIGD_INNER_PROJ=1: the reference's
+    # placement (1250-1252) whatever the measured invariance of range(P).
+    return os.environ.get("EIGD_INNER_PROJ", "0") != "1"
 
 
 def _pair_defect_tol():

@@ -1205,13 +1205,13 @@ def test_two_krylov_steps_per_gram_schmidt_pass_match_the_one_step_solver(monkey
     monkeypatch.setenv("EIGD_SSTEP", "2")
     pb, _ = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, maxiter=7, nrestart=0)
     assert relerr(pb, pa) < 1e-10
-    # option: ONE projection of the raw pair in place of the two behind the operator applications (1250-1252), valid when
-    # the measured invariance of range(P) allows (converged eigenvectors): same counts, same psi
+    # ONE projection of the raw pair in place of the two behind the operator applications (1250-1252) when the measured
+    # invariance of range(P) allows (converged eigenvectors; the default): same counts, same psi as the reference's placement
     monkeypatch.setenv("EIGD_SSTEP", "2")
-    assert _adj.LAST_ROUND["inner_projections"] is True
-    monkeypatch.setenv("EIGD_INNER_PROJ", "0")
+    assert _adj.LAST_ROUND["inner_projections"] is False
+    monkeypatch.setenv("EIGD_INNER_PROJ", "1")
     pd, _ = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1)
-    assert _adj.LAST_ROUND["inner_projections"] is False and list(s.last_info) == info2
+    assert _adj.LAST_ROUND["inner_projections"] is True and list(s.last_info) == info2
     assert relerr(psi2, pd) < 1e-11
     monkeypatch.delenv("EIGD_INNER_PROJ")
     # a Krylov history deeper than one coefficient block of the pair kernels (maxiter > 120 at 32 columns): the one-step
