@@ -68,6 +68,8 @@ struct FrontArrays {
   int W;                // instead of branching around the load, which would serialise the loads of a tile
   int tri;              // 1: the diagonal blocks of T are lower triangular (Cholesky / sign-tracked path); 0: dense 64 x 64
                         // diagonal blocks (Bunch-Kaufman path: pivoting inside the panel), the sweeps skip no part of them
+  double pivtol;        // Bunch-Kaufman path: a pivot column whose largest entry inside the panel block is below this
+                        // (sqrt(eps) * max |a_ij|) is singular to the panel: its diagonal is set to +-pivtol (static pivot)
 };
 
 constexpr int kPlaneCols = 4 + 8 + 16 + 32;  // one set of carry planes per sweep width
@@ -182,7 +184,10 @@ __global__ __launch_bounds__(kThreads) void potrf_inv_kernel(FrontArrays fa, con
 // D = Q diag(e) Q^T, so that A_pp = M S M^T with M = P^T L Q |e|^(1/2) and S = diag(sign e).  M is a dense block, but
 // the rest of the factorisation and the sweeps only ever use inv(M) (trsm as a product, T = inv(M11) explicit), so
 // nothing else changes: the permutation never leaves this kernel and the symbolic structure stays what it was.
-// Pivots are not delayed to the parent front: a front whose own block is singular by itself still fails.
+// Pivots are not delayed to the parent front.  A column that is singular INSIDE its panel block (largest candidate below
+// sqrt(eps) |A|: a front whose own block is singular by itself, which SuperLU's partial pivoting over the whole column
+// survives) gets a STATIC pivot instead, as SuperLU_DIST / PARDISO do: its diagonal is replaced by +-sqrt(eps) |A|, the
+// replacements are counted (flag[2]) and the caller refines every solve against the true matrix a few times.
 __global__ __launch_bounds__(kThreads) void ldlt_bk_inv_kernel(FrontArrays fa, const int* __restrict__ fronts, int step,
                                                               double* __restrict__ F, double* __restrict__ Inv,
                                                               int* __restrict__ flag) {
@@ -219,8 +224,13 @@ __global__ __launch_bounds__(kThreads) void ldlt_bk_inv_kernel(FrontArrays fa, c
       }
       int kp = k, kstep = 1;
       const double big = fmax(absakk, colmax);
-      if (!(big > 0.0) || !(big < 1.0e300)) {
-        s_bad = 1;  // the whole column is zero / not finite: singular to working precision
+      if (!(big >= 0.0) || !(big < 1.0e300)) {
+        s_bad = 1;  // not finite
+      } else if (big <= fa.pivtol) {
+        // no usable pivot in this column of the panel block: static pivot
+        A[k * TLD + k] = (A[k * TLD + k] < 0.0) ? -fa.pivtol : fa.pivtol;
+        atomicAdd(flag + 2, 1);
+        if (!(fa.pivtol > 0.0)) s_bad = 1;  // (all-zero matrix)
       } else if (absakk < alpha * colmax) {
         double rowmax = 0.0;
         for (int j = k; j < w; ++j)
@@ -2056,6 +2066,8 @@ struct eigd_factor {
   int* d_cmask = nullptr;
   double *d_data = nullptr, *d_F = nullptr, *d_Inv = nullptr, *d_V = nullptr, *d_Y = nullptr, *d_sgn = nullptr;
   int n_negative = 0;
+  int n_perturbed = 0;     // static pivots of the Bunch-Kaufman path (columns singular inside their panel block)
+  double pivtol = 0.0;
   bool pivoted = false;  // the last numeric phase ran the Bunch-Kaufman panel kernel (dense diagonal blocks in T)
   int* d_flag = nullptr;
   size_t bytes = 0;
@@ -2084,6 +2096,7 @@ struct eigd_factor {
     a.neg1 = reinterpret_cast<const int*>(d_aux + 1);
     a.W = sym->W;
     a.tri = pivoted ? 0 : 1;
+    a.pivtol = pivtol;
     return a;
   }
 };
@@ -2107,7 +2120,7 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false, bool piv
     EIGD_HIP(hipMemcpyAsync(f->d_data, data, sizeof(double) * f->data_len,
                             on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   EIGD_HIP(hipMemsetAsync(f->d_F, 0, sizeof(double) * s.front_doubles, st));
-  EIGD_HIP(hipMemsetAsync(f->d_flag, 0, 2 * sizeof(int), st));
+  EIGD_HIP(hipMemsetAsync(f->d_flag, 0, 3 * sizeof(int), st));
   {
     const int nb = static_cast<int>(std::min<int64_t>((s.nlower + 255) / 256, 65536));
     hipLaunchKernelGGL(scatter_a_kernel, dim3(std::max(nb, 1)), dim3(256), 0, st, s.nlower, f->d_a_src, f->d_a_dst,
@@ -2172,14 +2185,23 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false, bool piv
                        f->d_T, f->d_Fm, f->d_Bm);
     EIGD_LAUNCH_CHECK();
   }
-  int flag[2] = {0, 0};
-  EIGD_HIP(hipMemcpyAsync(flag, f->d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  int flag[3] = {0, 0, 0};
+  EIGD_HIP(hipMemcpyAsync(flag, f->d_flag, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
   EIGD_HIP(hipStreamSynchronize(st));
   f->n_negative = flag[1];
+  f->n_perturbed = flag[2];
   // Not positive definite (negative or unusable pivots on the Cholesky path): the shift lies inside the spectrum.
   // Factor again with Bunch-Kaufman pivoting inside the panels -- the positive definite shifts of the reference's
   // examples never come here and keep the plain (bitwise unchanged) Cholesky path.
-  if (!pivot && (flag[0] != 0 || flag[1] != 0)) return numeric(f, nullptr, true, true);
+  if (!pivot && (flag[0] != 0 || flag[1] != 0)) {
+    // the threshold of the static pivots: sqrt(eps) * max |a_ij| (the values are on the device by now)
+    std::vector<double> h(f->data_len);
+    EIGD_HIP(hipMemcpy(h.data(), f->d_data, sizeof(double) * f->data_len, hipMemcpyDeviceToHost));
+    double amax = 0.0;
+    for (double v : h) amax = std::max(amax, std::fabs(v));
+    f->pivtol = 1.4901161193847656e-08 * amax;
+    return numeric(f, nullptr, true, true);
+  }
   if (flag[0] != 0) {
     set_error("zero or non-finite pivot in front %d: the (shifted) matrix is singular to working precision -- move the "
               "shift away from an eigenvalue",
@@ -3060,7 +3082,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   rc = dmalloc(&f->d_Y, static_cast<size_t>(s.sumd) * KBMAX);
   rc = dmalloc(&f->d_sgn, static_cast<size_t>(s.n));
   if (rc == EIGD_OK) {
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_flag), 2 * sizeof(int));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_flag), 3 * sizeof(int));
     if (e != hipSuccess) {
       set_error("hipMalloc failed: %s", hipGetErrorString(e));
       rc = EIGD_E_HIP;
@@ -3197,9 +3219,10 @@ int eigd_factor_lane_solve_to(eigd_lane* l, const double* dIn, int ldin, double*
 
 int eigd_factor_stats(eigd_factor* f, double* out, int nout) {
   EIGD_REQUIRE(f && out && nout >= 1, "null argument");
-  const double v[5] = {static_cast<double>(f->sym->nnzL), static_cast<double>(f->bytes), f->sym->flops,
-                       static_cast<double>(f->sym->nfronts), static_cast<double>(f->n_negative)};
-  for (int i = 0; i < nout && i < 5; ++i) out[i] = v[i];
+  const double v[6] = {static_cast<double>(f->sym->nnzL), static_cast<double>(f->bytes), f->sym->flops,
+                       static_cast<double>(f->sym->nfronts), static_cast<double>(f->n_negative),
+                       static_cast<double>(f->n_perturbed)};
+  for (int i = 0; i < nout && i < 6; ++i) out[i] = v[i];
   return EIGD_OK;
 }
 

@@ -829,6 +829,8 @@ class Factor:
         h = c_vp()
         call("eigd_factor_create", ctx.h, self.symbolic.h, hptr(data), C.byref(h))
         self.h = h
+        if self.stats()["static_pivots"] > 0:
+            self.verify_static_pivots(CSRMatrix(ctx, A))
 
     def __del__(self):
         try:
@@ -848,6 +850,38 @@ class Factor:
         self.symbolic.check_pattern(A)
         data = np.ascontiguousarray(A.data, dtype=np.float64)
         call("eigd_factor_refactor", self.h, hptr(data))
+        if self.stats()["static_pivots"] > 0:
+            self.verify_static_pivots(CSRMatrix(self.ctx, A))
+
+    def refine(self, mat_dev, B, X, alpha=1.0, steps=1):
+        """X <- X + mat^{-1} (alpha B - mat X), ``steps`` times: iterative refinement of X ~ alpha mat^{-1} B on device blocks"""
+        R = X.ctx.empty(X.n, X.k)
+        for _ in range(steps):
+            mat_dev.apply(X, R)
+            R.assign_lincomb([(alpha, B), (-1.0, R)])
+            self.solve_to(R, R, 1.0)
+            X.assign_lincomb([(1.0, X), (1.0, R)])
+        return X
+
+    STATIC_PIVOT_REFINEMENTS = 3
+
+    def verify_static_pivots(self, mat_dev):
+        """
+        The factorisation replaced pivots that were singular inside their panel block by +-sqrt(eps) |A| (static pivots,
+        see ldlt_bk_inv_kernel): it is the factor of a nearby matrix, good as a preconditioner of a few refinement steps
+        -- unless the matrix itself is singular to working precision, which partial pivoting over whole columns
+        (SuperLU, reference 13) would have reported.  One refined solve of a random system tells the two apart.
+        """
+        b = self.ctx.from_host(np.random.default_rng(0).uniform(-1.0, 1.0, size=(self.n, 1)))
+        x = self.solve_to(b, self.ctx.empty(self.n, 1))
+        self.refine(mat_dev, b, x, steps=self.STATIC_PIVOT_REFINEMENTS)
+        r = mat_dev.apply(x)
+        r.assign_lincomb([(1.0, r), (-1.0, b)])
+        rel = float(r.colnorms()[0] / b.colnorms()[0])
+        if not rel < 1e-8:
+            raise _ffi.NotPositiveDefiniteError(
+                f"the (shifted) matrix is singular to working precision ({self.stats()['static_pivots']} static pivots, "
+                f"relative residual {rel:.1e} after refinement): move the shift away from an eigenvalue")
 
     def refactor_device(self, vals):
         """numeric refactorisation from CSR values that already live on the device (ElementAssembler.assemble)"""
@@ -884,10 +918,10 @@ class Factor:
         return lanes[key][0]
 
     def stats(self):
-        out = np.zeros(5)
-        call("eigd_factor_stats", self.h, hptr(out), 5)
+        out = np.zeros(6)
+        call("eigd_factor_stats", self.h, hptr(out), 6)
         return {"nnzL": int(out[0]), "device_bytes": int(out[1]), "flops": float(out[2]), "nfronts": int(out[3]),
-                "negative_pivots": int(out[4])}
+                "negative_pivots": int(out[4]), "static_pivots": int(out[5])}
 
     def solve_bytes(self, k):
         b = C.c_double()

@@ -42,9 +42,13 @@ class SpLuOperator(LinearOperator):
     first buckling load); for a shift inside the spectrum (the reference's CRM example, sigma = omega_0^2) the numeric
     phase is repeated with Bunch-Kaufman pivoting (1 x 1 and 2 x 2 pivots, interchanges inside the 64-column panel of
     a front, so the symbolic structure is kept; ``negative_pivots`` = number of eigenvalues of the pencil below the
-    shift) and every application is followed by one step of iterative refinement.  A panel block that is singular
-    to working precision raises ``NotPositiveDefiniteError`` (a ``numpy.linalg.LinAlgError``): the shift sits on an
-    eigenvalue (pivots are not delayed to the parent front).
+    shift) and every application is followed by one step of iterative refinement.  Pivots are not delayed to the parent
+    front; a column that is singular inside its panel block -- a front whose own block is singular by itself, which
+    SuperLU's partial pivoting over whole columns survives -- gets a static pivot of +-sqrt(eps) |mat| instead
+    (``static_pivots`` counts them; SuperLU_DIST and PARDISO do the same) and every application is then refined three
+    times against the true matrix.  A matrix that is singular to working precision as a whole is told apart by one
+    refined solve of a random system at factorisation time and raises ``NotPositiveDefiniteError`` (a
+    ``numpy.linalg.LinAlgError``): the shift sits on an eigenvalue.
     """
 
     def __init__(self, mat, ctx=None, symbolic=None, leaf_size=0, panel_width=0, check_symmetry=True, coords=None):
@@ -79,20 +83,25 @@ class SpLuOperator(LinearOperator):
         self.factor = Factor(self.ctx, csr, symbolic=symbolic, leaf_size=leaf_size, panel_width=panel_width,
                              coords=coords)
         self.symbolic = self.factor.symbolic
-        self.negative_pivots = self.factor.stats()["negative_pivots"]
-        # indefinite: LDL^T without pivoting is only conditionally stable -> one refinement step per application
-        self._mat_dev = CSRMatrix(self.ctx, csr) if self.negative_pivots > 0 else None
+        self._read_inertia()
+        # indefinite: pivoting is confined to the panel blocks -> one refinement step per application (three when static
+        # pivots were needed)
+        self._mat_dev = CSRMatrix(self.ctx, csr) if self._pivoted() else None
+
+    def _pivoted(self):
+        return self.negative_pivots > 0 or self.static_pivots > 0
+
+    def _read_inertia(self):
+        st = self.factor.stats()
+        self.negative_pivots = st["negative_pivots"]
+        self.static_pivots = st["static_pivots"]   # pivots singular inside their panel block, replaced by +-sqrt(eps)|A|
+        self._refine_steps = self.factor.STATIC_PIVOT_REFINEMENTS if self.static_pivots > 0 else 1
 
     def _refine(self, B, X, alpha):
-        """X <- X + alpha * mat^{-1} (B - mat X / alpha) ... one step of iterative refinement on device blocks"""
+        """X <- X + mat^{-1} (alpha B - mat X): iterative refinement on device blocks (one step; three with static pivots)"""
         # everything on X's context: with concurrent mode groups (streams > 1) X lives on a forked context whose
         # stream and sweep lane must carry the whole refinement step
-        R = X.ctx.empty(X.n, X.k)
-        self._mat_dev.apply(X, R)                        # mat X   (X = alpha * approx(mat^{-1} B))
-        R.assign_lincomb([(alpha, B), (-1.0, R)])        # alpha B - mat X
-        self.factor.solve_to(R, R, 1.0)
-        X.assign_lincomb([(1.0, X), (1.0, R)])
-        return X
+        return self.factor.refine(self._mat_dev, B, X, alpha, steps=self._refine_steps)
 
     # -- device path (used by the drivers) ------------------------------------
     def solve_device(self, X, alpha=1.0, count=None):
@@ -125,18 +134,20 @@ class SpLuOperator(LinearOperator):
         the device CSRMatrix holding the same values (``indefinite_matrix``) for the refinement step.
         """
         self.factor.refactor_device(vals)
-        self.negative_pivots = self.factor.stats()["negative_pivots"]
-        if self.negative_pivots > 0 and indefinite_matrix is None:
+        self._read_inertia()
+        if self._pivoted() and indefinite_matrix is None:
             raise ValueError("indefinite refactorisation: pass the device matrix for the refinement step")
-        self._mat_dev = indefinite_matrix if self.negative_pivots > 0 else None
+        self._mat_dev = indefinite_matrix if self._pivoted() else None
+        if self.static_pivots > 0:
+            self.factor.verify_static_pivots(self._mat_dev)
 
     def refactor(self, mat):
         """numeric refactorisation with new values on the same sparsity pattern"""
         csr = mat.tocsr().astype(np.float64)
         csr.sort_indices()
         self.factor.refactor(csr)
-        self.negative_pivots = self.factor.stats()["negative_pivots"]
-        self._mat_dev = CSRMatrix(self.ctx, csr) if self.negative_pivots > 0 else None
+        self._read_inertia()
+        self._mat_dev = CSRMatrix(self.ctx, csr) if self._pivoted() else None
 
     def solve_device_dual(self, Xr, Xi, count=None):
         """complex-step operand (Xr + i Xi) <- mat^{-1} (Xr + i Xi) in place on two device blocks (see __init__)"""

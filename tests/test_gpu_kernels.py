@@ -2,6 +2,8 @@
 GPU parity of every C-ABI kernel against numpy / scipy on seeded inputs.
 Bit-exact where the arithmetic order is the reference's (SpMV), tight tolerances elsewhere.
 """
+import warnings
+
 import numpy as np
 import pytest
 from scipy import sparse
@@ -638,6 +640,56 @@ def test_bunch_kaufman_pivoting_inside_the_fronts(ctx):
     # a positive definite matrix never takes the pivoting path: same bits as before
     opd = eg.SpLuOperator((K + 0.3 * M).tocsc(), ctx=ctx)
     assert opd.negative_pivots == 0 and relerr(opd(B), splu((K + 0.3 * M).tocsc()).solve(B)) < 1e-12
+
+
+def test_front_singular_by_itself_gets_a_static_pivot(ctx):
+    """
+    Verdict r2 item 9: a shifted matrix whose LEAF front is singular by itself while the matrix is not.  SuperLU's
+    partial pivoting over the whole column does not notice (reference eigenvector_derivatives.py:11-23; examples/crm.py
+    puts sigma inside the spectrum); Bunch-Kaufman pivoting confined to the panel block finds no pivot there.  The
+    column gets a static pivot (+-sqrt(eps) |mat|, counted in ``static_pivots``) and the solves are refined three
+    times: SuperLU-level results; a matrix that is singular as a whole still raises.
+    """
+    import eigd_amd as eg
+    from eigd_amd._ffi import NotPositiveDefiniteError
+    from eigd_amd.device import Symbolic
+
+    K = grid_matrix(26, 22, 1, seed=4)
+    n = K.shape[0]
+    rng = np.random.default_rng(8)
+    M = sparse.diags(rng.uniform(0.5, 1.5, size=n)).tocsr()
+    sym = Symbolic(K, leaf_size=24)
+    perm, c0, ns, lvl = sym.array("perm"), sym.array("f_c0"), sym.array("f_ns"), sym.array("f_level")
+    leaf = int(np.flatnonzero(lvl == lvl.min())[0])
+    idx = perm[c0[leaf]: c0[leaf] + ns[leaf]]                       # the dofs the leaf front eliminates
+    assert 4 <= len(idx) <= 64
+    Md = M.diagonal()
+    Kl = K.toarray()[np.ix_(idx, idx)]
+    ev = np.linalg.eigvalsh(np.diag(Md[idx] ** -0.5) @ Kl @ np.diag(Md[idx] ** -0.5))
+    lam_all = np.linalg.eigvalsh(np.diag(Md ** -0.5) @ K.toarray() @ np.diag(Md ** -0.5))
+    B = rng.normal(size=(n, 5))
+    for q in (0, len(ev) // 2):
+        sigma = ev[q]                                                # (K - sigma M) restricted to the leaf is singular
+        assert np.min(np.abs(lam_all - sigma)) > 1e-4 * abs(sigma)   # ... the matrix itself is not
+        mat = (K - sigma * M).tocsr()
+        op = eg.SpLuOperator(mat.tocsc(), ctx=ctx, leaf_size=24)
+        assert op.static_pivots >= 1
+        X = op(B)
+        Xr = splu(mat.tocsc()).solve(B)
+        assert np.linalg.norm(mat @ X - B) / np.linalg.norm(B) < 1e-10, sigma
+        assert relerr(X, Xr) < 1e-8, sigma
+    # shift-invert Lanczos and the adjoint stage on top of such a factor
+    sigma = ev[0]
+    op = eg.SpLuOperator((K - sigma * M).tocsc(), ctx=ctx, leaf_size=24)
+    s = eg.BasicLanczos(N=4, m=60, tol=1e-12, ctx=ctx)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lam, Phi = s.solve(K, M, op, sigma)
+    near = np.sort(lam_all[np.argsort(np.abs(lam_all - sigma))[:4]])
+    assert relerr(np.sort(lam), near) < 1e-9
+    # singular as a whole (sigma on an eigenvalue of the pencil): still an error, not garbage
+    with pytest.raises(NotPositiveDefiniteError):
+        eg.SpLuOperator((K - lam_all[5] * M).tocsc(), ctx=ctx, leaf_size=24)
 
 
 def test_interior_shift_eigenpairs_and_adjoint_with_streams(ctx):

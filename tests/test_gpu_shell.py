@@ -190,24 +190,22 @@ def test_c5_full_size_properties():
     assert relerr(a, b) < 1e-8
     del a, b, psi_r
     # The whole gradient against finite differences over EVERY design variable, the two parts of
-    # f = w . ln(lam) + sum_i Phib_i . phi_i separately: neighbouring loads are as close as 6e-3, so a central difference
-    # with a step that keeps the rounding of the quotient small (5e-5) carries a truncation term from mode veering
-    # (4e-3 on the two upper-skin groups) -- Richardson extrapolation over the steps h and 2h removes it (the h^2 term),
-    # leaving h^4 / gap^4.  Eigenvalue part: eigenvalues are accurate to ~1e-12, gate 1e-6.  Eigenvector part:
-    # eigenvectors accurate to ~1e-9 (cond(K) ~ 1e7) times |Phib| ~ 8e2 per mode over 2 h t: gate 1e-5.
+    # f = w . ln(lam) + sum_i Phib_i . phi_i separately, central differences at the relative steps h, 2h, 4h, 8h (h = 1e-5)
+    # with Richardson extrapolation.  Neighbouring loads are as close as 6e-3 and two of the upper-skin groups move a
+    # pair of modes through a veering zone about 1.6e-4 wide: a plain central difference at 1e-5 is 4e-3 off there, the
+    # two-level extrapolation (h, 2h) still 2e-5 (its h^4 term), steps of 5e-5 and more are outside the zone's radius of
+    # convergence altogether (measured: 4e-2).  Eigenvector part: three levels (h, 2h, 4h; the h^6 term is 6e-8), gate
+    # 1e-5.  Eigenvalue part: smooth through the zone (the two loads exchange roles) but its quotient is noisy at small
+    # steps (eigenvalues good to 1e-12 over a thickness step of 2e-7): two levels (4h, 8h), gate 1e-6.
     zero_blk = ctx.zeros(box.n, N)
     dfdx_lam = s.add_total_derivative(w, zero_blk, zero_blk, dAdx, dBdx, np.zeros(box.ngroups), adj_corr_data={},
                                       deriv_type="tensor")
     dfdx_vec = dfdx - dfdx_lam
     del zero_blk
     t_base = box.t.copy()
-    h = 5e-5   # (relative steps h and 2h: the loads move by ~1e-4 of themselves, a sixtieth of the closest gap; at 1e-5 the
-    # rounding of the quotient -- eigenvalues good to 1e-12 over a thickness step of 2e-7 -- was 1.5e-6 / 1.9e-5 of the two parts)
-
+    h = 1e-5
     dKPhi0 = ctx.from_host(KP)                 # K Phi at the base point: the perturbed modes are matched to the base modes
-    # through the K inner product (modes of different symmetry classes of the box cross without veering: over a step of
-    # 1e-4 two of the 64 loads of the upper-skin groups change places, and a pairing by index then differentiates
-    # Phib_i . phi_{i+1})
+    # through the K inner product, not by their place in the order of the loads
 
     def parts(t):
         dev.assemble(t)
@@ -223,14 +221,15 @@ def test_c5_full_size_properties():
     fd = np.zeros((box.ngroups, 2))
     for g in range(box.ngroups):
         d = []
-        for step in (h, 2.0 * h):
+        for step in (h, 2.0 * h, 4.0 * h, 8.0 * h):
             f = []
             for sgn in (1.0, -1.0):
                 t = t_base.copy()
                 t[g] += sgn * step * t_base[g]
                 f.append(parts(t))
             d.append((f[0] - f[1]) / (2.0 * step * t_base[g]))
-        fd[g] = (4.0 * d[0] - d[1]) / 3.0
+        fd[g, 0] = (4.0 * d[2][0] - d[3][0]) / 3.0
+        fd[g, 1] = (64.0 * d[0][1] - 20.0 * d[1][1] + d[2][1]) / 45.0
         print(f"C5: group {g}: FD {fd[g]} adjoint {dfdx_lam[g]:.6e} {dfdx_vec[g]:.6e} ({time.perf_counter() - t_start:.0f} s)",
               flush=True)
     e_lam, e_vec = relerr(dfdx_lam, fd[:, 0]), relerr(dfdx_vec, fd[:, 1])
