@@ -131,7 +131,7 @@ def test_shell_box_small_against_cpu_oracle():
     assert relerr(dfdx, fd) < 2e-6, (dfdx, fd)
 
 
-def test_c5_full_size_properties():
+def test_c5_full_size_properties(capsys):
     """~2.0 M dof, 64 modes (BASELINE configs[4]); everything on the device, the checks are size independent"""
     import eigd_amd as eg
     from eigd_amd.problems import ShellBox, ShellBoxOnDevice
@@ -230,8 +230,9 @@ def test_c5_full_size_properties():
             d.append((f[0] - f[1]) / (2.0 * step * t_base[g]))
         fd[g, 0] = (4.0 * d[2][0] - d[3][0]) / 3.0
         fd[g, 1] = (64.0 * d[0][1] - 20.0 * d[1][1] + d[2][1]) / 45.0
-        print(f"C5: group {g}: FD {fd[g]} adjoint {dfdx_lam[g]:.6e} {dfdx_vec[g]:.6e} ({time.perf_counter() - t_start:.0f} s)",
-              flush=True)
+        with capsys.disabled():   # (a line every ~35 s: the finite differences take four minutes, runners watch for silence)
+            print(f"C5: group {g}: FD {fd[g]} adjoint {dfdx_lam[g]:.6e} {dfdx_vec[g]:.6e} "
+                  f"({time.perf_counter() - t_start:.0f} s)", flush=True)
     e_lam, e_vec = relerr(dfdx_lam, fd[:, 0]), relerr(dfdx_vec, fd[:, 1])
     print(f"C5: df/dx vs Richardson-extrapolated central differences over all {box.ngroups} design variables: eigenvalue "
           f"part {e_lam:.2e}, eigenvector part {e_vec:.2e}, whole gradient {relerr(dfdx, fd.sum(axis=1)):.2e}; "
