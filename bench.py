@@ -147,13 +147,17 @@ def launch_ranks(nranks, argv=None, limit_s=None, poll_s=0.05):
 
 def measured_traffic(entry, sources):
     """
-    HBM bytes per launch from the committed PMC passes (profiles/r02_traffic.json, written by tools/pmc_report.py from
+    HBM bytes per launch from the committed PMC passes (profiles/r03_traffic.json, written by tools/pmc_report.py from
     the rocprofv3 --pmc CSVs), valid only for the kernel sources they were taken with: a changed kernel file gives null.
     """
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    try:
-        rec = json.load(open(path))[entry]
-    except (OSError, KeyError, ValueError):
+    rec = None
+    for name in ("r03_traffic.json", "r02_traffic.json"):      # the newest round's passes first
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))[entry]
+            break
+        except (OSError, KeyError, ValueError):
+            continue
+    if rec is None:
         return None, "no PMC record"
     for fn in sources:
         sha = hashlib.sha256(open(os.path.join(ROOT, "eigd_amd", "csrc", fn), "rb").read()).hexdigest()[:16]
