@@ -339,8 +339,17 @@ __global__ __launch_bounds__(kThreads) void ldlt_bk_inv_kernel(FrontArrays fa, c
         // eigen-decomposition of [[a, b], [b, cc]]: rotation by theta with tan(2 theta) = 2 b / (a - cc)
         const double th = 0.5 * atan2(2.0 * b, a - cc);
         const double cs = cos(th), sn = sin(th);
-        const double e1 = a * cs * cs + 2.0 * b * cs * sn + cc * sn * sn;
-        const double e2 = a * sn * sn - 2.0 * b * cs * sn + cc * cs * cs;
+        double e1 = a * cs * cs + 2.0 * b * cs * sn + cc * sn * sn;
+        double e2 = a * sn * sn - 2.0 * b * cs * sn + cc * cs * cs;
+        // a 2 x 2 pivot block that is singular itself (the matrix' own null direction can hide in one): static pivot
+        if (fabs(e1) <= fa.pivtol) {
+          e1 = (e1 < 0.0) ? -fa.pivtol : fa.pivtol;
+          if (c == 0) atomicAdd(flag + 2, 1);
+        }
+        if (fabs(e2) <= fa.pivtol) {
+          e2 = (e2 < 0.0) ? -fa.pivtol : fa.pivtol;
+          if (c == 0) atomicAdd(flag + 2, 1);
+        }
         const double x0 = x[i], x1 = x[i + 1];
         x[i] = (cs * x0 + sn * x1) / sqrt(fabs(e1));
         x[i + 1] = (-sn * x0 + cs * x1) / sqrt(fabs(e2));
