@@ -846,6 +846,38 @@ def test_foreign_factor_and_operators_are_honoured():
     assert relerr(psi, g["normal_sibk_psi"]) < RTOL
 
 
+def test_iram_wanted_ritz_values_spread_over_three_decades():
+    """
+    ADVICE r2: the noise floor of IRAM's convergence test scales with each Ritz value itself, not with the largest one.
+    A pencil whose wanted eigenvalues spread over three decades around the shift (theta = 1 / (lam - sigma) from 2e2 down
+    to 0.2): every returned pair against scipy's dense solution at 1e-8, residuals and eig_res small for the pairs far
+    from the shift too.
+    """
+    import eigd_amd as eg
+    from scipy import sparse
+    from scipy.linalg import eigh as dense_eigh
+
+    rng = np.random.default_rng(4)
+    n, N = 400, 10
+    # tridiagonal stiffness of a chain whose springs grow geometrically: eigenvalues spread over many decades
+    kspr = np.geomspace(1e-3, 1e3, n + 1)
+    K = sparse.diags([-kspr[1:-1], kspr[:-1] + kspr[1:], -kspr[1:-1]], [-1, 0, 1], format="csr")
+    M = sparse.diags(rng.uniform(0.5, 1.5, size=n)).tocsr()
+    lam_ref, Phi_ref = dense_eigh(K.toarray(), M.toarray())
+    sigma = lam_ref[0] - 0.005 * (lam_ref[1] - lam_ref[0]) - 1e-9
+    theta = 1.0 / (lam_ref[:N] - sigma)
+    assert theta[0] / theta[-1] > 1e2
+    fac = eg.SpLuOperator((K - sigma * M).tocsc())
+    s = eg.IRAM(N=N, m=40)
+    lam, Phi = s.solve(K, M, fac, sigma)
+    assert relerr(lam, lam_ref[:N]) < 1e-8
+    Phi_a, _ = align_signs(Phi, Phi_ref[:, :N])
+    assert np.max(np.linalg.norm(Phi_a - Phi_ref[:, :N], axis=0) / np.linalg.norm(Phi_ref[:, :N], axis=0)) < 1e-6
+    R = K @ Phi - (M @ Phi) * lam
+    assert np.linalg.norm(R, axis=0).max() < 1e-8 * np.linalg.norm(K @ Phi, axis=0).max()
+    assert np.all(s.eig_res <= 1e-10 * np.abs(s.theta[s.indices[:N]]))
+
+
 def test_iram_reports_non_convergence():
     import eigd_amd as eg
     from scipy.sparse.linalg import ArpackNoConvergence
