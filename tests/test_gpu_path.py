@@ -873,8 +873,8 @@ def test_iram_wanted_ritz_values_spread_over_three_decades():
     assert relerr(lam, lam_ref[:N]) < 1e-8
     Phi_a, _ = align_signs(Phi, Phi_ref[:, :N])
     assert np.max(np.linalg.norm(Phi_a - Phi_ref[:, :N], axis=0) / np.linalg.norm(Phi_ref[:, :N], axis=0)) < 1e-6
-    R = K @ Phi - (M @ Phi) * lam
-    assert np.linalg.norm(R, axis=0).max() < 1e-8 * np.linalg.norm(K @ Phi, axis=0).max()
+    R = K @ Phi - (M @ Phi) * lam                       # backward error: |K| ~ 2e3 against eigenvalues of 4e-6 ... 3e-4
+    assert np.linalg.norm(R, axis=0).max() < 1e-12 * abs(K).max() * np.linalg.norm(Phi, axis=0).max()
     assert np.all(s.eig_res <= 1e-10 * np.abs(s.theta[s.indices[:N]]))
 
 
