@@ -8,6 +8,7 @@
 #include <algorithm>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -428,16 +429,87 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(int n, int ku, int kx
   }
 }
 
+// masked lanes load this word (address select) instead of branching around the load: loads in divergent branches
+// make the compiler wait for ALL outstanding memory operations (vmcnt(0)) at every later use -- including every
+// store, which then run one at a time
+__device__ const double g_zero_word = 0.0;
+
+// The same product for WIDE results (more than four 16 x 16 tiles: the projection coefficients Phi_D^T [T1 | T2], 63 x 64)
+// with row-major U: in the direct form above every wave reads the fragments of its own tiles from global memory, so
+// with sixteen tiles each operand row is requested four times per workgroup (the rows are the whole traffic here:
+// 1 GB per projection).  Here a chunk of 32 rows of U and of X is staged in LDS once (coalesced, the next chunk in
+// registers while this one multiplies) and the four waves take their fragments from there.
+constexpr int kTsRows = 32;
+
+__global__ __launch_bounds__(kThreads) void gemm_tn_staged_kernel(int n, int ku, int kx, const double* __restrict__ U,
+                                                                 int64_t rsu, const double* __restrict__ X, int ldx,
+                                                                 double* __restrict__ partial) {
+  __shared__ double Us[kTsRows * kMaxK];
+  __shared__ double Xs[kTsRows * kMaxK];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int nta = (ku + 15) >> 4, ntb = (kx + 15) >> 4;
+  const int ntiles = nta * ntb;  // <= 16
+  constexpr int IT = kTsRows * kMaxK / kThreads;  // 8 elements of each operand per lane and chunk
+  const int col = tid & (kMaxK - 1), row0 = tid >> 6;  // element it of a lane: row row0 + 4 it, column col
+  double4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+  double ru[IT], rx[IT];
+  auto fetch = [&](int64_t base) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int64_t r = base + row0 + 4 * it;
+      ru[it] = *((r < n && col < ku) ? U + r * rsu + col : &g_zero_word);
+      rx[it] = *((r < n && col < kx) ? X + r * ldx + col : &g_zero_word);
+    }
+  };
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kTsRows;
+  int64_t base = static_cast<int64_t>(blockIdx.x) * kTsRows;
+  if (base < n) fetch(base);
+  for (; base < n; base += stride) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      Us[(row0 + 4 * it) * kMaxK + col] = ru[it];
+      Xs[(row0 + 4 * it) * kMaxK + col] = rx[it];
+    }
+    __syncthreads();
+    if (base + stride < n) fetch(base + stride);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < ntiles) {
+        const int ta = tile / ntb, tb = tile - ta * ntb;
+        double4_t c = acc[t];
+#pragma unroll
+        for (int q = 0; q < kTsRows / 4; ++q)
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[(4 * q + lk) * kMaxK + 16 * ta + li],
+                                                   Xs[(4 * q + lk) * kMaxK + 16 * tb + li], c, 0, 0, 0);
+        acc[t] = c;
+      }
+    }
+  }
+  double* p = partial + static_cast<int64_t>(blockIdx.x) * ku * kx;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int tile = wave + 4 * t;
+    if (tile >= ntiles) break;
+    const int ta = tile / ntb, tb = tile - ta * ntb;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int a = ta * 16 + lk + 4 * reg, b = tb * 16 + li;  // f64 MFMA result map: row = (l>>4) + 4*reg, col = l&15
+      if (a < ku && b < kx) p[a * kx + b] = acc[t][reg];
+    }
+  }
+}
+
 // X[r][b] = beta * X[r][b] + alpha * sum_a U(r,a) C[a][b], C on the device (ku x kx).
 // A 64-row chunk of U is staged in LDS with all its loads in flight; wave w owns rows 16w..16w+15 and
 // forms each 16 x 16 output tile with v_mfma_f64_16x16x4_f64 (A = U rows from LDS, B = C from LDS with a
 // conflict-free row stride), so the LDS traffic per flop is an eighth of a scalar inner loop.
 __device__ __forceinline__ int cs_stride(int kx) { return (kx % 32 == 0) ? kx + 16 : kx; }
 
-// masked lanes load this word (address select) instead of branching around the load: loads in divergent branches
-// make the compiler wait for ALL outstanding memory operations (vmcnt(0)) at every later use -- including every
-// store, which then run one at a time
-__device__ const double g_zero_word = 0.0;
 
 // Row-major U (csu == 1): every wave works alone on 16-row groups and feeds its MFMAs with fragments of U loaded
 // straight from global memory (lane (i, k) holds U(base + i, 4 q + k): 32-byte pieces of the rows, every line is
@@ -682,8 +754,15 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
   if (rc) return rc;
   double* res = ctx->scratch;
   double* partial = ctx->scratch + nout;
+  static const bool staged_tn = [] {  // EIGD_TN_STAGED=0: wide results through the direct form too
+    const char* v = std::getenv("EIGD_TN_STAGED");
+    return (v && *v) ? std::atoi(v) != 0 : true;
+  }();
   if (((ku + 15) / 16) * ((kx + 15) / 16) <= 4)
     hipLaunchKernelGGL(gemm_tn_kernel<1>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, csu, dX, ldx,
+                       partial);
+  else if (csu == 1 && staged_tn)
+    hipLaunchKernelGGL(gemm_tn_staged_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, dX, ldx,
                        partial);
   else
     hipLaunchKernelGGL(gemm_tn_kernel<4>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, csu, dX, ldx,
