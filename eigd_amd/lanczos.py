@@ -950,7 +950,7 @@ class IRAM(_AdjointAPI):
         if p == 1:
             return 1, extra, m
         k_want = N + extra
-        m_int = max(m, 2 * k_want + p)
+        m_int = int(os.environ.get("EIGD_IRAM_BASIS", "0")) or max(m, 2 * k_want + p)
         m_int = p * (-(-m_int // p))
         if m_int + p > n:
             return 1, min(extra, max(0, m - 1 - N)), m
