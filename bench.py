@@ -495,6 +495,19 @@ def main():
                      "note": "same step with numpy arrays in and out (H2D of Phib, D2H + H2D of psi): results come back in "
                              "pooled page-locked memory, the caller's Phib is page-locked in place from its second use; the "
                              "first two calls (listed) pay for that once"}
+        if args.pyprofile:
+            import cProfile
+            import pstats
+
+            pr = cProfile.Profile()
+            pr.enable()
+            psi_np, data_np = solver.solve_adjoint(Phib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1)
+            solver.add_total_derivative(lamb, Phib, psi_np, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data_np,
+                                        deriv_type="tensor")
+            ctx.sync()
+            pr.disable()
+            with open(args.pyprofile + ".numpy", "w") as fh:
+                pstats.Stats(pr, stream=fh).sort_stats("cumulative").print_stats(60)
         del psi_np
         log(rank, f"numpy-in / numpy-out step: {1e3 * t_np:.1f} ms ({N / t_np:.1f} modes/s)")
 
