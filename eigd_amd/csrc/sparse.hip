@@ -11,8 +11,9 @@
 //            Tiled form: the rows are cut into blocks of kTileRows; at upload every block gets the sorted
 //            list of the distinct columns it touches and each non-zero a 16-bit position in that list.
 //            A workgroup stages those rows of X in LDS once (neighbouring matrix rows share most of
-//            them: 5.6x fewer gathered bytes on the Q4 meshes) and the products read LDS; the adds stay
-//            in CSR order.  Blocks whose column lists do not fit LDS use the direct-gather kernel.
+//            them: 5.6x fewer gathered bytes on the Q4 meshes) and the products read LDS, eight lanes
+//            per matrix row with k/8 neighbouring columns each; the adds stay in CSR order.  Blocks
+//            whose column lists do not fit LDS use the direct-gather kernel.
 //
 // algorithmic bytes: SpMV 12 nnz + 20 n ; SpMM 12 nnz + 4 n + 16 n k.
 #include <algorithm>
@@ -33,6 +34,7 @@ struct eigd_mat {
   int nblocks = 0;
   // tiled SpMM
   int ntiles = 0, umax = 0;       // row tiles; longest distinct-column list
+  int tnz_cap = 0;                // non-zeros of a tile staged through LDS: the fullest tile's, at most kTileNnz
   int32_t* tile_ptr = nullptr;    // ntiles + 1 : offsets into ucols
   int32_t* ucols = nullptr;       // distinct columns of each tile, ascending
   uint16_t* lidx = nullptr;       // per non-zero: position of its column in the tile's list
@@ -42,9 +44,10 @@ namespace eigd {
 
 constexpr int kTileRows = 32;    // matrix rows per SpMM tile
 constexpr int kTileLds = 40 * 1024;  // LDS budget of the staged X rows (bytes)
-constexpr int kTileNnz = 1024;       // non-zeros of a tile staged through LDS (more: read from global memory)
+constexpr int kTileNnz = 1024;       // most non-zeros of a tile staged through LDS (more: read from global memory)
 constexpr int kNnzTile = 2048;   // products staged per workgroup (16 KiB of LDS)
 constexpr int kMaxRowsTile = 256;
+
 
 __device__ __forceinline__ int xcd_remap(int b, int nblocks_padded) {
   // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range
@@ -156,8 +159,20 @@ __global__ __launch_bounds__(kThreads) void spmm_rows_kernel(int n, int k, const
   *yp = (beta == 0.0) ? alpha * s : alpha * s + beta * (*yp);
 }
 
-// Tiled SpMM: see the file header.  Xs row stride KP + 1 doubles (rows of different lanes land on different banks).
-template <int KP>
+// Tiled SpMM: see the file header.
+// Product phase: a row of the tile belongs to LPR = KP / CPL lanes, each with CPL neighbouring columns in registers
+// (KP >= 8: eight lanes per row, so the 256 lanes take the 32 rows of the tile in one pass).  The value and the local
+// column number of a non-zero are read from LDS once per lane and serve CPL products, the staged row of X comes as
+// 16-byte pieces: at 32 columns 5.5 LDS cycles per 64 products instead of 10 (the kernel is bound by the LDS pipe).
+// The sums stay in CSR order per (row, column): the mapping of lanes to columns does not enter the result.
+template <int KP, int LANES = 8>
+struct SpmmTile {
+  static constexpr int CPL = (KP >= LANES) ? KP / LANES : 1;  // columns per lane
+  static constexpr int LPR = KP / CPL;                         // lanes per row
+  static constexpr int LD = (CPL >= 2) ? KP + 4 : KP + 1;      // Xs row stride in doubles (CPL >= 2: rows 16-byte aligned)
+};
+
+template <int KP, int LANES>
 __global__ __launch_bounds__(kThreads) void spmm_tiled_kernel(int n, int k, int ntiles, int tiles_per_xcd,
                                                              const int32_t* __restrict__ tile_ptr,
                                                              const int32_t* __restrict__ ucols,
@@ -166,29 +181,31 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled_kernel(int n, int k, int 
                                                              const double* __restrict__ vals,
                                                              const double* __restrict__ X, int ldx,
                                                              double* __restrict__ Y, int ldy, double alpha, double beta,
-                                                             int umax) {
-  extern __shared__ double Xs[];
-  constexpr int RP = kThreads / KP;
-  constexpr int LD = KP + 1;
+                                                             int umax, int tnz_cap) {
+  extern __shared__ __align__(16) double Xs[];
+  constexpr int RP = kThreads / KP;  // staging: rows of X per trip, lane (rr, c) moves one double
+  constexpr int CPL = SpmmTile<KP, LANES>::CPL, LPR = SpmmTile<KP, LANES>::LPR, LD = SpmmTile<KP, LANES>::LD;
+  constexpr int RPP = kThreads / LPR;                    // product phase: matrix rows per pass
+  constexpr int NR = (kTileRows + RPP - 1) / RPP;        // passes (1 for KP >= 8)
   // the tile's non-zeros (values, local column numbers) go through LDS too: requested with the X rows, coalesced,
   // instead of a dependent round trip per 8 non-zeros of a row in the product loop
   double* const Vs = Xs + static_cast<size_t>(umax) * LD;
-  uint16_t* const Ls = reinterpret_cast<uint16_t*>(Vs + kTileNnz);
+  uint16_t* const Ls = reinterpret_cast<uint16_t*>(Vs + tnz_cap);  // (tnz_cap: multiple of 8)
   // contiguous tile ranges per XCD (workgroups are dealt round-robin over the 8 XCDs): neighbouring tiles share
   // most of their X rows, this keeps that reuse inside one L2
   const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
   const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
+  const int pl = threadIdx.x % LPR, prow = threadIdx.x / LPR;  // product phase: lane pl of row prow, columns CPL pl ..
   const int u0 = tile_ptr[tile], nu = tile_ptr[tile + 1] - u0;
   const int rend = min(n, (tile + 1) * kTileRows);
   const int e0 = indptr[tile * kTileRows], tnz = indptr[rend] - e0;
-  const bool staged = tnz <= kTileNnz;  // (a tile with very long rows reads its non-zeros from global memory)
+  const bool staged = tnz <= tnz_cap;  // (a tile with very long rows reads its non-zeros from global memory)
   constexpr int NQ = kTileNnz / kThreads;
-  constexpr int NR = (kTileRows + RP - 1) / RP;  // rows per lane; their extents are requested with everything else
-  int ra[NR], rz[NR];
+  int ra[NR], rz[NR];  // the extents of the lane's rows are requested with everything else
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
-    const int r = tile * kTileRows + rr + i * RP;
+    const int r = tile * kTileRows + prow + i * RPP;
     ra[i] = (r < rend) ? indptr[r] - e0 : 0;
     rz[i] = (r < rend) ? indptr[r + 1] - e0 : 0;
   }
@@ -229,52 +246,74 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled_kernel(int n, int k, int 
     }
   }
   __syncthreads();
-  if (c >= k) return;
+  const int cb = CPL * pl;  // the lane's first column
+  if (cb >= k) return;
+  auto store_row = [&](int r, const double (&s)[CPL]) {
+    double* yp = Y + static_cast<int64_t>(r) * ldy + cb;
+#pragma unroll
+    for (int t = 0; t < CPL; ++t)
+      if (cb + t < k) yp[t] = (beta == 0.0) ? alpha * s[t] : alpha * s[t] + beta * yp[t];
+  };
   if (staged) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const int r = tile * kTileRows + rr + i * RP;
+      const int r = tile * kTileRows + prow + i * RPP;
       if (r >= rend) break;
       const int a = ra[i], z = rz[i];
-      double s = 0.0;
+      double s[CPL];
+#pragma unroll
+      for (int t = 0; t < CPL; ++t) s[t] = 0.0;
       int e = a;
       for (; e + 8 <= z; e += 8) {  // eight non-zeros per trip: their LDS reads are in flight together
         int li[8];
-        double v[8], x[8];
+        double v[8], x[8][CPL];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           li[q] = Ls[e + q];
           v[q] = Vs[e + q];
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) x[q] = Xs[li[q] * LD + c];
+        for (int q = 0; q < 8; ++q) {
+          const double* xp = Xs + li[q] * LD + cb;
+          if constexpr (CPL >= 2) {
+            const double2* xp2 = reinterpret_cast<const double2*>(xp);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s = __dadd_rn(s, __dmul_rn(v[q], x[q]));
+            for (int t = 0; t < CPL / 2; ++t) {
+              const double2 w = xp2[t];
+              x[q][2 * t] = w.x;
+              x[q][2 * t + 1] = w.y;
+            }
+          } else {
+            x[q][0] = xp[0];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int t = 0; t < CPL; ++t) s[t] = __dadd_rn(s[t], __dmul_rn(v[q], x[q][t]));
       }
-      for (; e < z; ++e) s = __dadd_rn(s, __dmul_rn(Vs[e], Xs[Ls[e] * LD + c]));
-      double* yp = Y + static_cast<int64_t>(r) * ldy + c;
-      *yp = (beta == 0.0) ? alpha * s : alpha * s + beta * (*yp);
+      for (; e < z; ++e) {
+        const double v = Vs[e];
+        const double* xp = Xs + Ls[e] * LD + cb;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) s[t] = __dadd_rn(s[t], __dmul_rn(v, xp[t]));
+      }
+      store_row(r, s);
     }
     return;
   }
-  for (int r = tile * kTileRows + rr; r < rend; r += RP) {
+  for (int r = tile * kTileRows + prow; r < rend; r += RPP) {
     const int a = indptr[r], z = indptr[r + 1];
-    double s = 0.0;
-    int e = a;
-    for (; e + 8 <= z; e += 8) {
-      int li[8];
-      double v[8];
+    double s[CPL];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        li[q] = lidx[e + q];
-        v[q] = vals[e + q];
-      }
+    for (int t = 0; t < CPL; ++t) s[t] = 0.0;
+    for (int e = a; e < z; ++e) {
+      const double v = vals[e];
+      const double* xp = Xs + lidx[e] * LD + cb;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s = __dadd_rn(s, __dmul_rn(v[q], Xs[li[q] * LD + c]));
+      for (int t = 0; t < CPL; ++t) s[t] = __dadd_rn(s[t], __dmul_rn(v, xp[t]));
     }
-    for (; e < z; ++e) s = __dadd_rn(s, __dmul_rn(vals[e], Xs[lidx[e] * LD + c]));
-    double* yp = Y + static_cast<int64_t>(r) * ldy + c;
-    *yp = (beta == 0.0) ? alpha * s : alpha * s + beta * (*yp);
+    store_row(r, s);
   }
 }
 
@@ -322,6 +361,7 @@ int eigd_csr_upload_rect(eigd_ctx* ctx, int n, int ncols, int64_t nnz, const int
   std::vector<int32_t> tile_ptr(static_cast<size_t>(ntiles) + 1, 0), ucols;
   std::vector<uint16_t> lidx(static_cast<size_t>(nnz) + 8, 0);
   int umax = 0;
+  int64_t tnz_max = 0;
   bool tiles_ok = true;
   {
     std::vector<int32_t> cols, stamp(static_cast<size_t>(ncols), -1), pos(static_cast<size_t>(ncols), 0);
@@ -339,6 +379,7 @@ int eigd_csr_upload_rect(eigd_ctx* ctx, int n, int ncols, int64_t nnz, const int
       std::sort(cols.begin(), cols.end());
       if (cols.size() > 65535) tiles_ok = false;
       umax = std::max<int>(umax, static_cast<int>(cols.size()));
+      tnz_max = std::max<int64_t>(tnz_max, hindptr[r1] - hindptr[r0]);
       for (size_t q = 0; q < cols.size(); ++q) pos[cols[q]] = static_cast<int32_t>(q);
       for (int64_t e = hindptr[r0]; e < hindptr[r1]; ++e) lidx[e] = static_cast<uint16_t>(pos[hindices[e]]);
       ucols.insert(ucols.end(), cols.begin(), cols.end());
@@ -355,6 +396,7 @@ int eigd_csr_upload_rect(eigd_ctx* ctx, int n, int ncols, int64_t nnz, const int
   if (tiles_ok) {
     A->ntiles = ntiles;
     A->umax = umax;
+    A->tnz_cap = static_cast<int>(std::min<int64_t>(kTileNnz, (tnz_max + 7) & ~int64_t(7)));
     hipError_t t1 = hipMalloc(reinterpret_cast<void**>(&A->tile_ptr), sizeof(int32_t) * tile_ptr.size());
     hipError_t t2 = hipMalloc(reinterpret_cast<void**>(&A->ucols), sizeof(int32_t) * std::max<size_t>(ucols.size(), 1));
     hipError_t t3 = hipMalloc(reinterpret_cast<void**>(&A->lidx), sizeof(uint16_t) * lidx.size());
@@ -438,16 +480,27 @@ int eigd_spmm_on(eigd_ctx* ctx, eigd_mat* A, const double* dX, int ldx, double* 
     const int kp = std::max(2, next_pow2(kb));
     const int rp = kThreads / kp;
     const dim3 grid((A->n + rp - 1) / rp);
-    const size_t tile_lds = sizeof(double) * static_cast<size_t>(A->umax) * (kp + 1);
-    const size_t tile_lds_all = tile_lds + static_cast<size_t>(kTileNnz) * (sizeof(double) + sizeof(uint16_t));
+    // lanes per matrix row in the product phase (EIGD_SPMM_LANES=0: one lane per column, the round-2 mapping)
+    static const int lanes = [] {
+      const char* v = std::getenv("EIGD_SPMM_LANES");
+      return (v && *v) ? std::atoi(v) : 8;
+    }();
+    const int cpl = (lanes == 8 && kp >= 8) ? kp / 8 : 1;
+    const size_t tile_lds = sizeof(double) * static_cast<size_t>(A->umax) * (cpl >= 2 ? kp + 4 : kp + 1);  // SpmmTile::LD
+    const size_t tile_lds_all = tile_lds + static_cast<size_t>(A->tnz_cap) * (sizeof(double) + sizeof(uint16_t));
     if (A->ntiles > 0 && tile_lds <= static_cast<size_t>(kTileLds)) {
       const int per_xcd = (A->ntiles + 7) / 8;
       const dim3 tgrid(per_xcd * 8);
 #define EIGD_SPMM_TILED(KP)                                                                                            \
   case KP:                                                                                                             \
-    hipLaunchKernelGGL(spmm_tiled_kernel<KP>, tgrid, dim3(kThreads), tile_lds_all, st, A->n, kb, A->ntiles, per_xcd,    \
-                       A->tile_ptr, A->ucols, A->indptr, A->lidx, A->data, dX + c0, ldx, dY + c0, ldy, alpha, beta,    \
-                       A->umax);                                                                                       \
+    if (lanes == 8)                                                                                                    \
+      hipLaunchKernelGGL((spmm_tiled_kernel<KP, 8>), tgrid, dim3(kThreads), tile_lds_all, st, A->n, kb, A->ntiles,     \
+                         per_xcd, A->tile_ptr, A->ucols, A->indptr, A->lidx, A->data, dX + c0, ldx, dY + c0, ldy,      \
+                         alpha, beta, A->umax, A->tnz_cap);                                                            \
+    else                                                                                                               \
+      hipLaunchKernelGGL((spmm_tiled_kernel<KP, 1024>), tgrid, dim3(kThreads), tile_lds_all, st, A->n, kb, A->ntiles,  \
+                         per_xcd, A->tile_ptr, A->ucols, A->indptr, A->lidx, A->data, dX + c0, ldx, dY + c0, ldy,      \
+                         alpha, beta, A->umax, A->tnz_cap);                                                            \
     break;
       switch (kp) {
         EIGD_SPMM_TILED(2)
