@@ -396,6 +396,7 @@ def main():
     def step():
         factor.count = 0
         _adj.LAST_ROUND["gs_cycles"] = _adj.LAST_ROUND["gs_correcting_passes"] = 0
+        _adj.LAST_ROUND["post_gs_projections"] = _adj.LAST_ROUND["post_gs_updates_applied"] = 0
         dpsi, data = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1,
                                           comm=comm, streams=args.streams)
         dfdx = solver.add_total_derivative(lamb, dPhib, dpsi, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data,
@@ -669,7 +670,9 @@ def main():
         "lock_step": {"steps_per_gram_schmidt_pass": _adj.LAST_ROUND.get("steps_per_pass"),
                       "inner_projections": _adj.LAST_ROUND.get("inner_projections"),
                       "cycles": _adj.LAST_ROUND.get("gs_cycles"),
-                      "correcting_gram_schmidt_passes": _adj.LAST_ROUND.get("gs_correcting_passes")},
+                      "correcting_gram_schmidt_passes": _adj.LAST_ROUND.get("gs_correcting_passes"),
+                      "post_gs_projections_measured": _adj.LAST_ROUND.get("post_gs_projections"),
+                      "post_gs_updates_applied": _adj.LAST_ROUND.get("post_gs_updates_applied")},
         # one design point of an optimisation loop as the reference's harness runs it (buckling.py:548-632, 874-986):
         # assembly + factorisation (device: K, G(u), K + sigma G, numeric factor) + eigensolve + the timed step
         "design_point_s": round(timing["device_assemble_and_refactor_s"] + timing["eigensolve_s"] + ms_per_step * 1e-3, 4),

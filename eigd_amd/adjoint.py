@@ -979,6 +979,9 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
         dpsi.copy_from(upd)
     if ok:
         LAST_ROUND["steps_per_pass"] = 2
+    measured, applied = ctx.project_stats()               # ref 1257: how often the update behind the Gram-Schmidt
+    LAST_ROUND["post_gs_projections"] = LAST_ROUND.get("post_gs_projections", 0) + measured      # step was needed
+    LAST_ROUND["post_gs_updates_applied"] = LAST_ROUND.get("post_gs_updates_applied", 0) + applied
     return dpsi, converged, info, ok
 
 

@@ -66,6 +66,8 @@ struct eigd_ctx {
   int pinned_count = 0;
   double* pinned_h = nullptr;  // pinned staging of coefficient blocks (eigd_stack_cgs2)
   size_t pinned_h_bytes = 0;
+  // eigd_project_norm2: {projections measured, of those: updates applied} since the last eigd_project_stats
+  int* proj_stats = nullptr;
 
   int ensure_scratch(size_t bytes);
   int ensure_coef(size_t bytes);

@@ -92,6 +92,7 @@ int eigd_ctx_destroy(eigd_ctx* ctx) {
   if (ctx->ev_pinned) (void)hipEventDestroy(ctx->ev_pinned);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pinned_h) (void)hipHostFree(ctx->pinned_h);
+  if (ctx->proj_stats) (void)hipFree(ctx->proj_stats);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return EIGD_OK;

@@ -28,8 +28,12 @@ static inline int grid_for_rows(int n, int rows_per_block) {
 
 // out[o] = sum over g of partial[g * nout + o]: one wave per output, lane l adds g = l, l+64, ...
 // in ascending order, then a fixed shuffle tree -- the same association for every launch shape.
+// gate (optional): a device word written earlier in the stream; zero = the launch that produced the partials was
+// skipped, out keeps what it holds
 __global__ __launch_bounds__(kThreads) void reduce_partials_kernel(const double* __restrict__ partial, int nblocks,
-                                                                  int nout, double* __restrict__ out) {
+                                                                  int nout, double* __restrict__ out,
+                                                                  const int* __restrict__ gate = nullptr) {
+  if (gate != nullptr && *gate == 0) return;
   const int lane = threadIdx.x & 63;
   const int o = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (o >= nout) return;
@@ -441,11 +445,15 @@ __device__ const double g_zero_word = 0.0;
 // registers while this one multiplies) and the four waves take their fragments from there.
 constexpr int kTsRows = 32;
 
+// xnorm_part (optional): the squared column norms of X ride along, one partial sum per workgroup and column
+// (xnorm_part[blockIdx.x * kx + b]; fixed order: the lane's chunks, then the four waves)
 __global__ __launch_bounds__(kThreads) void gemm_tn_staged_kernel(int n, int ku, int kx, const double* __restrict__ U,
                                                                  int64_t rsu, const double* __restrict__ X, int ldx,
-                                                                 double* __restrict__ partial) {
+                                                                 double* __restrict__ partial,
+                                                                 double* __restrict__ xnorm_part) {
   __shared__ double Us[kTsRows * kMaxK];
   __shared__ double Xs[kTsRows * kMaxK];
+  double xsq = 0.0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int nta = (ku + 15) >> 4, ntb = (kx + 15) >> 4;
@@ -473,6 +481,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_staged_kernel(int n, int ku,
     for (int it = 0; it < IT; ++it) {
       Us[(row0 + 4 * it) * kMaxK + col] = ru[it];
       Xs[(row0 + 4 * it) * kMaxK + col] = rx[it];
+      xsq += rx[it] * rx[it];
     }
     __syncthreads();
     if (base + stride < n) fetch(base + stride);
@@ -502,6 +511,36 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_staged_kernel(int n, int ku,
       if (a < ku && b < kx) p[a * kx + b] = acc[t][reg];
     }
   }
+  if (xnorm_part != nullptr) {
+    __syncthreads();
+    Xs[row0 * kMaxK + col] = xsq;  // (row0 = wave: the four lanes of a column sit in the four waves)
+    __syncthreads();
+    if (tid < kx)
+      xnorm_part[static_cast<int64_t>(blockIdx.x) * kx + tid] =
+          ((Xs[tid] + Xs[kMaxK + tid]) + Xs[2 * kMaxK + tid]) + Xs[3 * kMaxK + tid];
+  }
+}
+
+// gate[0] = 1 if some coefficient of a projection matters, |C[a][b]| > tol * |x_b| (norm2 = squared column norms of
+// X from the same pass), else 0: the update X -= U C that follows is skipped then (see eigd_project_norm2)
+__global__ __launch_bounds__(kThreads) void project_decide_kernel(const double* __restrict__ C, int ku, int kx,
+                                                                 const double* __restrict__ norm2, double tol,
+                                                                 int* __restrict__ gate, int* __restrict__ stats) {
+  __shared__ int any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int q = threadIdx.x; q < ku * kx; q += kThreads) {
+    const double c = C[q], lim = tol * tol * norm2[q % kx];
+    if (!(c * c <= lim)) mine = 1;  // (a NaN anywhere keeps the update)
+  }
+  if (mine) any = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    gate[0] = any;
+    stats[0] += 1;  // (one workgroup, launches of a stream run in order: plain adds)
+    stats[1] += any;
+  }
 }
 
 // X[r][b] = beta * X[r][b] + alpha * sum_a U(r,a) C[a][b], C on the device (ku x kx).
@@ -519,9 +558,12 @@ template <int NQ>
 __global__ __launch_bounds__(kThreads) void gemm_nn_direct_kernel(int n, int ku, int kx, const double* __restrict__ U,
                                                                  int64_t rsu, const double* __restrict__ C,
                                                                  double* __restrict__ X, int ldx, double alpha,
-                                                                 double beta, double* __restrict__ normpart) {
+                                                                 double beta, double* __restrict__ normpart,
+                                                                 const int* __restrict__ gate) {
   // normpart != nullptr: the squared column norms of the result are left as one partial sum per workgroup and
   // column (normpart[blockIdx.x * kx + b]) -- the norm pass over X that would follow a projection is folded in
+  // gate != nullptr: a device word written earlier in the stream; zero = leave X alone
+  if (gate != nullptr && *gate == 0) return;
   extern __shared__ double Cs[];  // ku x cs_stride(kx)
   __shared__ double nred[kThreads / 64][64];
   double nsq[4] = {0.0, 0.0, 0.0, 0.0};
@@ -734,9 +776,10 @@ static int dispatch_kp(int k, F&& f) {
   return EIGD_OK;
 }
 
-static int reduce_to_host(eigd_ctx* ctx, const double* partial, int nblocks, int nout, double* dres, double* hout) {
+static int reduce_to_host(eigd_ctx* ctx, const double* partial, int nblocks, int nout, double* dres, double* hout,
+                          const int* gate = nullptr) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 3) / 4), dim3(kThreads), 0, ctx->stream, partial, nblocks,
-                     nout, dres);
+                     nout, dres, gate);
   EIGD_LAUNCH_CHECK();
   if (hout) {
     EIGD_HIP(hipMemcpyAsync(hout, dres, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));
@@ -746,14 +789,31 @@ static int reduce_to_host(eigd_ctx* ctx, const double* partial, int nblocks, int
 }
 
 // partial-sum layout in ctx->scratch: [result nout][partials nblocks*nout]
+// xnorm2 (optional, row-major U only): the squared column norms of X from the same pass, left in xnorm2[0..kx) on the device
 static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu,
-                          const double* dX, int ldx, double** dres, double* hC) {
+                          const double* dX, int ldx, double** dres, double* hC, double* xnorm2 = nullptr) {
   const int nb = grid_for_rows(n, kRB);
   const int nout = ku * kx;
-  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) + 1) * nout);
+  int rc = ctx->ensure_scratch(sizeof(double) * ((static_cast<size_t>(nb) + 1) * nout + static_cast<size_t>(nb) * kx));
   if (rc) return rc;
   double* res = ctx->scratch;
   double* partial = ctx->scratch + nout;
+  double* xpart = partial + static_cast<size_t>(nb) * nout;
+  if (xnorm2 != nullptr) {
+    if (csu != 1) {
+      set_error("internal: column norms ride along with a row-major U only");
+      return EIGD_E_INTERNAL;
+    }
+    hipLaunchKernelGGL(gemm_tn_staged_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, dX, ldx,
+                       partial, xpart);
+    EIGD_LAUNCH_CHECK();
+    rc = reduce_to_host(ctx, partial, nb, nout, res, hC);
+    if (rc) return rc;
+    rc = reduce_to_host(ctx, xpart, nb, kx, xnorm2, nullptr);
+    if (rc) return rc;
+    if (dres) *dres = res;
+    return EIGD_OK;
+  }
   static const bool staged_tn = [] {  // EIGD_TN_STAGED=0: wide results through the direct form too
     const char* v = std::getenv("EIGD_TN_STAGED");
     return (v && *v) ? std::atoi(v) != 0 : true;
@@ -763,7 +823,7 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
                        partial);
   else if (csu == 1 && staged_tn)
     hipLaunchKernelGGL(gemm_tn_staged_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, dX, ldx,
-                       partial);
+                       partial, static_cast<double*>(nullptr));
   else
     hipLaunchKernelGGL(gemm_tn_kernel<4>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, csu, dX, ldx,
                        partial);
@@ -777,7 +837,7 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
 // normpart / nparts: see gemm_nn_direct_kernel (row-major U only); *nparts = number of partial sums per column
 static int gemm_nn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu,
                           const double* dC, double* dX, int ldx, double alpha, double beta, double* normpart = nullptr,
-                          int* nparts = nullptr) {
+                          int* nparts = nullptr, const int* gate = nullptr) {
   const size_t cs_bytes = sizeof(double) * (ku * ((kx % 32 == 0) ? kx + 16 : kx) + kRB * (ku + 1));
   if (csu == 1 && ku <= 64) {  // row-major U: wave-private streaming without LDS staging
     const size_t cbytes = sizeof(double) * ku * ((kx % 32 == 0) ? kx + 16 : kx);
@@ -785,14 +845,14 @@ static int gemm_nn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
     if (nparts) *nparts = nbd;
     if (ku <= 32)
       hipLaunchKernelGGL(gemm_nn_direct_kernel<8>, dim3(nbd), dim3(kThreads), cbytes, ctx->stream, n, ku, kx, dU, rsu, dC,
-                         dX, ldx, alpha, beta, normpart);
+                         dX, ldx, alpha, beta, normpart, gate);
     else
       hipLaunchKernelGGL(gemm_nn_direct_kernel<16>, dim3(nbd), dim3(kThreads), cbytes, ctx->stream, n, ku, kx, dU, rsu, dC,
-                         dX, ldx, alpha, beta, normpart);
+                         dX, ldx, alpha, beta, normpart, gate);
     EIGD_LAUNCH_CHECK();
     return EIGD_OK;
   }
-  if (normpart != nullptr) {
+  if (normpart != nullptr || gate != nullptr) {
     set_error("internal: fused column norms need a row-major U");
     return EIGD_E_INTERNAL;
   }
@@ -836,13 +896,14 @@ int eigd_gemm_nn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t
 
 // C = V^T X for up to 2 * kMaxK columns of V, left on the device in ctx->coef (ku x kx): the product kernel forms at
 // most kMaxK x kMaxK entries per launch, a wider V goes in two column halves (no host round trip in between)
-static int project_coefficients(eigd_ctx* ctx, int n, int ku, int kx, const double* dV, int ldv, const double* dX, int ldx) {
-  int rc = ctx->ensure_coef(sizeof(double) * static_cast<size_t>(ku) * kx);
+static int project_coefficients(eigd_ctx* ctx, int n, int ku, int kx, const double* dV, int ldv, const double* dX, int ldx,
+                                double* xnorm2 = nullptr) {
+  int rc = ctx->ensure_coef(sizeof(double) * static_cast<size_t>(ku) * kx + 64);  // (+ the gate word of project_norm2)
   if (rc) return rc;
   for (int a0 = 0; a0 < ku; a0 += kMaxK) {
     const int ka = std::min(kMaxK, ku - a0);
     double* dC = nullptr;
-    rc = gemm_tn_device(ctx, n, ka, kx, dV + a0, ldv, 1, dX, ldx, &dC, nullptr);
+    rc = gemm_tn_device(ctx, n, ka, kx, dV + a0, ldv, 1, dX, ldx, &dC, nullptr, a0 == 0 ? xnorm2 : nullptr);
     if (rc) return rc;
     EIGD_HIP(hipMemcpyAsync(ctx->coef + static_cast<size_t>(a0) * kx, dC, sizeof(double) * ka * kx, hipMemcpyDeviceToDevice,
                             ctx->stream));
@@ -872,24 +933,56 @@ int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, i
   EIGD_REQUIRE(ctx && dU && dV && dX && dOut, "null argument");
   EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= 2 * kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx && ldu >= ku && ldv >= ku,
                "bad shape n=%d ku=%d kx=%d", n, ku, kx);
+  // The projection behind a Gram-Schmidt step (reference 1257) meets a block that is already B-orthogonal to Phi up to
+  // rounding: the vectors it was built from were projected before.  Whether the update X -= U (V^T X) matters is
+  // MEASURED: the coefficient pass delivers the squared column norms of X as well, a one-workgroup kernel compares
+  // every coefficient with tol * |x_b| (EIGD_PROJ_SKIP_TOL, default 1e-13; 0: always update), and the update pass --
+  // the stream of U and two passes over X -- returns at once when none does; the norms of the pass already made are
+  // then the result.
+  static const double skip_tol = [] {
+    const char* v = std::getenv("EIGD_PROJ_SKIP_TOL");
+    return (v && *v) ? std::atof(v) : 1e-13;
+  }();
+  const bool measured = skip_tol > 0.0;
   // scratch: [C tile (<= kMaxK x kx)] [partials of C, later the partial squared norms]
   const int nbd = grid_for_rows(n, 64);
   int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(kMaxK) * kx + static_cast<size_t>(nbd) * kx));
   if (rc) return rc;
-  rc = project_coefficients(ctx, n, ku, kx, dV, ldv, dX, ldx);
+  rc = project_coefficients(ctx, n, ku, kx, dV, ldv, dX, ldx, measured ? dOut : nullptr);
   if (rc) return rc;
+  int* gate = nullptr;
+  if (measured) {
+    gate = reinterpret_cast<int*>(ctx->coef + static_cast<size_t>(ku) * kx);
+    if (!ctx->proj_stats) {
+      EIGD_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->proj_stats), 2 * sizeof(int)));
+      EIGD_HIP(hipMemsetAsync(ctx->proj_stats, 0, 2 * sizeof(int), ctx->stream));
+    }
+    hipLaunchKernelGGL(project_decide_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, ctx->coef, ku, kx, dOut, skip_tol,
+                       gate, ctx->proj_stats);
+    EIGD_LAUNCH_CHECK();
+  }
   double* normpart = ctx->scratch + static_cast<size_t>(kMaxK) * kx;  // (the partials of C are spent by now)
   int nparts = 0;
   for (int a0 = 0; a0 < ku; a0 += kMaxK) {
     const int ka = std::min(kMaxK, ku - a0);
     const bool last = a0 + kMaxK >= ku;                               // the norms belong to the finished block
     rc = gemm_nn_device(ctx, n, ka, kx, dU + a0, ldu, 1, ctx->coef + static_cast<size_t>(a0) * kx, dX, ldx, -1.0, 1.0,
-                        last ? normpart : nullptr, last ? &nparts : nullptr);
+                        last ? normpart : nullptr, last ? &nparts : nullptr, gate);
     if (rc) return rc;
   }
-  rc = reduce_to_host(ctx, normpart, nparts, kx, dOut, nullptr);
+  rc = reduce_to_host(ctx, normpart, nparts, kx, dOut, nullptr, gate);
   if (rc) return rc;
   return publish_norm2(ctx, dOut, kx);
+}
+
+int eigd_project_stats(eigd_ctx* ctx, int* out) {
+  EIGD_REQUIRE(ctx && out, "null argument");
+  out[0] = out[1] = 0;
+  if (!ctx->proj_stats) return EIGD_OK;
+  EIGD_HIP(hipMemcpyAsync(out, ctx->proj_stats, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  EIGD_HIP(hipMemsetAsync(ctx->proj_stats, 0, 2 * sizeof(int), ctx->stream));
+  EIGD_HIP(hipStreamSynchronize(ctx->stream));
+  return EIGD_OK;
 }
 
 int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout) {

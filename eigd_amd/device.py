@@ -87,6 +87,12 @@ class Context:
     def stack(self, ns, n, k=1):
         return DeviceStack(self, ns, n, k)
 
+    def project_stats(self):
+        """(projections measured, updates applied) by project_norm2 since the last call; resets the counters"""
+        out = np.zeros(2, dtype=np.int32)
+        call("eigd_project_stats", self.h, hptr(out))
+        return int(out[0]), int(out[1])
+
     def fetch_colnorm2(self, k):
         """host copy of the last colnorm2_dev result: waits for that copy only, not for work enqueued since"""
         out = np.empty(k)

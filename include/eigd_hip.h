@@ -156,9 +156,14 @@ int eigd_gemm_nn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t
 int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv, double* dX,
                  int ldx);
 /* the projector followed by the squared column norms of the result (1257 + 1259 of sibk in one pass over X):
- * dOut (device, kx) receives them; a pinned copy is left for eigd_colnorm2_fetch as after eigd_colnorm2_dev */
+ * dOut (device, kx) receives them; a pinned copy is left for eigd_colnorm2_fetch as after eigd_colnorm2_dev.
+ * The update pass is MEASURED: the coefficient pass also forms the column norms of X, and when no coefficient exceeds
+ * EIGD_PROJ_SKIP_TOL (1e-13; 0 = always update) times the norm of its column -- the block was built from projected
+ * vectors -- X is left as it is and those norms are the result.  eigd_project_stats: out[0] = projections measured,
+ * out[1] = updates applied since the last call (resets both). */
 int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv,
                        double* dX, int ldx, double* dOut);
+int eigd_project_stats(eigd_ctx* ctx, int* out);
 /* column-wise dots  out[c] = sum_r X[r,c] Y[r,c]  (HOST out, length k); inner products / norms
  * of 1157-1158, 1219, 1233, 1259, 1504, 1537 batched over the modes                     */
 int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout);

@@ -494,6 +494,41 @@ def test_projection_with_fused_column_norms(ctx, n, ku, k):
         ctx.fetch_colnorm2(3)
 
 
+@pytest.mark.parametrize("n,ku,k", [(20000, 63, 64), (9001, 96, 32), (5000, 12, 6)])
+def test_projection_update_is_skipped_when_the_block_is_already_projected(ctx, n, ku, k):
+    """
+    project_norm2 measures its own update pass (the projection behind a Gram-Schmidt step, 1257, meets vectors built from
+    projected ones): with no coefficient above 1e-13 of its column's norm the block is left bit for bit as it is and the
+    norms of the coefficient pass are returned; a block with a component along U is projected as before.  A zero column
+    (a finished mode riding along) does not force the update.
+    """
+    rng = np.random.default_rng(ku + k)
+    U = np.linalg.qr(rng.normal(size=(n, ku)))[0]
+    V = U.copy()                                           # V^T U = I: an orthogonal projector
+    X = rng.normal(size=(n, k))
+    X[:, k // 2] = 0.0
+    dU, dV = ctx.from_host(U), ctx.from_host(V)
+    ctx.project_stats()
+    dX = ctx.from_host(X)
+    n2 = dX.project_norm2(dU, dV)                          # components of order one along U: the update runs
+    P = dX.get()
+    assert relerr(P, X - U @ (V.T @ X)) < 1e-13
+    assert np.allclose(n2.get()[0], (P * P).sum(axis=0), rtol=1e-13, atol=0.0)
+    assert ctx.project_stats() == (1, 1)
+    n2b = dX.project_norm2(dU, dV)                         # what is left along U is rounding: nothing to do
+    assert np.array_equal(dX.get(), P)
+    assert np.allclose(n2b.get()[0], (P * P).sum(axis=0), rtol=1e-13, atol=0.0)
+    assert np.allclose(ctx.fetch_colnorm2(k), (P * P).sum(axis=0), rtol=1e-13, atol=0.0)
+    assert ctx.project_stats() == (1, 0)
+    Y = P.copy()
+    Y[:, 0] += 1e-9 * np.linalg.norm(P[:, 0]) * U[:, 0]    # one column picks up 1e-9 of a direction of U
+    dY = ctx.from_host(Y)
+    dY.project_norm2(dU, dV)
+    ctx.fetch_colnorm2(k)
+    assert ctx.project_stats() == (1, 1)
+    assert np.abs(U.T @ dY.get()).max() < 1e-13 * np.linalg.norm(P[:, 0])
+
+
 def test_split_chain_hand_off_is_reproducible_over_many_sweeps(ctx):
     """the in-launch hand-off of partial blocks (big fronts near the root) gives the same bits sweep after sweep"""
     from eigd_amd.device import Factor
