@@ -602,6 +602,26 @@ def main():
             "traffic": spmv_traffic, "traffic_source": spmv_src,
             "bytes_per_launch": spmv_bytes, "us_per_launch": round(spmv_ms * 1e3, 2)}
 
+    # SpMM at the width of a lock-step Krylov step (N columns, the tiled kernel), K and G alternating as above
+    Ys, Ys2 = ctx.empty(n, N), ctx.empty(n, N)
+    for _ in range(3):
+        dK.apply(Xs, Ys)
+        dG.apply(Xs, Ys2)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(10):
+        dK.apply(Xs, Ys)
+        dG.apply(Xs, Ys2)
+    spmm_ms = ctx.timer_stop_ms() / 20
+    spmm_bytes = dK.spmv_bytes(N)
+    spmm_rate = spmm_bytes / (spmm_ms * 1e-3) / 1e9
+    spmm_traffic, spmm_src = (measured_traffic("spmm_k32_c3", ("sparse.hip",)) if default_c3 else (None, "not the C3 default"))
+    spmm = {"kernel": "spmm_tiled_kernel", "bound": "hbm", "achieved": round(spmm_rate, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(spmm_rate / HBM_PEAK_GBS, 4), "traffic": spmm_traffic,
+            "traffic_source": spmm_src, "bytes_per_launch": spmm_bytes, "us_per_launch": round(spmm_ms * 1e3, 2),
+            "columns": N}
+    del Ys, Ys2
+
     # ------------------------------------------------------------------ the same design point prepared on the device
     # (untimed preamble): K values, stress stiffness G(u), K + sigma G and the numeric refactorisation
     # without host arrays; compared with the host-assembled matrices.
@@ -659,6 +679,7 @@ def main():
                    "parallelism": f"modes sharded over {world} GPU(s), one RCCL all-reduce of df/dx per step"},
         "roofline": roofline,
         "spmv": spmv,
+        "spmm": spmm,
         "cpu_baseline": cpu,
         "numpy_api": numpy_api,
         "accuracy": accuracy,

@@ -38,7 +38,15 @@ __global__ __launch_bounds__(kThreads) void reduce_partials_kernel(const double*
   const int o = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (o >= nout) return;
   double s = 0.0;
-  for (int g = lane; g < nblocks; g += 64) s += partial[static_cast<int64_t>(g) * nout + o];
+  int g = lane;
+  for (; g + 7 * 64 < nblocks; g += 8 * 64) {  // eight loads in flight, added in the same ascending order
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = partial[static_cast<int64_t>(g + 64 * q) * nout + o];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += v[q];
+  }
+  for (; g < nblocks; g += 64) s += partial[static_cast<int64_t>(g) * nout + o];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if (lane == 0) out[o] = s;

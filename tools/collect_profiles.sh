@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence for profiles/: kernel-trace statistics of the bench command, the two PMC passes over the sweep and
 # the SpMV (separate runs: --pmc with --kernel-trace only), the per-level table.  Run on the GPU box from the repo root:
-#   tools/collect_profiles.sh r03 [stats|pmc|all]
+#   tools/collect_profiles.sh r03 [stats|pmc|steppmc|all]
 # Results land in gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
 tag=${1:-r03}
 what=${2:-all}
@@ -23,5 +23,15 @@ if [ "$what" = "pmc" ] || [ "$what" = "all" ]; then
         > $out/pmc_spmv_$ctr.log 2>&1) || exit 1
     cp $(find $out/pmc_spmv_$ctr -name "*counter_collection.csv" | head -1) $out/pmc_${ctr}_spmv_coldot.csv
   done
+fi
+if [ "$what" = "steppmc" ] || [ "$what" = "all" ]; then
+  # HBM traffic of a whole step: the bench command under the two counters (separate runs, --kernel-trace only)
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_step_$ctr -- python3 $root/bench.py --steps 2 \
+        --warmup 1 --cpu-sample none --no-fd-check --numpy-steps 0 --spmv-reps 4 > $out/pmc_step_$ctr.json \
+        2> $out/pmc_step_$ctr.log || exit 1
+    cp $(find $out/pmc_step_$ctr -name "*counter_collection.csv" | head -1) $out/pmc_${ctr}_step.csv
+  done
+  python3 $root/tools/step_traffic_report.py $out/pmc_FETCH_SIZE_step.csv $out/pmc_WRITE_SIZE_step.csv > $out/step_traffic.txt
 fi
 ls -la $out | head -40

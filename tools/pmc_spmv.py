@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Small driver for the PMC passes: the C3 stiffness matrix, 20 SpMV launches and, as a byte-count
+"""Small driver for the PMC passes: the C3 stiffness matrix, 20 SpMV launches, 20 SpMM launches of 32 columns and, as a byte-count
 calibration of the counters for 8-byte-per-lane streams, 20 column-dot launches over two n x 32 blocks
 (exactly 2 * 8 * n * 32 bytes read each)."""
 import sys
@@ -23,7 +23,12 @@ Y = ctx.from_host(rng.normal(size=(n, 32)))
 for _ in range(20):
     dK.apply(x, y)
 ctx.sync()
+X2 = ctx.empty(n, 32)
+for _ in range(20):                     # the tiled SpMM at 32 columns
+    dK.apply(X, X2)
+ctx.sync()
+del X2
 for _ in range(20):
     X.coldot(Y)
 ctx.sync()
-print("n", n, "nnz", K.nnz, "spmv algorithmic bytes", dK.spmv_bytes(1), "coldot bytes", 2 * 8 * n * 32)
+print("n", n, "nnz", K.nnz, "spmv algorithmic bytes", dK.spmv_bytes(1), "spmm(32)", dK.spmv_bytes(32), "coldot bytes", 2 * 8 * n * 32)

@@ -16,11 +16,13 @@ K = col.stiffness()
 n = K.shape[0]
 F = Factor(ctx, K, coords=col.dof_coords())
 rng = np.random.default_rng(0)
-B = ctx.from_host(rng.normal(size=(n, 32)))
-X = ctx.empty(n, 32)
+kcols = int(os.environ.get("SWEEP_K", "32"))       # (development: the narrow sweeps' levels with SWEEP_K=4)
+B = ctx.from_host(rng.normal(size=(n, kcols)))
+X = ctx.empty(n, kcols)
 for _ in range(10):
     F.solve_to(B, X)
 ctx.sync()
+B = ctx.from_host(rng.normal(size=(n, 32)))
 Y = ctx.from_host(rng.normal(size=(n, 32)))
 for _ in range(20):
     B.coldot(Y)
