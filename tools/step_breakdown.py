@@ -7,7 +7,9 @@ import glob
 import re
 import sys
 
-f = glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True)[0]
+import os
+
+f = max(glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True), key=os.path.getmtime)  # the newest run
 rows = list(csv.DictReader(open(f)))
 names = [r["Kernel_Name"] for r in rows]
 st = [int(r["Start_Timestamp"]) for r in rows]
