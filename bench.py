@@ -424,6 +424,7 @@ def main():
     if comm is not None:
         elapsed = comm.allreduce_max(elapsed)       # the slowest rank's wall time
     adj_count = factor.count
+    last_round = dict(_adj.LAST_ROUND)              # the counters of the last timed step (later legs run more solves)
     ms_per_step = 1e3 * elapsed / args.steps
     value = N * args.steps / elapsed
 
@@ -688,12 +689,12 @@ def main():
         "sibk_iterations": [int(i) for i in solver.last_info],
         "eigensolve_sweeps": int(eig_count),
         "eigensolver": eig_info,
-        "lock_step": {"steps_per_gram_schmidt_pass": _adj.LAST_ROUND.get("steps_per_pass"),
-                      "inner_projections": _adj.LAST_ROUND.get("inner_projections"),
-                      "cycles": _adj.LAST_ROUND.get("gs_cycles"),
-                      "correcting_gram_schmidt_passes": _adj.LAST_ROUND.get("gs_correcting_passes"),
-                      "post_gs_projections_measured": _adj.LAST_ROUND.get("post_gs_projections"),
-                      "post_gs_updates_applied": _adj.LAST_ROUND.get("post_gs_updates_applied")},
+        "lock_step": {"steps_per_gram_schmidt_pass": last_round.get("steps_per_pass"),
+                      "inner_projections": last_round.get("inner_projections"),
+                      "cycles": last_round.get("gs_cycles"),
+                      "correcting_gram_schmidt_passes": last_round.get("gs_correcting_passes"),
+                      "post_gs_projections_measured": last_round.get("post_gs_projections"),
+                      "post_gs_updates_applied": last_round.get("post_gs_updates_applied")},
         # one design point of an optimisation loop as the reference's harness runs it (buckling.py:548-632, 874-986):
         # assembly + factorisation (device: K, G(u), K + sigma G, numeric factor) + eigensolve + the timed step
         "design_point_s": round(timing["device_assemble_and_refactor_s"] + timing["eigensolve_s"] + ms_per_step * 1e-3, 4),
