@@ -533,7 +533,8 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_staged_kernel(int n, int ku,
 // X from the same pass), else 0: the update X -= U C that follows is skipped then (see eigd_project_norm2)
 __global__ __launch_bounds__(kThreads) void project_decide_kernel(const double* __restrict__ C, int ku, int kx,
                                                                  const double* __restrict__ norm2, double tol,
-                                                                 int* __restrict__ gate, int* __restrict__ stats) {
+                                                                 int* __restrict__ gate, int* __restrict__ stats,
+                                                                 double* __restrict__ flag_out = nullptr) {
   __shared__ int any;
   if (threadIdx.x == 0) any = 0;
   __syncthreads();
@@ -546,8 +547,11 @@ __global__ __launch_bounds__(kThreads) void project_decide_kernel(const double* 
   __syncthreads();
   if (threadIdx.x == 0) {
     gate[0] = any;
-    stats[0] += 1;  // (one workgroup, launches of a stream run in order: plain adds)
-    stats[1] += any;
+    if (stats != nullptr) {
+      stats[0] += 1;  // (one workgroup, launches of a stream run in order: plain adds)
+      stats[1] += any;
+    }
+    if (flag_out != nullptr) flag_out[0] = any ? 1.0 : 0.0;
   }
 }
 
@@ -826,7 +830,15 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
     const char* v = std::getenv("EIGD_TN_STAGED");
     return (v && *v) ? std::atoi(v) != 0 : true;
   }();
-  if (((ku + 15) / 16) * ((kx + 15) / 16) <= 4)
+  // few tiles (narrow X): the direct form, whose waves share the rows of a tile -- measured against the staged form at
+  // 64 x 8: 137 against 165 us per call (EIGD_TN_STAGED_MIN: widest row-major U that still takes the direct form then;
+  // default 64 = always)
+  static const int staged_min = [] {
+    const char* v = std::getenv("EIGD_TN_STAGED_MIN");
+    return (v && *v) ? std::atoi(v) : 64;
+  }();
+  const bool few = ((ku + 15) / 16) * ((kx + 15) / 16) <= 4;
+  if (few && !(csu == 1 && staged_tn && ku > staged_min))
     hipLaunchKernelGGL(gemm_tn_kernel<1>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, csu, dX, ldx,
                        partial);
   else if (csu == 1 && staged_tn)
@@ -906,7 +918,8 @@ int eigd_gemm_nn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t
 // most kMaxK x kMaxK entries per launch, a wider V goes in two column halves (no host round trip in between)
 static int project_coefficients(eigd_ctx* ctx, int n, int ku, int kx, const double* dV, int ldv, const double* dX, int ldx,
                                 double* xnorm2 = nullptr) {
-  int rc = ctx->ensure_coef(sizeof(double) * static_cast<size_t>(ku) * kx + 64);  // (+ the gate word of project_norm2)
+  // (behind the coefficients: the gate word of the measured updates and kMaxK column norms)
+  int rc = ctx->ensure_coef(sizeof(double) * (static_cast<size_t>(ku) * kx + 8 + kMaxK));
   if (rc) return rc;
   for (int a0 = 0; a0 < ku; a0 += kMaxK) {
     const int ka = std::min(kMaxK, ku - a0);
@@ -981,6 +994,30 @@ int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, i
   rc = reduce_to_host(ctx, normpart, nparts, kx, dOut, nullptr, gate);
   if (rc) return rc;
   return publish_norm2(ctx, dOut, kx);
+}
+
+int eigd_project_to(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv, double* dX,
+                    int ldx, double* dC, int ldc, double tol, double* dFlag) {
+  EIGD_REQUIRE(ctx && dU && dV && dX && dC, "null argument");
+  EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx && ldu >= ku && ldv >= ku && ldc >= kx,
+               "bad shape n=%d ku=%d kx=%d", n, ku, kx);
+  EIGD_REQUIRE(tol >= 0.0 && (tol == 0.0 || dFlag != nullptr), "a measured update needs somewhere to report to");
+  const bool measured = tol > 0.0;
+  int rc = ctx->ensure_coef(sizeof(double) * (static_cast<size_t>(ku) * kx + 8 + kMaxK));
+  if (rc) return rc;
+  double* norms = ctx->coef + static_cast<size_t>(ku) * kx + 8;
+  rc = project_coefficients(ctx, n, ku, kx, dV, ldv, dX, ldx, measured ? norms : nullptr);
+  if (rc) return rc;
+  EIGD_HIP(hipMemcpy2DAsync(dC, sizeof(double) * ldc, ctx->coef, sizeof(double) * kx, sizeof(double) * kx, ku,
+                            hipMemcpyDeviceToDevice, ctx->stream));
+  int* gate = nullptr;
+  if (measured) {
+    gate = reinterpret_cast<int*>(ctx->coef + static_cast<size_t>(ku) * kx);
+    hipLaunchKernelGGL(project_decide_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, ctx->coef, ku, kx, norms, tol, gate,
+                       static_cast<int*>(nullptr), dFlag);
+    EIGD_LAUNCH_CHECK();
+  }
+  return gemm_nn_device(ctx, n, ku, kx, dU, ldu, 1, ctx->coef, dX, ldx, -1.0, 1.0, nullptr, nullptr, gate);
 }
 
 int eigd_project_stats(eigd_ctx* ctx, int* out) {

@@ -146,6 +146,7 @@ def default_context():
 _PIN_MIN_BYTES = 1 << 20             # smaller blocks: the staging of a pageable copy costs nothing that matters
 _PIN_POOL_MAX_BYTES = 8 * 1024**3    # released result buffers kept for reuse (a step returns the same shapes again)
 _PIN_KEEP_PER_SIZE = 3
+_PIN_FIRST_USE_MAX_BYTES = 32 << 20  # results of this size and more are page-locked from their second appearance on
 
 
 class _PinnedHost:
@@ -164,6 +165,7 @@ class _PinnedHost:
         self.held = 0
         self.seen = {}            # (address, nbytes) -> sightings of a caller-owned buffer
         self.registered = {}      # address -> nbytes
+        self.asked = {}           # nbytes -> results of that size asked for so far
 
     def empty(self, shape):
         import weakref
@@ -174,6 +176,12 @@ class _PinnedHost:
             ptr = lst.pop()
             self.held -= nbytes
         else:
+            # page-locking costs about what the staged copy of the same bytes costs twice over (62 ms for 255 MB): it
+            # pays from the second result of a size on -- a one-off download (the eigenvectors after a solve) goes to an
+            # ordinary array
+            self.asked[nbytes] = self.asked.get(nbytes, 0) + 1
+            if self.asked[nbytes] < 2 and nbytes >= _PIN_FIRST_USE_MAX_BYTES:
+                return np.empty(shape)
             h = c_vp()
             try:
                 call("eigd_host_alloc", nbytes, C.byref(h))
@@ -306,6 +314,10 @@ class DeviceBlock:
     def cols(self, c0, c1):
         """view of columns [c0, c1) (same rows, same leading dimension)"""
         return DeviceBlock(self.ctx, self.n, c1 - c0, self.buf, self.offset + c0, self.ld)
+
+    def rows(self, r0, r1):
+        """view of rows [r0, r1) (same columns, same leading dimension)"""
+        return DeviceBlock(self.ctx, r1 - r0, self.k, self.buf, self.offset + r0 * self.ld, self.ld)
 
     def zero(self):
         if self.ld == self.k:
@@ -449,6 +461,16 @@ class DeviceBlock:
             t = V.tdot(self)
             return self.add_product(U, t, alpha=-1.0, beta=1.0)
         call("eigd_project", self.ctx.h, self.n, U.k, self.k, U.ptr, U.ld, V.ptr, V.ld, self.ptr, self.ld)
+        return self
+
+    def project_to(self, U, V, Cdev, tol=0.0, flag=None):
+        """self <- self - U (V^T self) with the coefficients V^T self written to the device block Cdev (U.k x self.k)
+        and no host synchronisation; tol > 0: the update is applied only where it matters (measured on the device, as in
+        project_norm2) and flag (a 1 x 1 device block) receives 1.0 / 0.0"""
+        if U.k > 64 or self.k > 64 or (Cdev.n, Cdev.k) != (U.k, self.k):
+            raise ValueError("project_to: panels of at most 64 columns, coefficient block U.k x self.k")
+        call("eigd_project_to", self.ctx.h, self.n, U.k, self.k, U.ptr, U.ld, V.ptr, V.ld, self.ptr, self.ld, Cdev.ptr,
+             Cdev.ld, float(tol), flag.ptr if flag is not None else None)
         return self
 
     def project_norm2(self, U, V):

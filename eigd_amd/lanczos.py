@@ -212,12 +212,21 @@ def small_eigh(T):
     times the arithmetic of such a matrix waking its threads (20 ms instead of 2 for 136 x 136 on 256 cores): a few
     threads at most.
     """
-    try:
-        from threadpoolctl import threadpool_limits
-    except ImportError:
+    global _THREADPOOLS
+    if _THREADPOOLS is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+
+            _THREADPOOLS = ThreadpoolController()          # (finding the loaded BLAS libraries costs 1.3 ms: once)
+        except ImportError:
+            _THREADPOOLS = False
+    if _THREADPOOLS is False:
         return np.linalg.eigh(T)
-    with threadpool_limits(limits=4):
+    with _THREADPOOLS.limit(limits=4):
         return np.linalg.eigh(T)
+
+
+_THREADPOOLS = None
 
 
 def ritz_bounds(C_last, S, p):
@@ -370,6 +379,14 @@ class _BlockLanczosDevice:
             w[p] = tuple(self.ctx.empty(self.n, p) for _ in range(3))
         return w[p]
 
+    def _coefficients(self, p):
+        """device block for the coefficients of one step: rows [0, nc) first pass, [nc, 2 nc) second pass, then one row
+        per panel whose first entry says whether that panel's second pass was applied"""
+        w = self.__dict__.setdefault("_cf", {})
+        if p not in w:
+            w[p] = self.ctx.zeros(2 * self.V.ncols + self.V.npanels, p)
+        return w[p]
+
     def _orthonormalise(self, X, BX, tmp):
         """B-orthonormalise the block X in place (SVQB, twice); BX <- B X; returns C with X_in = X_out C"""
         Ctot = np.eye(X.k)
@@ -398,14 +415,24 @@ class _BlockLanczosDevice:
         self.BV.get_block(c - p, p, out=X)
         self.prob.fac(X)                                  # W = factor(B V_last): one p-column sweep
         self.sweeps += 1
-        H = self.BV.tdot_block(X, ns=c)
-        self.V.times_into(X, H, ns=c, alpha=-1.0, beta=1.0)
-        H2 = self.BV.tdot_block(X, ns=c)                   # what one pass left along the basis: measured ...
-        n1, n2 = np.linalg.norm(H, axis=0), np.linalg.norm(H2, axis=0)
-        if np.any(n2 > 1e-13 * np.maximum(n1, np.finfo(float).tiny)):
-            self.V.times_into(X, H2, ns=c, alpha=-1.0, beta=1.0)   # ... and removed where it matters
-            H = H + H2
-            self.reorth_passes += 1
+        # Gram-Schmidt against the basis, panel by panel, coefficients kept on the device (no host round trip per
+        # panel); then what that pass left along the basis is MEASURED panel by panel and removed where it matters
+        # (|coefficient| > 1e-13 |column|, decided on the device).  One synchronisation fetches the step's coefficients.
+        nc = self.V.ncols
+        Hd = self._coefficients(p)
+        pieces = list(zip(self.V.pieces(0, c), self.BV.pieces(0, c)))
+        for (Vb, a, b), (BVb, _, _) in pieces:
+            X.project_to(Vb, BVb, Hd.rows(a, b))
+        for q, ((Vb, a, b), (BVb, _, _)) in enumerate(pieces):
+            X.project_to(Vb, BVb, Hd.rows(nc + a, nc + b), tol=1e-13, flag=Hd.rows(2 * nc + q, 2 * nc + q + 1).cols(0, 1))
+        Hall = Hd.get()
+        H = Hall[:c].copy()
+        again = False
+        for q, ((_, a, b), _) in enumerate(pieces):
+            if Hall[2 * nc + q, 0] != 0.0:
+                H[a:b] += Hall[nc + a: nc + b]
+                again = True
+        self.reorth_passes += int(again)
         C = self._orthonormalise(X, BX, tmp)
         self.V.set_block(c, X)
         self.BV.set_block(c, BX)

@@ -164,6 +164,14 @@ int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu
 int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv,
                        double* dX, int ldx, double* dOut);
 int eigd_project_stats(eigd_ctx* ctx, int* out);
+/* One step of block Gram-Schmidt against a panel of the Lanczos basis with the coefficients KEPT ON THE DEVICE (the
+ * restarted block eigensolver that stands in for ARPACK's dsaitr reorthogonalisation, eigenvector_derivatives.py:1908-
+ * 1986): C = V^T X (ku x kx, ku, kx <= 64) is written to dC (row stride ldc), then X <- X - U C.  tol > 0: the update
+ * is MEASURED as in eigd_project_norm2 -- applied only if some |C[a][b]| > tol * |x_b| -- and dFlag[0] (device double)
+ * receives 1.0 or 0.0 accordingly (the second pass of "twice is enough").  No host synchronisation: the caller
+ * fetches the coefficient blocks of a whole step at once. */
+int eigd_project_to(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv, double* dX,
+                    int ldx, double* dC, int ldc, double tol, double* dFlag);
 /* column-wise dots  out[c] = sum_r X[r,c] Y[r,c]  (HOST out, length k); inner products / norms
  * of 1157-1158, 1219, 1233, 1259, 1504, 1537 batched over the modes                     */
 int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout);

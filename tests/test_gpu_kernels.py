@@ -529,6 +529,36 @@ def test_projection_update_is_skipped_when_the_block_is_already_projected(ctx, n
     assert np.abs(U.T @ dY.get()).max() < 1e-13 * np.linalg.norm(P[:, 0])
 
 
+@pytest.mark.parametrize("n,ku,k", [(30011, 64, 8), (4099, 40, 1), (9000, 8, 4)])
+def test_block_gram_schmidt_step_keeps_its_coefficients_on_the_device(ctx, n, ku, k):
+    """
+    eigd_project_to: X <- X - U (V^T X) with the coefficients written into rows of a device block (the restarted block
+    Lanczos fetches the coefficients of a whole step at once); with a tolerance the update is measured and the flag
+    says whether it ran.
+    """
+    rng = np.random.default_rng(n + ku)
+    U = np.linalg.qr(rng.normal(size=(n, ku)))[0]
+    X = rng.normal(size=(n, k))
+    dU = ctx.from_host(U)
+    Cd = ctx.zeros(2 * ku + 1, k)
+    dX = ctx.from_host(X)
+    dX.project_to(dU, dU, Cd.rows(0, ku))
+    flag = Cd.rows(2 * ku, 2 * ku + 1).cols(0, 1)
+    dX.project_to(dU, dU, Cd.rows(ku, 2 * ku), tol=1e-13, flag=flag)
+    Ch = Cd.get()
+    assert relerr(Ch[:ku], U.T @ X) < 1e-13
+    P = X - U @ (U.T @ X)
+    assert relerr(dX.get(), P) < 1e-13
+    assert np.abs(Ch[ku: 2 * ku]).max() < 1e-13 * np.abs(X).max() * np.sqrt(n) and Ch[2 * ku, 0] == 0.0
+    Y = P.copy()
+    Y[:, 0] += 1e-7 * U[:, 0]
+    dY = ctx.from_host(Y)
+    dY.project_to(dU, dU, Cd.rows(ku, 2 * ku), tol=1e-13, flag=flag)
+    Ch = Cd.get()
+    assert Ch[2 * ku, 0] == 1.0 and abs(Ch[ku, 0] - 1e-7) < 1e-12
+    assert np.abs(U.T @ dY.get()).max() < 1e-12
+
+
 def test_split_chain_hand_off_is_reproducible_over_many_sweeps(ctx):
     """the in-launch hand-off of partial blocks (big fronts near the root) gives the same bits sweep after sweep"""
     from eigd_amd.device import Factor
