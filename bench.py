@@ -377,10 +377,24 @@ def main():
     ctx.sync()
     timing["eigensolve_s"] = time.perf_counter() - t0
     eig_count = factor.count
+    # the same eigensolve once more, as every design point after the first sees it (work blocks, page-locked result
+    # buffers and the coefficient slots come from the pools the first one filled)
+    # (twice: the second large result of a size is the one that page-locks its buffer, the third finds it in the pool)
+    del lam, Phi
+    for _ in range(2):
+        solver = lam = Phi = None
+        solver = eg.IRAM(N=N, m=args.m, mode="buckling", ctx=ctx)
+        ctx.sync()
+        t0 = time.perf_counter()
+        lam, Phi = solver.solve(dG, dK, factor, sigma)     # (the matrices as they sit in HBM: no upload, as after a device assembly)
+        ctx.sync()
+        timing["eigensolve_repeat_s"] = time.perf_counter() - t0
+    factor.count = eig_count
     eig_info = {"block_size": int(getattr(solver, "block_size", 1)), "internal_basis": int(getattr(solver, "internal_basis", args.m)),
                 "restarts": int(solver.n_restarts), "sweeps": int(getattr(solver, "sweeps", eig_count)),
                 "factor_applications": int(eig_count), "extra_pairs_for_deflation": int(solver.n_extra)}
-    log(rank, f"eigensolve: {timing['eigensolve_s']:.2f}s, {eig_info}; BLF = {lam[:4]} ... {lam[-1]:.4f}")
+    log(rank, f"eigensolve: {timing['eigensolve_s']:.2f}s (repeated: {timing['eigensolve_repeat_s']:.2f}s), {eig_info}; "
+              f"BLF = {lam[:4]} ... {lam[-1]:.4f}")
 
     rng = np.random.default_rng(1)
     Phib = rng.uniform(size=(n, N))
@@ -697,7 +711,9 @@ def main():
                       "post_gs_updates_applied": last_round.get("post_gs_updates_applied")},
         # one design point of an optimisation loop as the reference's harness runs it (buckling.py:548-632, 874-986):
         # assembly + factorisation (device: K, G(u), K + sigma G, numeric factor) + eigensolve + the timed step
-        "design_point_s": round(timing["device_assemble_and_refactor_s"] + timing["eigensolve_s"] + ms_per_step * 1e-3, 4),
+        # (a design point after the first: device assembly + refactorisation and the eigensolve as repeated)
+        "design_point_s": round(timing["device_assemble_and_refactor_s"] + timing["eigensolve_repeat_s"] + ms_per_step * 1e-3, 4),
+        "first_design_point_s": round(timing["device_assemble_and_refactor_s"] + timing["eigensolve_s"] + ms_per_step * 1e-3, 4),
     }
     print(json.dumps(out), flush=True)
 

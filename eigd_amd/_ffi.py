@@ -76,9 +76,11 @@ _SIGNATURES = {
     "eigd_gemm_tn": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_int, c_vp],
     "eigd_gemm_nn": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_dbl, c_dbl],
     "eigd_project": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int],
-    "eigd_project_norm2": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp],
+    "eigd_project_norm2": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_dbl],
     "eigd_project_stats": [c_vp, c_vp],
-    "eigd_project_to": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_dbl, c_vp],
+    "eigd_svqb_step": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp],
+    "eigd_project_to": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_dbl, c_vp, c_vp],
+    "eigd_coldot_dev": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp],
     "eigd_coldot": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp],
     "eigd_coldot_dd": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp],
     "eigd_lincomb": [c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp],

@@ -105,7 +105,12 @@ class DeviceProblem:
     def project_r_norm2(self, X):
         """project_r followed by the squared column norms of the result (device block; see DeviceBlock.project_norm2)"""
         U, V = self._projector()
-        return X.project_norm2(U, V)
+        # the measured update compares |u_a| |c_ab| with |x_b|: the largest column norm of U, once per deflation set
+        cache = self.__dict__.setdefault("_uscale", {})
+        key = (U.buf, U.offset, U.k)
+        if cache.get("key") != key:
+            cache["key"], cache["value"] = key, float(np.max(U.colnorms()))
+        return X.project_norm2(U, V, uscale=cache["value"])
 
     def project_s(self, X):
         """X <- X - Phi (BPhi^T X)   (solution-side projector P^T)"""

@@ -529,8 +529,10 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_staged_kernel(int n, int ku,
   }
 }
 
-// gate[0] = 1 if some coefficient of a projection matters, |C[a][b]| > tol * |x_b| (norm2 = squared column norms of
-// X from the same pass), else 0: the update X -= U C that follows is skipped then (see eigd_project_norm2)
+// gate[0] = 1 if some coefficient of a projection matters, |C[a][b]| > tol * sqrt(norm2[b]), else 0: the update X -= U C
+// that follows is skipped then (see eigd_project_norm2).  norm2 = the squared column norms of X: the Euclidean ones
+// from the same pass, or -- eigd_project_to with dNorm2 -- the squared B-norms x_b^T B x_b the caller formed, which makes
+// the test the relative B-orthogonality of the block against the panel whatever the scale of B.
 __global__ __launch_bounds__(kThreads) void project_decide_kernel(const double* __restrict__ C, int ku, int kx,
                                                                  const double* __restrict__ norm2, double tol,
                                                                  int* __restrict__ gate, int* __restrict__ stats,
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(kThreads) void project_decide_kernel(const double* 
   int mine = 0;
   for (int q = threadIdx.x; q < ku * kx; q += kThreads) {
     const double c = C[q], lim = tol * tol * norm2[q % kx];
-    if (!(c * c <= lim)) mine = 1;  // (a NaN anywhere keeps the update)
+    if (!(c * c <= lim)) mine = 1;  // (a NaN anywhere, or a norm that rounding made negative, keeps the update)
   }
   if (mine) any = 1;
   __syncthreads();
@@ -555,6 +557,116 @@ __global__ __launch_bounds__(kThreads) void project_decide_kernel(const double* 
   }
 }
 
+// SVQB orthonormalising transform of a block from its Gram matrix, on the device (one wave; the host form is
+// lanczos.py:_svqb): G = X^T B X (p x p, p <= 32) is symmetrised and scaled to unit diagonal, A = D^-1 G D^-1 =
+// U diag(w) U^T by cyclic Jacobi rotations (small eigenvalues of a scaled positive matrix come out with high RELATIVE
+// accuracy, which is what the inverse square roots need), eigenvalues ascending as LAPACK orders them;
+// Tr = D^-1 U w^-1/2 makes X Tr B-orthonormal, Cq = w^1/2 U^T D gives X = (X Tr) Cq, Ctot <- Cq Ctot (first: Ctot <- Cq).
+// Directions with w <= 1e-28 max(w) carry nothing but rounding: their rows of Cq are zero and flag[0] becomes 1.0.
+constexpr int kSvqbMax = 32;
+__global__ __launch_bounds__(64) void svqb_kernel(const double* __restrict__ G, int p, double* __restrict__ Tr,
+                                                  double* __restrict__ Ctot, int first, double* __restrict__ flag) {
+  __shared__ double A[kSvqbMax][kSvqbMax + 1], U[kSvqbMax][kSvqbMax + 1], Cq[kSvqbMax][kSvqbMax + 1];
+  __shared__ double d[kSvqbMax], wi[kSvqbMax];
+  __shared__ int perm[kSvqbMax], bad[kSvqbMax], rotated;
+  const int lane = threadIdx.x;
+  for (int q = lane; q < p * p; q += 64) A[q / p][q % p] = 0.5 * (G[q] + G[(q % p) * p + q / p]);
+  __syncthreads();
+  if (lane < p) d[lane] = sqrt(fmax(A[lane][lane], 2.2250738585072014e-308));
+  __syncthreads();
+  for (int q = lane; q < p * p; q += 64) {
+    const int i = q / p, j = q % p;
+    A[i][j] = A[i][j] / (d[i] * d[j]);
+    U[i][j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const double eps = 1.1102230246251565e-16;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    if (lane == 0) rotated = 0;
+    __syncthreads();
+    for (int i = 0; i + 1 < p; ++i)
+      for (int j = i + 1; j < p; ++j) {
+        const double aij = A[i][j], aii = A[i][i], ajj = A[j][j];  // (the same for every lane: the branch is uniform)
+        if (fabs(aij) > eps * sqrt(fabs(aii * ajj))) {
+          const double tau = (ajj - aii) / (2.0 * aij);
+          const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+          const int k = lane;
+          if (k < p) {
+            if (k != i && k != j) {
+              const double aki = A[k][i], akj = A[k][j];
+              const double nki = c * aki - sn * akj, nkj = sn * aki + c * akj;
+              A[k][i] = nki;
+              A[i][k] = nki;
+              A[k][j] = nkj;
+              A[j][k] = nkj;
+            }
+            const double uki = U[k][i], ukj = U[k][j];
+            U[k][i] = c * uki - sn * ukj;
+            U[k][j] = sn * uki + c * ukj;
+          }
+          if (lane == 0) {
+            A[i][i] = aii - t * aij;
+            A[j][j] = ajj + t * aij;
+            A[i][j] = 0.0;
+            A[j][i] = 0.0;
+            rotated = 1;
+          }
+        }
+        __syncthreads();
+      }
+    if (rotated == 0) break;
+    __syncthreads();
+  }
+  // ascending order (rank by value, ties by index), the noise floor, the two transforms
+  if (lane < p) {
+    const double w = A[lane][lane];
+    int rank = 0;
+    double wmax = 2.2250738585072014e-308;
+    for (int j = 0; j < p; ++j) {
+      const double wj = A[j][j];
+      rank += (wj < w || (wj == w && j < lane)) ? 1 : 0;
+      wmax = fmax(wmax, wj);
+    }
+    perm[rank] = lane;
+    const int b = !(w > 1e-28 * wmax);
+    bad[lane] = b;
+    wi[lane] = b ? 1.0 : w;
+  }
+  __syncthreads();
+  for (int q = lane; q < p * p; q += 64) {
+    const int i = q / p, r = q % p, e = perm[r];
+    const double sq = sqrt(wi[e]);
+    Tr[i * p + r] = U[i][e] / sq / d[i];
+    Cq[r][i] = bad[e] ? 0.0 : sq * U[i][e] * d[i];
+  }
+  __syncthreads();
+  double out[(kSvqbMax * kSvqbMax + 63) / 64];
+  int nq = 0;
+  for (int q = lane; q < p * p; q += 64, ++nq) {
+    const int r = q / p, j = q % p;
+    double v;
+    if (first) {
+      v = Cq[r][j];
+    } else {
+      v = 0.0;
+      for (int i = 0; i < p; ++i) v += Cq[r][i] * Ctot[i * p + j];
+    }
+    out[nq] = v;
+  }
+  __syncthreads();  // (every entry of the old Ctot is read before any is replaced)
+  nq = 0;
+  for (int q = lane; q < p * p; q += 64, ++nq) Ctot[q] = out[nq];
+  if (lane == 0) {
+    int any = 0;
+    for (int j = 0; j < p; ++j) any |= bad[j];
+    if (first)
+      flag[0] = any ? 1.0 : 0.0;
+    else if (any)
+      flag[0] = 1.0;
+  }
+}
+
 // X[r][b] = beta * X[r][b] + alpha * sum_a U(r,a) C[a][b], C on the device (ku x kx).
 // A 64-row chunk of U is staged in LDS with all its loads in flight; wave w owns rows 16w..16w+15 and
 // forms each 16 x 16 output tile with v_mfma_f64_16x16x4_f64 (A = U rows from LDS, B = C from LDS with a
@@ -563,9 +675,15 @@ __device__ __forceinline__ int cs_stride(int kx) { return (kx % 32 == 0) ? kx + 
 
 
 // Row-major U (csu == 1): every wave works alone on 16-row groups and feeds its MFMAs with fragments of U loaded
-// straight from global memory (lane (i, k) holds U(base + i, 4 q + k): 32-byte pieces of the rows, every line is
-// used up by the eight loads of the group).  No LDS for U, no barrier after the one that publishes C, few registers:
-// many waves per CU keep the stream of U going.  NQ = ceil(ku / 4) compiled in (8 or 16).
+// straight from global memory.  Lane (i, g) holds NQ CONSECUTIVE columns of row base + i, U(base + i, NQ g .. NQ g + NQ - 1):
+// one contiguous piece of 8 NQ bytes per lane (16-byte loads when the rows are so aligned), every line of U is
+// requested by exactly one lane -- with the MFMA's natural operand order (lane (i, g) holding U(., 4 q + g)) the sixteen
+// loads of a group touched every line four times, and with thirty-odd waves per CU streaming different rows the later
+// requests missed the vector cache: 3.9 TB/s at 64 x 8, against the 6.7 of the transposed product on the same panels.
+// K-step q therefore multiplies columns {q, NQ + q, 2 NQ + q, 3 NQ + q}: the rows of C sit in LDS in that order (slot
+// 4 q + g holds row NQ g + q, rows beyond ku are zero).  No LDS for U, no barrier after the one that publishes C, few
+// registers: many waves per CU keep the stream of U going.  NQ = 8 (ku <= 32) or 16 (ku <= 64) compiled in.
+typedef double double2_t __attribute__((ext_vector_type(2)));
 template <int NQ>
 __global__ __launch_bounds__(kThreads) void gemm_nn_direct_kernel(int n, int ku, int kx, const double* __restrict__ U,
                                                                  int64_t rsu, const double* __restrict__ C,
@@ -576,25 +694,41 @@ __global__ __launch_bounds__(kThreads) void gemm_nn_direct_kernel(int n, int ku,
   // column (normpart[blockIdx.x * kx + b]) -- the norm pass over X that would follow a projection is folded in
   // gate != nullptr: a device word written earlier in the stream; zero = leave X alone
   if (gate != nullptr && *gate == 0) return;
-  extern __shared__ double Cs[];  // ku x cs_stride(kx)
+  extern __shared__ double Cs[];  // 4 NQ x cs_stride(kx)
   __shared__ double nred[kThreads / 64][64];
   double nsq[4] = {0.0, 0.0, 0.0, 0.0};
   const int tid = threadIdx.x;
   const int cld = cs_stride(kx);
-  for (int q = tid; q < ku * kx; q += kThreads) Cs[(q / kx) * cld + q % kx] = C[q];
+  for (int q = tid; q < 4 * NQ * kx; q += kThreads) {
+    const int slot = q / kx, b = q % kx;
+    const int k = NQ * (slot & 3) + (slot >> 2);
+    Cs[slot * cld + b] = (k < ku) ? C[k * kx + b] : 0.0;
+  }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int ntb = (kx + 15) >> 4;  // <= 4
   const int64_t ngroups = (static_cast<int64_t>(n) + 15) / 16;
   const int64_t gstride = static_cast<int64_t>(gridDim.x) * 4;
+  // whole rows of 4 NQ columns, 16-byte aligned: the lane's piece as 16-byte loads (wave-uniform test)
+  const bool vec = (ku == 4 * NQ) && ((rsu & 1) == 0) && ((reinterpret_cast<uintptr_t>(U) & 15) == 0);
   for (int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave; g < ngroups; g += gstride) {
     const int64_t base = g * 16;
     const int rows = static_cast<int>((n - base) < 16 ? (n - base) : 16);
-    const double* up = U + (base + li) * rsu + lk;
+    const double* up = U + (base + li) * rsu + NQ * lk;
     double a[NQ];
+    if (vec && rows == 16) {
+      const double2_t* vp = reinterpret_cast<const double2_t*>(up);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) a[q] = *((li < rows && 4 * q + lk < ku) ? up + 4 * q : &g_zero_word);
+      for (int q = 0; q < NQ / 2; ++q) {
+        const double2_t v = vp[q];
+        a[2 * q] = v.x;
+        a[2 * q + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) a[q] = *((li < rows && NQ * lk + q < ku) ? up + q : &g_zero_word);
+    }
     double xv[4][4];
 #pragma unroll
     for (int tb = 0; tb < 4; ++tb)
@@ -611,8 +745,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nn_direct_kernel(int n, int ku,
       const int b = tb * 16 + li;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int k = 4 * q + lk;
-        const double bv = (k < ku && b < kx) ? Cs[k * cld + b] : 0.0;
+        const double bv = (b < kx) ? Cs[(4 * q + lk) * cld + b] : 0.0;   // (row NQ lk + q of C)
         accs[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bv, accs[tb], 0, 0, 0);
       }
     }
@@ -802,13 +935,15 @@ static int reduce_to_host(eigd_ctx* ctx, const double* partial, int nblocks, int
 
 // partial-sum layout in ctx->scratch: [result nout][partials nblocks*nout]
 // xnorm2 (optional, row-major U only): the squared column norms of X from the same pass, left in xnorm2[0..kx) on the device
+// dest (optional, device): where the ku x kx result is left (default: the head of ctx->scratch)
 static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu,
-                          const double* dX, int ldx, double** dres, double* hC, double* xnorm2 = nullptr) {
+                          const double* dX, int ldx, double** dres, double* hC, double* xnorm2 = nullptr,
+                          double* dest = nullptr) {
   const int nb = grid_for_rows(n, kRB);
   const int nout = ku * kx;
   int rc = ctx->ensure_scratch(sizeof(double) * ((static_cast<size_t>(nb) + 1) * nout + static_cast<size_t>(nb) * kx));
   if (rc) return rc;
-  double* res = ctx->scratch;
+  double* res = dest != nullptr ? dest : ctx->scratch;
   double* partial = ctx->scratch + nout;
   double* xpart = partial + static_cast<size_t>(nb) * nout;
   if (xnorm2 != nullptr) {
@@ -860,7 +995,7 @@ static int gemm_nn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
                           int* nparts = nullptr, const int* gate = nullptr) {
   const size_t cs_bytes = sizeof(double) * (ku * ((kx % 32 == 0) ? kx + 16 : kx) + kRB * (ku + 1));
   if (csu == 1 && ku <= 64) {  // row-major U: wave-private streaming without LDS staging
-    const size_t cbytes = sizeof(double) * ku * ((kx % 32 == 0) ? kx + 16 : kx);
+    const size_t cbytes = sizeof(double) * (ku <= 32 ? 32 : 64) * ((kx % 32 == 0) ? kx + 16 : kx);
     const int nbd = grid_for_rows(n, 64);
     if (nparts) *nparts = nbd;
     if (ku <= 32)
@@ -917,17 +1052,16 @@ int eigd_gemm_nn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t
 // C = V^T X for up to 2 * kMaxK columns of V, left on the device in ctx->coef (ku x kx): the product kernel forms at
 // most kMaxK x kMaxK entries per launch, a wider V goes in two column halves (no host round trip in between)
 static int project_coefficients(eigd_ctx* ctx, int n, int ku, int kx, const double* dV, int ldv, const double* dX, int ldx,
-                                double* xnorm2 = nullptr) {
+                                double* xnorm2 = nullptr, double* cdest = nullptr) {
   // (behind the coefficients: the gate word of the measured updates and kMaxK column norms)
   int rc = ctx->ensure_coef(sizeof(double) * (static_cast<size_t>(ku) * kx + 8 + kMaxK));
   if (rc) return rc;
   for (int a0 = 0; a0 < ku; a0 += kMaxK) {
     const int ka = std::min(kMaxK, ku - a0);
-    double* dC = nullptr;
-    rc = gemm_tn_device(ctx, n, ka, kx, dV + a0, ldv, 1, dX, ldx, &dC, nullptr, a0 == 0 ? xnorm2 : nullptr);
+    // (the reduction of the partial sums writes the coefficients where they are wanted: no copy kernel in between)
+    rc = gemm_tn_device(ctx, n, ka, kx, dV + a0, ldv, 1, dX, ldx, nullptr, nullptr, a0 == 0 ? xnorm2 : nullptr,
+                        (cdest != nullptr ? cdest : ctx->coef) + static_cast<size_t>(a0) * kx);
     if (rc) return rc;
-    EIGD_HIP(hipMemcpyAsync(ctx->coef + static_cast<size_t>(a0) * kx, dC, sizeof(double) * ka * kx, hipMemcpyDeviceToDevice,
-                            ctx->stream));
   }
   return EIGD_OK;
 }
@@ -950,16 +1084,18 @@ int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu
 static int publish_norm2(eigd_ctx* ctx, const double* dOut, int k);
 
 int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv,
-                       double* dX, int ldx, double* dOut) {
+                       double* dX, int ldx, double* dOut, double uscale) {
   EIGD_REQUIRE(ctx && dU && dV && dX && dOut, "null argument");
+  EIGD_REQUIRE(uscale >= 0.0, "uscale = largest Euclidean column norm of U (0: unknown, taken as 1)");
   EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= 2 * kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx && ldu >= ku && ldv >= ku,
                "bad shape n=%d ku=%d kx=%d", n, ku, kx);
   // The projection behind a Gram-Schmidt step (reference 1257) meets a block that is already B-orthogonal to Phi up to
   // rounding: the vectors it was built from were projected before.  Whether the update X -= U (V^T X) matters is
   // MEASURED: the coefficient pass delivers the squared column norms of X as well, a one-workgroup kernel compares
-  // every coefficient with tol * |x_b| (EIGD_PROJ_SKIP_TOL, default 1e-13; 0: always update), and the update pass --
-  // the stream of U and two passes over X -- returns at once when none does; the norms of the pass already made are
-  // then the result.
+  // every coefficient with tol * |x_b| / uscale (EIGD_PROJ_SKIP_TOL, default 1e-13; 0: always update; uscale = the
+  // largest Euclidean column norm of U, so that what is compared is the size of the update |u_a| |c_ab| against |x_b|
+  // whatever the scale of the inner product), and the update pass -- the stream of U and two passes over X -- returns
+  // at once when none does; the norms of the pass already made are then the result.
   static const double skip_tol = [] {
     const char* v = std::getenv("EIGD_PROJ_SKIP_TOL");
     return (v && *v) ? std::atof(v) : 1e-13;
@@ -978,8 +1114,8 @@ int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, i
       EIGD_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->proj_stats), 2 * sizeof(int)));
       EIGD_HIP(hipMemsetAsync(ctx->proj_stats, 0, 2 * sizeof(int), ctx->stream));
     }
-    hipLaunchKernelGGL(project_decide_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, ctx->coef, ku, kx, dOut, skip_tol,
-                       gate, ctx->proj_stats);
+    hipLaunchKernelGGL(project_decide_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, ctx->coef, ku, kx, dOut,
+                       uscale > 0.0 ? skip_tol / uscale : skip_tol, gate, ctx->proj_stats);
     EIGD_LAUNCH_CHECK();
   }
   double* normpart = ctx->scratch + static_cast<size_t>(kMaxK) * kx;  // (the partials of C are spent by now)
@@ -997,7 +1133,7 @@ int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, i
 }
 
 int eigd_project_to(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv, double* dX,
-                    int ldx, double* dC, int ldc, double tol, double* dFlag) {
+                    int ldx, double* dC, int ldc, double tol, double* dFlag, const double* dNorm2) {
   EIGD_REQUIRE(ctx && dU && dV && dX && dC, "null argument");
   EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx && ldu >= ku && ldv >= ku && ldc >= kx,
                "bad shape n=%d ku=%d kx=%d", n, ku, kx);
@@ -1006,18 +1142,39 @@ int eigd_project_to(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int 
   int rc = ctx->ensure_coef(sizeof(double) * (static_cast<size_t>(ku) * kx + 8 + kMaxK));
   if (rc) return rc;
   double* norms = ctx->coef + static_cast<size_t>(ku) * kx + 8;
-  rc = project_coefficients(ctx, n, ku, kx, dV, ldv, dX, ldx, measured ? norms : nullptr);
+  // a contiguous coefficient block receives the coefficients directly and serves the update as well
+  double* coef = (ldc == kx) ? dC : ctx->coef;
+  rc = project_coefficients(ctx, n, ku, kx, dV, ldv, dX, ldx, (measured && dNorm2 == nullptr) ? norms : nullptr, coef);
   if (rc) return rc;
-  EIGD_HIP(hipMemcpy2DAsync(dC, sizeof(double) * ldc, ctx->coef, sizeof(double) * kx, sizeof(double) * kx, ku,
-                            hipMemcpyDeviceToDevice, ctx->stream));
+  if (coef != dC)
+    EIGD_HIP(hipMemcpy2DAsync(dC, sizeof(double) * ldc, ctx->coef, sizeof(double) * kx, sizeof(double) * kx, ku,
+                              hipMemcpyDeviceToDevice, ctx->stream));
   int* gate = nullptr;
   if (measured) {
     gate = reinterpret_cast<int*>(ctx->coef + static_cast<size_t>(ku) * kx);
-    hipLaunchKernelGGL(project_decide_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, ctx->coef, ku, kx, norms, tol, gate,
-                       static_cast<int*>(nullptr), dFlag);
+    hipLaunchKernelGGL(project_decide_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, coef, ku, kx,
+                       dNorm2 != nullptr ? dNorm2 : norms, tol, gate, static_cast<int*>(nullptr), dFlag);
     EIGD_LAUNCH_CHECK();
   }
-  return gemm_nn_device(ctx, n, ku, kx, dU, ldu, 1, ctx->coef, dX, ldx, -1.0, 1.0, nullptr, nullptr, gate);
+  return gemm_nn_device(ctx, n, ku, kx, dU, ldu, 1, coef, dX, ldx, -1.0, 1.0, nullptr, nullptr, gate);
+}
+
+int eigd_svqb_step(eigd_ctx* ctx, int n, int p, double* dX, int ldx, double* dBX, int ldbx, double* dC, int first,
+                   double* dFlag) {
+  EIGD_REQUIRE(ctx && dX && dBX && dC && dFlag, "null argument");
+  EIGD_REQUIRE(n > 0 && p >= 1 && p <= kSvqbMax && ldx >= p && ldbx >= p, "bad shape n=%d p=%d (blocks of at most %d)", n, p,
+               kSvqbMax);
+  int rc = ctx->ensure_coef(sizeof(double) * p * p);
+  if (rc) return rc;
+  double* gram = nullptr;
+  rc = gemm_tn_device(ctx, n, p, p, dX, ldx, 1, dBX, ldbx, &gram, nullptr);
+  if (rc) return rc;
+  hipLaunchKernelGGL(svqb_kernel, dim3(1), dim3(64), 0, ctx->stream, gram, p, ctx->coef, dC, first, dFlag);
+  EIGD_LAUNCH_CHECK();
+  // in place: a wave of the row-major product reads the sixteen rows of its group before it stores them
+  rc = gemm_nn_device(ctx, n, p, p, dX, ldx, 1, ctx->coef, dX, ldx, 1.0, 0.0);
+  if (rc) return rc;
+  return gemm_nn_device(ctx, n, p, p, dBX, ldbx, 1, ctx->coef, dBX, ldbx, 1.0, 0.0);
 }
 
 int eigd_project_stats(eigd_ctx* ctx, int* out) {
@@ -1028,6 +1185,23 @@ int eigd_project_stats(eigd_ctx* ctx, int* out) {
   EIGD_HIP(hipMemsetAsync(ctx->proj_stats, 0, 2 * sizeof(int), ctx->stream));
   EIGD_HIP(hipStreamSynchronize(ctx->stream));
   return EIGD_OK;
+}
+
+int eigd_coldot_dev(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* dOut) {
+  EIGD_REQUIRE(ctx && dX && dY && dOut, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldx >= k && ldy >= k, "bad shape n=%d k=%d", n, k);
+  const int kp = next_pow2(k);
+  const int nb = grid_for_rows(n, (kThreads / kp) * 8);
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(nb) + 1) * k);
+  if (rc) return rc;
+  double* partial = ctx->scratch + k;
+  rc = dispatch_kp(k, [&](auto KP) {
+    hipLaunchKernelGGL(coldot_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dX, ldx, dY,
+                       ldy, partial);
+  });
+  if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  return reduce_to_host(ctx, partial, nb, k, dOut, nullptr);
 }
 
 int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout) {

@@ -463,23 +463,46 @@ class DeviceBlock:
         call("eigd_project", self.ctx.h, self.n, U.k, self.k, U.ptr, U.ld, V.ptr, V.ld, self.ptr, self.ld)
         return self
 
-    def project_to(self, U, V, Cdev, tol=0.0, flag=None):
+    def project_to(self, U, V, Cdev, tol=0.0, flag=None, norm2=None):
         """self <- self - U (V^T self) with the coefficients V^T self written to the device block Cdev (U.k x self.k)
-        and no host synchronisation; tol > 0: the update is applied only where it matters (measured on the device, as in
-        project_norm2) and flag (a 1 x 1 device block) receives 1.0 / 0.0"""
+        and no host synchronisation; tol > 0: the update is applied only where it matters (measured on the device: some
+        coefficient above tol times the norm of its column -- ``norm2``: a 1 x k device block of squared norms, e.g. the
+        B-norms from coldot_dev; without it the Euclidean norms as in project_norm2) and flag (a 1 x 1 device block)
+        receives 1.0 / 0.0"""
         if U.k > 64 or self.k > 64 or (Cdev.n, Cdev.k) != (U.k, self.k):
             raise ValueError("project_to: panels of at most 64 columns, coefficient block U.k x self.k")
+        if norm2 is not None and norm2.n * norm2.k != self.k:
+            raise ValueError("project_to: one squared norm per column of the block")
         call("eigd_project_to", self.ctx.h, self.n, U.k, self.k, U.ptr, U.ld, V.ptr, V.ld, self.ptr, self.ld, Cdev.ptr,
-             Cdev.ld, float(tol), flag.ptr if flag is not None else None)
+             Cdev.ld, float(tol), flag.ptr if flag is not None else None, norm2.ptr if norm2 is not None else None)
         return self
 
-    def project_norm2(self, U, V):
+    def coldot_dev(self, other, out):
+        """column-wise dots with ``other`` into the device block ``out`` (1 x k), no host synchronisation"""
+        if self.k > 64 or (other.n, other.k) != (self.n, self.k) or out.n * out.k != self.k:
+            raise ValueError("coldot_dev: blocks of the same shape with at most 64 columns, one result per column")
+        call("eigd_coldot_dev", self.ctx.h, self.n, self.k, self.ptr, self.ld, other.ptr, other.ld, out.ptr)
+        return out
+
+    def svqb_step(self, BX, Cdev, first, flag):
+        """one SVQB pass of the B-orthonormalisation of this block on the device (no host round trip): self and BX are
+        multiplied in place by the transform of their Gram matrix self^T BX, Cdev (p x p device block) <- Cq Cdev with
+        self_in = self_out Cq (first: Cdev <- Cq), flag (1 x 1 device block) tells a numerically dependent direction"""
+        if self.k > 32 or (BX.n, BX.k) != (self.n, self.k) or (Cdev.n, Cdev.k) != (self.k, self.k) or Cdev.ld != self.k:
+            raise ValueError("svqb_step: blocks of at most 32 columns, a contiguous p x p coefficient block")
+        call("eigd_svqb_step", self.ctx.h, self.n, self.k, self.ptr, self.ld, BX.ptr, BX.ld, Cdev.ptr, 1 if first else 0,
+             flag.ptr)
+        return self
+
+    def project_norm2(self, U, V, uscale=0.0):
         """project(U, V), then the squared column norms of the result: as colnorm2_dev (device block + pinned copy for
-        ctx.fetch_colnorm2), but formed while the projection writes the block -- no extra pass over it"""
+        ctx.fetch_colnorm2), but formed while the projection writes the block -- no extra pass over it.  ``uscale``: the
+        largest Euclidean column norm of U (makes the measured update independent of the scale of the inner product)"""
         if U.k > 128 or self.k > 64:
             return self.project(U, V).colnorm2_dev()
         out = self.ctx.empty(1, self.k)
-        call("eigd_project_norm2", self.ctx.h, self.n, U.k, self.k, U.ptr, U.ld, V.ptr, V.ld, self.ptr, self.ld, out.ptr)
+        call("eigd_project_norm2", self.ctx.h, self.n, U.k, self.k, U.ptr, U.ld, V.ptr, V.ld, self.ptr, self.ld, out.ptr,
+             float(uscale))
         return out
 
     def gather_cols(self, cols):

@@ -158,23 +158,36 @@ int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu
 /* the projector followed by the squared column norms of the result (1257 + 1259 of sibk in one pass over X):
  * dOut (device, kx) receives them; a pinned copy is left for eigd_colnorm2_fetch as after eigd_colnorm2_dev.
  * The update pass is MEASURED: the coefficient pass also forms the column norms of X, and when no coefficient exceeds
- * EIGD_PROJ_SKIP_TOL (1e-13; 0 = always update) times the norm of its column -- the block was built from projected
- * vectors -- X is left as it is and those norms are the result.  eigd_project_stats: out[0] = projections measured,
+ * EIGD_PROJ_SKIP_TOL (1e-13; 0 = always update) times the norm of its column divided by uscale -- the block was built
+ * from projected vectors -- X is left as it is and those norms are the result.  uscale = the largest Euclidean column
+ * norm of U (0: unknown, 1 is used): the test then compares the size of the update, |u_a| |C[a][b]|, with |x_b| and does
+ * not depend on how B scales against the Euclidean norm.  eigd_project_stats: out[0] = projections measured,
  * out[1] = updates applied since the last call (resets both). */
 int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv,
-                       double* dX, int ldx, double* dOut);
+                       double* dX, int ldx, double* dOut, double uscale);
 int eigd_project_stats(eigd_ctx* ctx, int* out);
 /* One step of block Gram-Schmidt against a panel of the Lanczos basis with the coefficients KEPT ON THE DEVICE (the
  * restarted block eigensolver that stands in for ARPACK's dsaitr reorthogonalisation, eigenvector_derivatives.py:1908-
  * 1986): C = V^T X (ku x kx, ku, kx <= 64) is written to dC (row stride ldc), then X <- X - U C.  tol > 0: the update
- * is MEASURED as in eigd_project_norm2 -- applied only if some |C[a][b]| > tol * |x_b| -- and dFlag[0] (device double)
- * receives 1.0 or 0.0 accordingly (the second pass of "twice is enough").  No host synchronisation: the caller
- * fetches the coefficient blocks of a whole step at once. */
+ * is MEASURED -- applied only if some |C[a][b]| > tol * sqrt(dNorm2[b]), dNorm2 (device, kx) being the squared B-norms
+ * x_b^T B x_b of the columns (eigd_coldot_dev of X and B X): the relative B-orthogonality of the block against the panel,
+ * independent of the scale of B (the second pass of "twice is enough"); dNorm2 = NULL: against the Euclidean norms
+ * |x_b| as in eigd_project_norm2 -- and dFlag[0] (device double) receives 1.0 or 0.0 accordingly.  No host
+ * synchronisation: the caller fetches the coefficient blocks of a whole step at once. */
 int eigd_project_to(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv, double* dX,
-                    int ldx, double* dC, int ldc, double tol, double* dFlag);
+                    int ldx, double* dC, int ldc, double tol, double* dFlag, const double* dNorm2);
+/* One pass of the B-orthonormalisation of a new Lanczos block WITHOUT a host round trip (the role of ARPACK's dsaitr
+ * normalisation, eigenvector_derivatives.py:1908-1986, for blocks of p <= 32 vectors): G = X^T BX on the device, its
+ * SVQB transform by a one-wave Jacobi eigensolver (G = D U w U^T D; X <- X D^-1 U w^-1/2, BX likewise, both in place),
+ * dC (device, p x p, row-major) <- Cq dC with X_in = X_out Cq (first != 0: dC <- Cq), dFlag[0] (device double) = 1.0
+ * when a direction of the block was numerically dependent (w <= 1e-28 max w; set to 0.0 by a clean first pass). */
+int eigd_svqb_step(eigd_ctx* ctx, int n, int p, double* dX, int ldx, double* dBX, int ldbx, double* dC, int first,
+                   double* dFlag);
 /* column-wise dots  out[c] = sum_r X[r,c] Y[r,c]  (HOST out, length k); inner products / norms
  * of 1157-1158, 1219, 1233, 1259, 1504, 1537 batched over the modes                     */
 int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout);
+/* the same with the result left on the device (dOut, length k; no host synchronisation) */
+int eigd_coldot_dev(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* dOut);
 /* the same dots accumulated in twice the working precision (error-free products and sums, errors carried in a second
  * double): hout[c] + hout[k + c] = sum_r X[r,c] Y[r,c] to ~1e-30 of sum |X Y|.  For the entries of G = -Phi^T Phib
  * (345, 1180) of numerically repeated pairs, whose DIFFERENCE is divided by the eigenvalue gap in xi, eta (373-383) */

@@ -54,6 +54,28 @@ class NumpyBackend:
         self.V[:, keep:keep + p] = tail
 
 
+class DeferredNumpyBackend(NumpyBackend):
+    """the same backend with the device's two-phase protocol: a cycle's steps are enqueued, their coefficients are
+    collected at the end of the cycle"""
+
+    def __init__(self, *a):
+        super().__init__(*a)
+        self.outstanding = 0
+        self.most_outstanding = 0
+
+    def expand_begin(self, c, p):
+        self.outstanding += 1
+        self.most_outstanding = max(self.most_outstanding, self.outstanding)
+        return NumpyBackend.expand(self, c, p)
+
+    def expand_end(self, token):
+        self.outstanding -= 1
+        return token
+
+    def expand(self, c, p):
+        return self.expand_end(self.expand_begin(c, p))
+
+
 def laplace(nside, seed=0):
     I = sparse.identity(nside)
     T = sparse.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(nside, nside))
@@ -98,6 +120,21 @@ def test_restarted_block_lanczos_contract(p, k_want, m, m_int):
     bounds = np.abs(beta_m * Y[m - 1, :])
     order = np.argsort(-np.abs(theta))[:k_want]
     assert arpack_converged(bounds[order], theta[order], eps, abs(beta_m)).all()
+
+
+def test_deferred_protocol_gives_the_same_projected_matrix():
+    """a backend with expand_begin / expand_end (the device's) is driven cycle by cycle: same T, same restarts"""
+    K, M = laplace(30)
+    n, sigma, p, k_want, m_int = K.shape[0], -0.1, 4, 14, 48
+    out = []
+    for cls in (NumpyBackend, DeferredNumpyBackend):
+        be = cls(K, M, sigma, m_int + p)
+        be.start(np.random.default_rng(12345).uniform(-1, 1, size=(n, p)))
+        out.append((be,) + thick_restart_block_lanczos(be, k_want, m_int, p, np.finfo(float).eps, 500))
+    (b0, T0, C0, c0, nconv0, nr0), (b1, T1, C1, c1, nconv1, nr1) = out
+    assert (c0, nconv0, nr0, b0.applications) == (c1, nconv1, nr1, b1.applications)
+    assert np.array_equal(T0, T1) and np.array_equal(C0, C1)
+    assert b1.outstanding == 0 and b1.most_outstanding == m_int // p        # the first cycle: all its steps in flight
 
 
 def test_no_convergence_is_reported_not_hidden():

@@ -376,11 +376,17 @@ def test_g2_natural_frequency_from_the_design_variables(solver):
 
 
 @pytest.mark.parametrize("name,tol", [("g3_thermal32_eps1e-1_basiclanczos", 1e-8), ("g3_thermal32_eps1e-8_basiclanczos", 1e-8),
-                                      ("g3_thermal32_eps1e-8_iram", 1e-8)])
+                                      ("g3_thermal32_eps1e-8_iram", 3e-8)])
 def test_g3_thermal_from_the_design_variables(name, tol):
     """examples/thermal.py end to end on the device (1 dof / node, K and M both design dependent): compliance value and
     df/dx against the reference, nothing of the reference's eigen data adopted.  epsilon = 1e-8: xi / eta of the repeated
-    pairs come from compensated dot products (test_g3_thermal_repeated_branch_rhoEb): 1e-8 like everything else."""
+    pairs come from compensated dot products (test_g3_thermal_repeated_branch_rhoEb, which holds the branch to 1e-8 on
+    the reference's own eigenvectors).  HERE the eigenvectors are this solver's own, and inside a pair whose members are
+    2e-7 apart double precision fixes the individual vectors to a rotation of ~5e-10 only (eps / gap), which the
+    repeated-pair formulas carry into df/dx with a factor of ~20: the restarted solver's df/dx moves by 1e-9 ... 1.6e-8
+    from one start vector to the next (tools/g3_noise_probe.py, eight start vectors: profiles/r03_g3_chain_noise.txt;
+    2e-9 ... 1.9e-8 against the reference, whose ARPACK vectors are one more such draw).  The gate for that case is
+    therefore 3e-8, twice the measured spread; the 1e-8 parity of the branch itself is the other test's."""
     from eigd_amd import design
     from eigd_amd.device import default_context
 

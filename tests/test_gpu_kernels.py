@@ -559,6 +559,94 @@ def test_block_gram_schmidt_step_keeps_its_coefficients_on_the_device(ctx, n, ku
     assert np.abs(U.T @ dY.get()).max() < 1e-12
 
 
+def test_measured_second_pass_does_not_depend_on_the_scale_of_the_inner_product(ctx):
+    """
+    The second Gram-Schmidt pass of the block eigensolver is gated by the B-norm of what the first pass left (the
+    relative B-orthogonality of the new vectors), not by the Euclidean norm of the block: with B = s^2 I, s = 1e-4 (a
+    consistent mass matrix on a fine mesh has entries of that size) a remainder of 5e-10 |x|_B along a basis vector is
+    5e-14 |x|_2 in absolute terms -- the Euclidean test lets it pass (shown), the B-norm test removes it.
+    """
+    n, ku, k, sc = 30011, 64, 8, 1e-4
+    rng = np.random.default_rng(11)
+    Q = np.linalg.qr(rng.normal(size=(n, ku)))[0]
+    V, BV = Q / sc, Q * sc                                     # B-orthonormal basis and B times it, B = sc^2 I
+    X0 = rng.normal(size=(n, k))
+    dV, dBV = ctx.from_host(V), ctx.from_host(BV)
+    Cd = ctx.zeros(2 * ku + 2, k)
+    flag, nb2 = Cd.rows(2 * ku, 2 * ku + 1).cols(0, 1), Cd.rows(2 * ku + 1, 2 * ku + 2)
+    dX = ctx.from_host(X0)
+    dX.project_to(dV, dBV, Cd.rows(0, ku))
+    P = dX.get()
+    xB = sc * np.linalg.norm(P[:, 0])                         # |x_0|_B
+    delta = 0.5e-9 * xB
+    assert delta < 0.6e-13 * np.linalg.norm(P[:, 0])           # invisible to the Euclidean test
+    Y = P.copy()
+    Y[:, 0] += delta * V[:, 0]
+    dY = ctx.from_host(Y)
+    dY.project_to(dV, dBV, Cd.rows(ku, 2 * ku), tol=1e-13, flag=flag)                       # Euclidean gate: skipped
+    assert Cd.get()[2 * ku, 0] == 0.0 and np.array_equal(dY.get(), Y)
+    dBY = ctx.from_host(sc * sc * Y)
+    dY.coldot_dev(dBY, nb2)
+    assert relerr(Cd.get()[2 * ku + 1], sc * sc * np.sum(Y * Y, axis=0)) < 1e-13
+    dY.project_to(dV, dBV, Cd.rows(ku, 2 * ku), tol=1e-13, flag=flag, norm2=nb2)            # against the B-norms
+    Ch = Cd.get()
+    assert Ch[2 * ku, 0] == 1.0 and abs(Ch[ku, 0] - delta) < 1e-3 * delta
+    assert np.abs(BV.T @ dY.get())[:, 0].max() < 1e-13 * xB
+    # and a block that IS B-orthogonal to the level of rounding is left alone by the same test
+    dZ = ctx.from_host(P)
+    dZ.project_to(dV, dBV, Cd.rows(ku, 2 * ku), tol=1e-13, flag=flag, norm2=nb2)
+    dZ.project_to(dV, dBV, Cd.rows(ku, 2 * ku), tol=1e-13, flag=flag, norm2=nb2)
+    assert Cd.get()[2 * ku, 0] == 0.0
+
+
+@pytest.mark.parametrize("n,p,cond", [(20011, 8, 1e2), (9001, 8, 1e10), (5003, 1, 1.0), (7001, 16, 1e6), (4001, 32, 1e4)])
+def test_block_orthonormalisation_on_the_device(ctx, n, p, cond):
+    """
+    eigd_svqb_step (two passes, as the block eigensolver runs them): the block comes out B-orthonormal to rounding, the
+    accumulated p x p factor reproduces the input block, X_in = X_out C, and agrees with the host form (lanczos._svqb)
+    up to the order and signs of the directions; columns of very different length and a condition number of 1e10 are
+    handled (the Gram matrix is scaled to unit diagonal and diagonalised by Jacobi rotations).
+    """
+    from scipy import sparse
+
+    rng = np.random.default_rng(n + p)
+    B = sparse.diags(rng.uniform(0.5, 2.0, size=n) * 1e-6).tocsr()          # a mass matrix of small scale
+    Q = np.linalg.qr(rng.normal(size=(n, p)))[0]
+    X0 = (Q * np.logspace(0, np.log10(cond), p)) @ np.linalg.qr(rng.normal(size=(p, p)))[0]
+    X0 *= 10.0 ** rng.uniform(-3, 3, size=p)                                  # columns of very different length
+    dX, dBX = ctx.from_host(X0), ctx.from_host(B @ X0)
+    Cd = ctx.zeros(p + 1, p)
+    flag = Cd.rows(p, p + 1).cols(0, 1)
+    dX.svqb_step(dBX, Cd.rows(0, p), True, flag)
+    dBX.set(B @ dX.get())                                                     # (the eigensolver carries B X along; same here)
+    dX.svqb_step(dBX, Cd.rows(0, p), False, flag)
+    X1, Ch = dX.get(), Cd.get()
+    assert Ch[p, 0] == 0.0
+    assert np.abs(X1.T @ (B @ X1) - np.eye(p)).max() < 1e-13
+    assert relerr(X1 @ Ch[:p], X0) < 1e-9 * max(1.0, cond * 1e-6)
+    assert relerr(dBX.get(), B @ X1) < 1e-12 * np.sqrt(cond)
+    # the projector on the block's range is the host form's (SVQB twice through numpy's eigh)
+    from eigd_amd.lanczos import _svqb
+
+    Xh = X0.copy()
+    for _ in range(2):
+        G = Xh.T @ (B @ Xh)
+        Xh = Xh @ _svqb(0.5 * (G + G.T))[0]
+    if cond <= 1e6:    # (numpy's eigh resolves the small end of the Gram spectrum to eps cond^2 only: nothing to compare beyond)
+        assert np.abs(Xh.T @ (B @ X1) @ (X1.T @ (B @ Xh)) - np.eye(p)).max() < 1e-9 + 1e-14 * cond ** 2
+
+
+def test_block_orthonormalisation_flags_a_dependent_block(ctx):
+    n, p = 6007, 8
+    rng = np.random.default_rng(0)
+    X0 = rng.normal(size=(n, p))
+    X0[:, 5] = 0.0                                                            # a direction that carries nothing
+    dX, dBX = ctx.from_host(X0), ctx.from_host(X0)
+    Cd = ctx.zeros(p + 1, p)
+    dX.svqb_step(dBX, Cd.rows(0, p), True, Cd.rows(p, p + 1).cols(0, 1))
+    assert Cd.get()[p, 0] == 1.0
+
+
 def test_split_chain_hand_off_is_reproducible_over_many_sweeps(ctx):
     """the in-launch hand-off of partial blocks (big fronts near the root) gives the same bits sweep after sweep"""
     from eigd_amd.device import Factor
