@@ -78,7 +78,7 @@ _SIGNATURES = {
     "eigd_project": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_project_norm2": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_dbl],
     "eigd_project_stats": [c_vp, c_vp],
-    "eigd_svqb_step": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp],
+    "eigd_svqb_step": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_project_to": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_dbl, c_vp, c_vp],
     "eigd_coldot_dev": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp],
     "eigd_coldot": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp],

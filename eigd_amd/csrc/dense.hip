@@ -1160,7 +1160,7 @@ int eigd_project_to(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int 
 }
 
 int eigd_svqb_step(eigd_ctx* ctx, int n, int p, double* dX, int ldx, double* dBX, int ldbx, double* dC, int first,
-                   double* dFlag) {
+                   double* dFlag, int update_bx) {
   EIGD_REQUIRE(ctx && dX && dBX && dC && dFlag, "null argument");
   EIGD_REQUIRE(n > 0 && p >= 1 && p <= kSvqbMax && ldx >= p && ldbx >= p, "bad shape n=%d p=%d (blocks of at most %d)", n, p,
                kSvqbMax);
@@ -1173,7 +1173,7 @@ int eigd_svqb_step(eigd_ctx* ctx, int n, int p, double* dX, int ldx, double* dBX
   EIGD_LAUNCH_CHECK();
   // in place: a wave of the row-major product reads the sixteen rows of its group before it stores them
   rc = gemm_nn_device(ctx, n, p, p, dX, ldx, 1, ctx->coef, dX, ldx, 1.0, 0.0);
-  if (rc) return rc;
+  if (rc || !update_bx) return rc;
   return gemm_nn_device(ctx, n, p, p, dBX, ldbx, 1, ctx->coef, dBX, ldbx, 1.0, 0.0);
 }
 

@@ -484,14 +484,15 @@ class DeviceBlock:
         call("eigd_coldot_dev", self.ctx.h, self.n, self.k, self.ptr, self.ld, other.ptr, other.ld, out.ptr)
         return out
 
-    def svqb_step(self, BX, Cdev, first, flag):
+    def svqb_step(self, BX, Cdev, first, flag, update_bx=True):
         """one SVQB pass of the B-orthonormalisation of this block on the device (no host round trip): self and BX are
         multiplied in place by the transform of their Gram matrix self^T BX, Cdev (p x p device block) <- Cq Cdev with
-        self_in = self_out Cq (first: Cdev <- Cq), flag (1 x 1 device block) tells a numerically dependent direction"""
+        self_in = self_out Cq (first: Cdev <- Cq), flag (1 x 1 device block) tells a numerically dependent direction;
+        update_bx=False leaves BX as it is (the caller recomputes B X from the finished block)"""
         if self.k > 32 or (BX.n, BX.k) != (self.n, self.k) or (Cdev.n, Cdev.k) != (self.k, self.k) or Cdev.ld != self.k:
             raise ValueError("svqb_step: blocks of at most 32 columns, a contiguous p x p coefficient block")
         call("eigd_svqb_step", self.ctx.h, self.n, self.k, self.ptr, self.ld, BX.ptr, BX.ld, Cdev.ptr, 1 if first else 0,
-             flag.ptr)
+             flag.ptr, 1 if update_bx else 0)
         return self
 
     def project_norm2(self, U, V, uscale=0.0):

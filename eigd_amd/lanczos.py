@@ -485,7 +485,7 @@ class _BlockLanczosDevice:
         if p <= 32:
             self.prob.opB.apply(X, BX)
             X.svqb_step(BX, Cd, True, flag)
-            X.svqb_step(BX, Cd, False, flag)
+            X.svqb_step(BX, Cd, False, flag, update_bx=False)
             self.prob.opB.apply(X, BX)                     # recomputed from the final X (not carried through two products)
             Chost = None
         else:

@@ -180,9 +180,10 @@ int eigd_project_to(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int 
  * normalisation, eigenvector_derivatives.py:1908-1986, for blocks of p <= 32 vectors): G = X^T BX on the device, its
  * SVQB transform by a one-wave Jacobi eigensolver (G = D U w U^T D; X <- X D^-1 U w^-1/2, BX likewise, both in place),
  * dC (device, p x p, row-major) <- Cq dC with X_in = X_out Cq (first != 0: dC <- Cq), dFlag[0] (device double) = 1.0
- * when a direction of the block was numerically dependent (w <= 1e-28 max w; set to 0.0 by a clean first pass). */
+ * when a direction of the block was numerically dependent (w <= 1e-28 max w; set to 0.0 by a clean first pass).
+ * update_bx = 0 leaves BX alone (the last pass, when the caller forms B X afresh from the finished block). */
 int eigd_svqb_step(eigd_ctx* ctx, int n, int p, double* dX, int ldx, double* dBX, int ldbx, double* dC, int first,
-                   double* dFlag);
+                   double* dFlag, int update_bx);
 /* column-wise dots  out[c] = sum_r X[r,c] Y[r,c]  (HOST out, length k); inner products / norms
  * of 1157-1158, 1219, 1233, 1259, 1504, 1537 batched over the modes                     */
 int eigd_coldot(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const double* dY, int ldy, double* hout);
