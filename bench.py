@@ -411,6 +411,7 @@ def main():
         factor.count = 0
         _adj.LAST_ROUND["gs_cycles"] = _adj.LAST_ROUND["gs_correcting_passes"] = 0
         _adj.LAST_ROUND["post_gs_projections"] = _adj.LAST_ROUND["post_gs_updates_applied"] = 0
+        _adj.LAST_ROUND["cycles_enqueued_for_nothing"] = _adj.LAST_ROUND["cycles_waited_for"] = 0
         dpsi, data = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1,
                                           comm=comm, streams=args.streams)
         dfdx = solver.add_total_derivative(lamb, dPhib, dpsi, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data,
@@ -708,7 +709,9 @@ def main():
                       "cycles": last_round.get("gs_cycles"),
                       "correcting_gram_schmidt_passes": last_round.get("gs_correcting_passes"),
                       "post_gs_projections_measured": last_round.get("post_gs_projections"),
-                      "post_gs_updates_applied": last_round.get("post_gs_updates_applied")},
+                      "post_gs_updates_applied": last_round.get("post_gs_updates_applied"),
+                      "cycles_enqueued_for_nothing": last_round.get("cycles_enqueued_for_nothing"),
+                      "cycles_waited_for": last_round.get("cycles_waited_for")},
         # one design point of an optimisation loop as the reference's harness runs it (buckling.py:548-632, 874-986):
         # assembly + factorisation (device: K, G(u), K + sigma G, numeric factor) + eigensolve + the timed step
         # (a design point after the first: device assembly + refactorisation and the eigensolve as repeated)

@@ -58,6 +58,7 @@ class DeviceProblem:
         self.Phix = self.BPhix = self.lam_x = None
         self.PhiD = self.BPhiD = None
         self.use_extra = False
+        self._uscale = {}     # largest Euclidean column norm of B Phi ("N") / B [Phi | Phix] ("D"), formed on first use
 
     def on(self, ctx):
         """the same problem (shared device data) with work enqueued on another context / stream of the device"""
@@ -70,6 +71,7 @@ class DeviceProblem:
     def set_phi(self, Phi_host=None, Phi_dev=None):
         self.Phi = Phi_dev if Phi_dev is not None else self.ctx.from_host(Phi_host)
         self.BPhi = self.opB.apply(self.Phi)
+        self._uscale = {}
         self._rebuild_deflation()
 
     def set_extra(self, Phix_dev, lam_x):
@@ -80,6 +82,7 @@ class DeviceProblem:
 
     def _rebuild_deflation(self):
         self.PhiD = self.BPhiD = None
+        self._uscale.pop("D", None)
         if self.Phix is None or self.Phi is None or self.Phix.k == 0:
             return
         # the caller may have replaced Phi (signs, rotations inside a cluster, another set altogether): the extra vectors
@@ -105,12 +108,11 @@ class DeviceProblem:
     def project_r_norm2(self, X):
         """project_r followed by the squared column norms of the result (device block; see DeviceBlock.project_norm2)"""
         U, V = self._projector()
-        # the measured update compares |u_a| |c_ab| with |x_b|: the largest column norm of U, once per deflation set
-        cache = self.__dict__.setdefault("_uscale", {})
-        key = (U.buf, U.offset, U.k)
-        if cache.get("key") != key:
-            cache["key"], cache["value"] = key, float(np.max(U.colnorms()))
-        return X.project_norm2(U, V, uscale=cache["value"])
+        # the measured update compares |u_a| |c_ab| with |x_b|: the largest column norm of U, once per projector
+        which = "D" if U is self.BPhiD else "N"
+        if self._uscale.get(which) is None:
+            self._uscale[which] = float(np.max(U.colnorms()))
+        return X.project_norm2(U, V, uscale=self._uscale[which])
 
     def project_s(self, X):
         """X <- X - Phi (BPhi^T X)   (solution-side projector P^T)"""
@@ -962,16 +964,27 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
         n2 = prob.project_r_norm2(TPv)                                # ref 1257 + 1259
         TPv.pair_orthonormalise(n2, W[j + 1].cols(lo, hi), W[j + 2].cols(lo, hi), done[lo:hi])   # ref 1260
         more = j + 2 < maxiter
-        if more:
-            # the next cycle is in flight while the host solves this one; it runs on the columns that were unfinished
-            # after the cycle before (a mode that finishes now rides along once more with zero coefficients)
+        # The next cycle is put in flight while the host solves this one (it then runs on the columns that were
+        # unfinished after the cycle before: a mode that finishes now rides along once more with zero coefficients) --
+        # unless every live mode is expected to finish in this cycle: the cycle behind the last one would be two sweeps
+        # and two products for nothing (2 ms of a 75 ms step at C3, and a twentieth of a four-mode rank's share).  The
+        # expectation comes from each mode's own residual history (the reduction per step of its last cycle, applied to
+        # the two steps now being solved); a wrong "will finish" costs the idle time of the host solve, a wrong "will
+        # not" is the speculative cycle of before.
+        ahead = more and not (_PREDICT_FINISH and j > 0 and _all_expected_to_finish(hist, done, rtol * rnorm0, atol))
+        if ahead:
             nrng = _active_range(done)
             enqueue_cycle(j + 2, *nrng)
         vals = ctx.fetch_colnorm2(4 * kk)
         small_solves(j, lo, hi, h, vals)
         jlast = min(j + 2, maxiter)
         if done.all() or not more or not ok:
+            LAST_ROUND["cycles_enqueued_for_nothing"] = LAST_ROUND.get("cycles_enqueued_for_nothing", 0) + int(ahead and done.all())
             break
+        if not ahead:
+            LAST_ROUND["cycles_waited_for"] = LAST_ROUND.get("cycles_waited_for", 0) + 1
+            nrng = _active_range(done)                    # (with this cycle's results: the narrowest range)
+            enqueue_cycle(j + 2, *nrng)
         j += 2
         rng = nrng
     if prob.fac.native and ok:                            # one factor application per Krylov step and mode (ref 1248);
@@ -988,6 +1001,25 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     LAST_ROUND["post_gs_projections"] = LAST_ROUND.get("post_gs_projections", 0) + measured      # step was needed
     LAST_ROUND["post_gs_updates_applied"] = LAST_ROUND.get("post_gs_updates_applied", 0) + applied
     return dpsi, converged, info, ok
+
+
+_PREDICT_FINISH = __import__("os").environ.get("EIGD_PREDICT_FINISH", "1") != "0"
+
+
+def _all_expected_to_finish(hist, done, tol_rel, atol, margin=4.0):
+    """
+    True if every unfinished mode's residual, extrapolated over the two steps of the cycle being solved with the
+    reduction per step of its last cycle, falls below ``margin`` times its tolerance.  ``hist[c]`` holds the residual
+    norms of mode c so far (entry 0: the start residual).
+    """
+    for c in np.flatnonzero(~np.asarray(done)):
+        hc = hist[c]
+        if len(hc) < 3 or not (hc[-3] > 0.0):
+            return False
+        rate2 = min(hc[-1] / hc[-3], 1.0)                 # reduction over the last two steps
+        if not (hc[-1] * rate2 < margin * max(tol_rel, atol)):
+            return False
+    return True
 
 
 def _default_streams():
