@@ -949,11 +949,21 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
                     done[c] = True
                     break
 
-    rng = _active_range(done)
+    # The device part of the next cycle is put in flight while the host solves the current one.  What it has to carry is
+    # not known then, so it is PREDICTED from each mode's own residual history (_expected_to_finish: the reduction per
+    # step of its last cycle applied to the two steps being solved; at C3 the residual two steps on is 0.3 ... 1.15 of that):
+    #  * every live mode expected to finish (generous margin): nothing is enqueued -- the cycle behind the last one
+    #    would be two sweeps and two products for nothing; if a mode has not finished after all, the next cycle starts
+    #    when the host knows, at the price of the host solve's time;
+    #  * otherwise the next cycle runs on the column range of the modes NOT expected to finish (strict margin), instead
+    #    of the range that was unfinished a cycle ago: the sweeps drop to the 16- and 8-column kernels one cycle
+    #    earlier.  A mode outside that range that did not finish after all gets the cycle of its own afterwards
+    #    (columns never mix: the same cycle index may be worked through range by range).
+    ranges = [_active_range(done)]                        # column ranges to work through at cycle index j; [0] is in flight
     j = 0
-    enqueue_cycle(0, *rng)
+    enqueue_cycle(0, *ranges[0])
     while True:
-        lo, hi = rng                                      # a cycle keeps the column range it was launched with
+        lo, hi = ranges.pop(0)                            # a cycle keeps the column range it was launched with
         kk = hi - lo
         TPv = TP.cols(0, 2 * kk)
         if not inner_proj[0] and j > 0:
@@ -964,29 +974,45 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
         n2 = prob.project_r_norm2(TPv)                                # ref 1257 + 1259
         TPv.pair_orthonormalise(n2, W[j + 1].cols(lo, hi), W[j + 2].cols(lo, hi), done[lo:hi])   # ref 1260
         more = j + 2 < maxiter
-        # The next cycle is put in flight while the host solves this one (it then runs on the columns that were
-        # unfinished after the cycle before: a mode that finishes now rides along once more with zero coefficients) --
-        # unless every live mode is expected to finish in this cycle: the cycle behind the last one would be two sweeps
-        # and two products for nothing (2 ms of a 75 ms step at C3, and a twentieth of a four-mode rank's share).  The
-        # expectation comes from each mode's own residual history (the reduction per step of its last cycle, applied to
-        # the two steps now being solved); a wrong "will finish" costs the idle time of the host solve, a wrong "will
-        # not" is the speculative cycle of before.
-        ahead = more and not (_PREDICT_FINISH and j > 0 and _all_expected_to_finish(hist, done, rtol * rnorm0, atol))
-        if ahead:
-            nrng = _active_range(done)
-            enqueue_cycle(j + 2, *nrng)
+        nxt = None                                        # (cycle index, lo, hi) put in flight behind this one
+        if ranges:
+            nxt = (j,) + tuple(ranges[0])                 # another range waits at this cycle index
+        elif more:
+            tol_c = max(rtol * rnorm0, atol)
+            in_cycle = np.zeros(k, dtype=bool)
+            in_cycle[lo:hi] = True                        # (their steps j+1, j+2 are the ones being solved)
+            if _PREDICT_FINISH and j > 0:
+                stay_lax = ~done & ~_expected_to_finish(hist, done, in_cycle, tol_c, 4.0)
+                stay = ~done & ~_expected_to_finish(hist, done, in_cycle, tol_c, 0.5)
+            else:
+                stay_lax = stay = ~done
+            if stay_lax.any():
+                cols_n = np.flatnonzero(stay)
+                nxt = (j + 2, int(cols_n[0]), int(cols_n[-1]) + 1)
+        if nxt is not None:
+            enqueue_cycle(*nxt)
         vals = ctx.fetch_colnorm2(4 * kk)
         small_solves(j, lo, hi, h, vals)
         jlast = min(j + 2, maxiter)
-        if done.all() or not more or not ok:
-            LAST_ROUND["cycles_enqueued_for_nothing"] = LAST_ROUND.get("cycles_enqueued_for_nothing", 0) + int(ahead and done.all())
+        if not ok:
             break
-        if not ahead:
+        if ranges:
+            continue                                      # the next range of this cycle index is in flight
+        if done.all() or not more:
+            LAST_ROUND["cycles_enqueued_for_nothing"] = LAST_ROUND.get("cycles_enqueued_for_nothing", 0) + int(nxt is not None)
+            break
+        live = np.flatnonzero(~done)
+        if nxt is None:
             LAST_ROUND["cycles_waited_for"] = LAST_ROUND.get("cycles_waited_for", 0) + 1
-            nrng = _active_range(done)                    # (with this cycle's results: the narrowest range)
-            enqueue_cycle(j + 2, *nrng)
+            ranges = [(int(live[0]), int(live[-1]) + 1)]  # (with this cycle's results: the narrowest range)
+            enqueue_cycle(j + 2, *ranges[0])
+        else:
+            ranges = [nxt[1:]]
+            for missed in (live[live < nxt[1]], live[live >= nxt[2]]):   # expected to finish, did not: cycles of their own
+                if len(missed):                                          # (below and above the range in flight, never across it)
+                    LAST_ROUND["cycles_repeated_for_missed_modes"] = LAST_ROUND.get("cycles_repeated_for_missed_modes", 0) + 1
+                    ranges.append((int(missed[0]), int(missed[-1]) + 1))
         j += 2
-        rng = nrng
     if prob.fac.native and ok:                            # one factor application per Krylov step and mode (ref 1248);
         with prob.fac.factor._count_lock:                 # an abandoned attempt is counted by the one-step form that redoes it
             prob.fac.factor.count += int(sum((i if i is not None else maxiter) for i in info))
@@ -1006,20 +1032,24 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
 _PREDICT_FINISH = __import__("os").environ.get("EIGD_PREDICT_FINISH", "1") != "0"
 
 
-def _all_expected_to_finish(hist, done, tol_rel, atol, margin=4.0):
+def _expected_to_finish(hist, done, in_cycle, tol, margin):
     """
-    True if every unfinished mode's residual, extrapolated over the two steps of the cycle being solved with the
-    reduction per step of its last cycle, falls below ``margin`` times its tolerance.  ``hist[c]`` holds the residual
-    norms of mode c so far (entry 0: the start residual).
+    Per mode: True if its residual, extrapolated over the two steps of the cycle being solved with the reduction per step
+    of its last cycle, falls below ``margin`` times its tolerance.  ``hist[c]`` holds the residual norms of mode c so far
+    (entry 0: the start residual); only modes of the cycle in flight (``in_cycle``) with three entries can be judged.
+    ``_PREDICT_HOOK`` (tests): a function (c, verdict) -> verdict.
     """
-    for c in np.flatnonzero(~np.asarray(done)):
+    out = np.zeros(len(done), dtype=bool)
+    for c in np.flatnonzero(~np.asarray(done) & in_cycle):
         hc = hist[c]
-        if len(hc) < 3 or not (hc[-3] > 0.0):
-            return False
-        rate2 = min(hc[-1] / hc[-3], 1.0)                 # reduction over the last two steps
-        if not (hc[-1] * rate2 < margin * max(tol_rel, atol)):
-            return False
-    return True
+        v = False
+        if len(hc) >= 3 and hc[-3] > 0.0:
+            v = bool(hc[-1] * min(hc[-1] / hc[-3], 1.0) < margin * tol)
+        out[c] = _PREDICT_HOOK(c, v) if _PREDICT_HOOK is not None else v
+    return out
+
+
+_PREDICT_HOOK = None
 
 
 def _default_streams():

@@ -1187,6 +1187,53 @@ def test_deflating_extra_converged_pairs_leaves_psi_unchanged(monkeypatch, mode)
     assert s9._prob.PhiD is not None and s9._prob.PhiD.k == N + 9
 
 
+def test_lock_step_cycles_follow_predicted_column_ranges_and_survive_wrong_predictions(monkeypatch):
+    """
+    The lock-step solver decides what the next cycle carries BEFORE the host has solved the current one, from each mode's
+    residual history (no cycle behind the last one, the range of the modes not expected to finish).  The predictions only
+    steer the pipeline: with every kind of wrong prediction forced -- "all finish" in every cycle (each cycle then waits
+    for the host), "the first two and the last mode finish" in every cycle (they get cycles of their own, below and
+    above the range in flight), "nobody ever finishes" (the speculative pipeline of before) -- iteration counts and
+    residual histories are the same and psi agrees to rounding.
+    """
+    import eigd_amd as eg
+    from eigd_amd import adjoint as _adj
+    from eigd_amd.device import default_context
+    from eigd_amd.problems import BucklingColumn
+
+    ctx = default_context()
+    col = BucklingColumn(90, 90, seed=2)
+    K = col.stiffness()
+    u = col.full_vector(eg.SpLuOperator(K, ctx=ctx, check_symmetry=False)(col.f[col.reduced]))
+    A, B, sigma, N = col.geometric_stiffness(u), K, 1.0, 24
+    fac = eg.SpLuOperator((B + sigma * A).tocsr(), ctx=ctx, check_symmetry=False)
+    s = eg.IRAM(N=N, m=2 * N + 1, mode="buckling", ctx=ctx)
+    lam, Phi = s.solve(A, B, fac, sigma)
+    Phib = np.random.default_rng(7).uniform(-1, 1, size=(B.shape[0], N))
+    hooks = {"default": None, "all finish": lambda c, v: True, "edges finish": lambda c, v: c in (0, 1, N - 1),
+             "nobody finishes": lambda c, v: False}
+    runs = {}
+    for name, hook in hooks.items():
+        monkeypatch.setattr(_adj, "_PREDICT_HOOK", hook)
+        for key in ("cycles_enqueued_for_nothing", "cycles_waited_for", "cycles_repeated_for_missed_modes"):
+            _adj.LAST_ROUND[key] = 0
+        hist = []
+        fac.count = 0
+        psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, callback=hist.append)
+        runs[name] = (psi, list(s.last_info), hist, fac.count, dict(_adj.LAST_ROUND))
+        assert _adj.LAST_ROUND["steps_per_pass"] == 2
+    psi0, info0, hist0, count0, round0 = runs["default"]
+    assert max(info0) > 8 and round0["cycles_enqueued_for_nothing"] == 0       # the last cycle was seen coming
+    for name in ("all finish", "edges finish", "nobody finishes"):
+        psi, info, hist, count, rnd = runs[name]
+        assert info == info0 and count == count0, name
+        assert len(hist) == len(hist0) and np.allclose(hist, hist0, rtol=1e-6, atol=1e-300), name
+        assert relerr(psi, psi0) < 1e-11, name
+    assert runs["all finish"][4]["cycles_waited_for"] >= (max(info0) + 1) // 2 - 2
+    assert runs["edges finish"][4]["cycles_repeated_for_missed_modes"] >= 4
+    assert runs["nobody finishes"][4]["cycles_enqueued_for_nothing"] == 1
+
+
 @pytest.mark.parametrize("mode", ["buckling", "normal"])
 def test_two_krylov_steps_per_gram_schmidt_pass_match_the_one_step_solver(monkeypatch, mode):
     """
