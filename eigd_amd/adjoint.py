@@ -869,8 +869,14 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     Z = ctx.workspace_stack("krylov_Z2", maxiter + 1, n, k)
     W0 = W[0]
     W0.copy_from(R0)
-    prob.project_r(W0)                                   # ref 1232
-    r00 = W0.colnorms()                                  # ref 1233
+    # ref 1232-1233: the start residual was projected by the caller already (1193): this projection is measured -- its
+    # coefficient pass delivers the column norms as well, the update runs only if some coefficient matters
+    if k <= 64:
+        r00 = np.sqrt(np.maximum(prob.project_r_norm2(W0).get().ravel(), 0.0))
+        ctx.project_stats()                              # (not one of the projections behind a Gram-Schmidt step: not counted)
+    else:
+        prob.project_r(W0)
+        r00 = W0.colnorms()
     scale = np.where(done | (r00 == 0.0), 0.0, 1.0 / np.where(r00 == 0.0, 1.0, r00))
     W0.assign_lincomb([(scale, W0)])                     # ref 1234
     H = np.zeros((k, maxiter + 3, maxiter + 2))
