@@ -527,6 +527,24 @@ def _laa_device(prob, Vstack, m, dPhib, lam, sigma, Y, theta, indices, b_ortho, 
     return psi
 
 
+def _laa_relation_device(prob, Vpan, c, p, T, C_last, dPhib, lam, sigma, Y, theta, indices, mode, cols=None):
+    """
+    The Lanczos adjoint approximation from the block eigensolver's own basis WITHOUT the factor application of 521:
+    psi = -factor(B V Cf), and the basis satisfies the Lanczos relation factor(B V) = V T + Q C_last E_last^T (Q: the
+    residual block, stored behind the c basis vectors; it holds to the rounding of the eigensolve, ~1e-13), so
+    psi = -(V (T Cf) + Q (C_last Cf[c-p:c])): two tall-skinny products instead of a product with B and a sweep.
+    Used as the first guess of the Krylov solvers only (the method "laa" itself answers as the reference does).
+    """
+    Yb = Vpan.tdot_block(dPhib, ns=c)
+    Cf = laa_coefficients(Yb, lam, sigma, Y, theta, indices, True, mode)
+    if cols is not None:
+        Cf = Cf[:, cols]
+    psi = prob.ctx.empty(prob.n, Cf.shape[1])
+    Vpan.times_into(psi, T @ Cf, ns=c, alpha=-1.0, beta=0.0)
+    Vpan.times_into(psi, C_last @ Cf[c - p:c], ns=p, alpha=-1.0, beta=1.0, j0=c)
+    return psi
+
+
 def _vstack_from_host(ctx, V):
     n, m = V.shape
     st = ctx.stack(m, n, 1)

@@ -648,8 +648,14 @@ class _AdjointAPI:
                     and self._phi_token is self.Phi):
                 # the solver's own, larger basis (nobody replaced the Lanczos data since solve()): first guess only --
                 # method "laa" itself answers from the m-vector contract basis
-                Vg, mg, th_g, Y_g, idx_g = g
-                psi_c = adj._laa_device(prob, Vg, mg, dPhib, lam, self.sigma, Y_g, th_g, idx_g, True, self.mode, cols=cols)
+                Vg, mg, th_g, Y_g, idx_g, T_g, C_g, p_g = g
+                if __import__("os").environ.get("EIGD_LAA_RELATION", "1") != "0":
+                    # ... through the Lanczos relation of that basis: no product with B, no sweep for the guess
+                    psi_c = adj._laa_relation_device(prob, Vg, mg, p_g, T_g, C_g, dPhib, lam, self.sigma, Y_g, th_g, idx_g,
+                                                     self.mode, cols=cols)
+                else:
+                    psi_c = adj._laa_device(prob, Vg, mg, dPhib, lam, self.sigma, Y_g, th_g, idx_g, True, self.mode,
+                                            cols=cols)
             else:
                 psi_c = adj._laa_device(prob, self._dev.V, self._m, dPhib, lam, self.sigma, Y, theta, indices, True,
                                         self.mode, cols=cols)
@@ -1112,7 +1118,9 @@ class IRAM(_AdjointAPI):
                 # approximation (laa's closed form only uses V^T B V = I and T = V^T B OP V), the better first guess
                 th_i, Y_i = small_eigh(T)
                 _, idx_i = ritz_to_eigs(th_i, sigma, self.mode)
-                self._guess = (dev.snapshot(c), c, th_i, Y_i, idx_i)
+                # (with the residual block behind the c vectors and the coupling: the Lanczos relation
+                # OP V = V T + Q C E_last^T lets the guess be formed without applying the factor)
+                self._guess = (dev.snapshot(c + p), c, th_i, Y_i, idx_i, T.copy(), np.array(C, dtype=float), p)
             T, beta_m = compress_to_single_vector_basis(dev, T, C, c, p, m, max(tol, tol_x) if extra > 0 else tol,
                                                         keep_first=min(k_want, m - 1) if nconv >= k_want else k)
         self.block_size, self.internal_basis = p, m_int

@@ -1187,6 +1187,43 @@ def test_deflating_extra_converged_pairs_leaves_psi_unchanged(monkeypatch, mode)
     assert s9._prob.PhiD is not None and s9._prob.PhiD.k == N + 9
 
 
+def test_first_guess_through_the_lanczos_relation_needs_no_factor_application(monkeypatch):
+    """
+    The block eigensolver's basis satisfies factor(B V) = V T + Q C E_last^T, so the Lanczos adjoint approximation that
+    starts the Krylov solvers, psi0 = -factor(B V Cf) (reference 501-521), is -(V T Cf + Q C Cf_last): no product with B, no
+    sweep.  Against the form that applies the factor: the same guess to the accuracy of the Lanczos relation, the same
+    iteration counts and psi, N factor applications fewer per call.
+    """
+    import eigd_amd as eg
+    from eigd_amd import adjoint as _adj
+    from eigd_amd.device import default_context
+    from eigd_amd.problems import BucklingColumn
+
+    ctx = default_context()
+    col = BucklingColumn(165, 165, seed=3)                     # 54 k dof: the block form of the restarted solver
+    K = col.stiffness()
+    u = col.full_vector(eg.SpLuOperator(K, ctx=ctx, check_symmetry=False)(col.f[col.reduced]))
+    A, B, sigma, N = col.geometric_stiffness(u), K, 1.0, 12
+    fac = eg.SpLuOperator((B + sigma * A).tocsr(), ctx=ctx, check_symmetry=False)
+    s = eg.IRAM(N=N, m=2 * N + 1, mode="buckling", ctx=ctx)
+    lam, Phi = s.solve(A, B, fac, sigma)
+    assert s.block_size > 1 and s._guess is not None
+    Vg, c, th, Y, idx, T, C, p = s._guess
+    Phib = np.random.default_rng(5).uniform(-1, 1, size=(B.shape[0], N))
+    dPhib = ctx.from_host(Phib)
+    g_rel = _adj._laa_relation_device(s._prob, Vg, c, p, T, C, dPhib, lam, sigma, Y, th, idx, "buckling").get()
+    g_fac = _adj._laa_device(s._prob, Vg, c, dPhib, lam, sigma, Y, th, idx, True, "buckling").get()
+    assert relerr(g_rel, g_fac) < 1e-10
+    runs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("EIGD_LAA_RELATION", flag)
+        fac.count = 0
+        psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1)
+        runs[flag] = (psi, list(s.last_info), fac.count)
+    assert runs["1"][1] == runs["0"][1] and relerr(runs["1"][0], runs["0"][0]) < 1e-10
+    assert runs["0"][2] - runs["1"][2] == N
+
+
 def test_lock_step_cycles_follow_predicted_column_ranges_and_survive_wrong_predictions(monkeypatch):
     """
     The lock-step solver decides what the next cycle carries BEFORE the host has solved the current one, from each mode's
