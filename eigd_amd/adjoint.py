@@ -1125,7 +1125,10 @@ def _run_groups(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist, s
         return _sibk_round(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist)
     import threading
 
-    parts = [np.arange(g, k, groups) for g in range(groups)]
+    if __import__("os").environ.get("EIGD_STREAM_SPLIT", "cyclic") == "block":
+        parts = [np.asarray(a) for a in np.array_split(np.arange(k), groups)]
+    else:
+        parts = [np.arange(g, k, groups) for g in range(groups)]
     Rg = [Rc.gather_cols(part) for part in parts]
     prob.ctx.sync()
     out = [None] * groups
@@ -1137,8 +1140,18 @@ def _run_groups(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist, s
             ctxg.make_current()   # a fresh host thread: HIP's current device is per thread
             pg = prob.on(ctxg)
             R0 = ctxg.empty(Rc.n, len(parts[g])).copy_from(Rg[g])
-            out[g] = _sibk_round(pg, R0, lam_p[parts[g]], sigma, rnorm0, rtol, atol, maxiter,
-                                 [sub_hist[c] for c in parts[g]])
+            hg = [sub_hist[c] for c in parts[g]]
+            kg = len(parts[g])
+            res = None
+            if _sstep_default() == 2 and 2 * kg <= 64 and maxiter * 2 * min(kg, 32) * 8 <= 60 * 1024:
+                keep = [list(hh) for hh in hg]
+                ug, cg, ig, okg = _sibk_round_pair(pg, R0, lam_p[parts[g]], sigma, rnorm0, rtol, atol, maxiter, hg)
+                if okg:
+                    res = (ug, cg, ig)
+                else:
+                    for hh, h0 in zip(hg, keep):
+                        hh[:] = h0
+            out[g] = res if res is not None else _sibk_round(pg, R0, lam_p[parts[g]], sigma, rnorm0, rtol, atol, maxiter, hg)
             ctxg.sync()
         except BaseException as exc:  # re-raised on the calling thread
             errors.append(exc)

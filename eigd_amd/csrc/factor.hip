@@ -44,6 +44,12 @@ constexpr int TLD = TW + 1;  // padded LDS leading dimension
 #ifndef EIGD_FRAG_WAVES
 #define EIGD_FRAG_WAVES 3  // waves per SIMD the direct-fragment level kernels are compiled for
 #endif
+#ifndef EIGD_THIN_WAVES_LEAF
+#define EIGD_THIN_WAVES_LEAF 3  // waves per SIMD asked of the 32-column buffer-access thin forward kernels: leaf fronts ...
+#endif
+#ifndef EIGD_THIN_WAVES_KIDS
+#define EIGD_THIN_WAVES_KIDS 3  // ... and fronts with two carry planes
+#endif
 constexpr int KBMAX = 32;    // right-hand sides per sweep
 
 struct FrontArrays {
@@ -1556,6 +1562,21 @@ __global__ __launch_bounds__(64) void bwd_wave_kernel(FrontArrays fa, const WgRe
 }
 
 
+// Raw buffer access (stride 0, byte offsets): an offset at or past num_records reads 0.0 / drops the store -- the
+// masked lanes of the wave-per-front kernels need neither a second (64-bit) address nor a load from the zero word.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+constexpr unsigned kBufOob = 0xFFFFFFF8u;   // with num_records <= kBufMax every access at this offset is out of range
+constexpr int64_t kBufMax = 0xFFFFFFF0ll;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(static_cast<unsigned>(bytes)), 0x00020000);
+}
+__device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, static_cast<int>(off), 0, 0));
+}
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned off, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, static_cast<int>(off), 0, 0);
+}
+
 // ------------------------------------------------------------------ thin fronts (few own columns), 16 or 32 columns
 // Two or three levels above the leaves the fronts have a handful of own columns and a long border: almost no flops,
 // but every tile step of the workgroup kernels above is a round of dependent loads with two workgroups per CU to hide
@@ -1566,8 +1587,12 @@ __global__ __launch_bounds__(64) void bwd_wave_kernel(FrontArrays fa, const WgRe
 // forward: wave = 16-row blocks rb, rb + 2, ... of [T; M21] (two waves per front).  K = own columns (NKS steps of 4).
 // WPF: waves per front (1: the right-hand side block is loaded once per front); TRI: T has lower triangular diagonal
 // blocks (Cholesky path) -- false on the Bunch-Kaufman path, whose diagonal blocks are dense
-template <int KB, int NKS, int NSL, int WPF, bool TRI>
-__global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
+// BUF: the row blocks' matrix operands, carries and results go through raw buffer accesses (needs the row-major copy
+// Ftp and planes / result blocks below 4 GB: checked by the launcher): one 32-bit offset per access instead of a
+// selected 64-bit address, masked lanes out of range -- the registers that buys are a third wave per SIMD
+template <int KB, int NKS, int NSL, int WPF, bool TRI, bool BUF = false>
+__global__ __launch_bounds__(64 * WPF) __attribute__((amdgpu_waves_per_eu((BUF && KB == 32) ? (NSL == 0 ? EIGD_THIN_WAVES_LEAF : (NSL == 2 ? EIGD_THIN_WAVES_KIDS : 1)) : 1)))
+void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
                                                        const double* __restrict__ F, const double* __restrict__ Tb,
                                                        const double* X, int ldx, double alpha, double* V,
                                                        double* __restrict__ Y, int kb, const double* __restrict__ Ftp) {
@@ -1587,6 +1612,23 @@ __global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, cons
       xi[s] = *((4 * s + lk < ns) ? fa.v_src + vbase + 4 * s + lk : fa.neg1);
       mo[s] = (NSL > 0) ? *((4 * s + lk < ns && nslot > 0) ? fa.cmask + vbase + 4 * s + lk : reinterpret_cast<const int*>(fa.zero)) : 0;
     }
+    if constexpr (BUF) {  // (the launcher has checked that the caller's block and a plane stay below 4 GB)
+      const __amdgpu_buffer_rsrc_t rx = buf_rsrc(X, kBufMax);
+#pragma unroll
+      for (int s = 0; s < NKS; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int o = 4 * s + lk, n = 16 * nb + li;
+          const bool ok = xi[s] >= 0 && n < kb;
+          const double xv = alpha * buf_load(rx, ok ? static_cast<unsigned>((static_cast<int64_t>(xi[s]) * ldx + n) * 8) : kBufOob);
+          const unsigned coff = static_cast<unsigned>(((vbase + o) * KB + n) * 8);
+          double v = 0.0;
+#pragma unroll
+          for (int sl = 0; sl < NSL; ++sl)
+            v += buf_load(buf_rsrc(V + sl * vslot, vslot * 8), (ok && ((mo[s] >> sl) & 1)) ? coff : kBufOob);
+          b[s][nb] = xv + v;
+        }
+    } else {
 #pragma unroll
     for (int s = 0; s < NKS; ++s)
 #pragma unroll
@@ -1600,6 +1642,7 @@ __global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, cons
         for (int sl = 0; sl < NSL; ++sl) v += *((ok && ((mo[s] >> sl) & 1)) ? cp + sl * vslot : fa.zero);
         b[s][nb] = xv + v;
       }
+    }
   }
   double* Vout = V + static_cast<int64_t>(w.slot) * vslot;
   const double* Tf = Tb + w.toff;
@@ -1612,6 +1655,95 @@ __global__ __launch_bounds__(64 * WPF) void fwd_thin_kernel(FrontArrays fa, cons
 #pragma unroll
   for (int q = 0; q < 6; ++q)
     M[q] = (NSL > 0) ? *((mreg && 64 * q + lane < d) ? fa.cmask + vbase + 64 * q + lane : reinterpret_cast<const int*>(fa.zero)) : 0;
+  if constexpr (BUF) {
+    // lane offsets are bytes inside the front's block of Ft (d x ns doubles, row-major), a plane of V or the block Y
+    const __amdgpu_buffer_rsrc_t ra = buf_rsrc(Ftp + w.ftoff, static_cast<int64_t>(d) * ns * 8);
+    const __amdgpu_buffer_rsrc_t ry = buf_rsrc(Y, (vbase + d) * kb * 8);
+    const __amdgpu_buffer_rsrc_t rv = buf_rsrc(Vout, vslot * 8);
+    for (int rb = wave; rb < nrb; rb += WPF) {
+      const int r = 16 * rb + li;
+      const int smax = (TRI && 16 * rb + 16 <= ns) ? 4 * (rb + 1) : NKS;
+      // rows past the front are past the block (out of range: 0.0); entries past the row's ns columns belong to the
+      // next row and meet the zero rows of v1; K-steps past the diagonal block are not requested (offset out of range)
+      const unsigned aoff = static_cast<unsigned>(r * ns + lk) * 8u;
+      double a[NKS];
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) a[s] = buf_load(ra, (s < smax ? aoff : 0x80000000u) + 32u * s);  // (a front's block is far below 2 GB)
+      int di[4];
+      double sg[4], cg[4][NB];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ro = 16 * rb + lk + 4 * reg;
+        const bool border = ro >= ns && ro < d;
+        di[reg] = *(border ? fa.rel + w.bptr + (ro - ns) : fa.neg1);
+        sg[reg] = *((ro < ns) ? fa.sgn + w.c0 + ro : fa.zero);
+      }
+      if constexpr (NSL > 0) {
+        int mk[4];
+        if (mreg) {
+          const int q = rb >> 2;
+          const int Mq = (q == 0) ? M[0] : (q == 1) ? M[1] : (q == 2) ? M[2] : (q == 3) ? M[3] : (q == 4) ? M[4] : M[5];
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int ro = 16 * rb + lk + 4 * reg;
+            const int m = __shfl(Mq, ro & 63);
+            mk[reg] = (ro >= ns && ro < d) ? m : 0;
+          }
+        } else {
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int ro = 16 * rb + lk + 4 * reg;
+            mk[reg] = *((ro >= ns && ro < d && nslot > 0) ? fa.cmask + vbase + ro : reinterpret_cast<const int*>(fa.zero));
+          }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int ro = 16 * rb + lk + 4 * reg;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int n = 16 * nb + li;
+            const unsigned coff = static_cast<unsigned>(((vbase + ro) * KB + n) * 8);
+            double v = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl)
+              v += buf_load(buf_rsrc(V + sl * vslot, vslot * 8), (n < kb && ((mk[reg] >> sl) & 1)) ? coff : kBufOob);
+            cg[reg][nb] = v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) cg[reg][nb] = 0.0;
+      }
+      double4_t c[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) c[nb] = double4_t{0.0, 0.0, 0.0, 0.0};
+      const int kmax = (NKS <= 8) ? min(smax, (ns + 3) >> 2) : NKS;
+#pragma unroll
+      for (int s = 0; s < NKS; ++s)
+        if (NKS > 8 || s < kmax) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) c[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s][nb], c[nb], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one wait, then the stores back to back
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ro = 16 * rb + lk + 4 * reg;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int n = 16 * nb + li;
+          if (ro < ns) {  // (wave-uniform per register only at multiples of 4 rows: the mask goes into the offset)
+            buf_store(ry, (n < kb) ? static_cast<unsigned>(((vbase + ro) * kb + n) * 8) : kBufOob, sg[reg] * c[nb][reg]);
+          } else {
+            const int64_t drow = (w.scratch != 0) ? vbase + ro : w.pvoff + di[reg];
+            buf_store(rv, (di[reg] >= 0 && n < kb) ? static_cast<unsigned>((drow * KB + n) * 8) : kBufOob, cg[reg][nb] - c[nb][reg]);
+          }
+        }
+      }
+    }
+    return;
+  }
   for (int rb = wave; rb < nrb; rb += WPF) {
     const int r = 16 * rb + li;  // the row this lane feeds as A operand
     // a block of 16 own rows meets only zeros of T past its diagonal block (T is lower triangular): those K-steps
@@ -2343,16 +2475,30 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
           return (v && *v) ? std::atoi(v) : 2;
         }();
         const double* thin_ft = (thin_rowm == 2 || (thin_rowm == 1 && leaf)) ? f->d_Ft : nullptr;
+        static const unsigned thin_lds = [] {  // occupancy probe: dynamic LDS the thin forward launches reserve (unused)
+          const char* v = std::getenv("EIGD_THIN_LDS");
+          return (v && *v) ? static_cast<unsigned>(std::atoi(v)) : 0u;
+        }();
+        // raw buffer accesses in the row blocks (EIGD_THIN_BUF=0: selected 64-bit addresses): planes and result block below 4 GB
+        static const bool thin_buf_env = [] {
+          const char* v = std::getenv("EIGD_THIN_BUF");
+          return (v && *v) ? std::atoi(v) != 0 : true;
+        }();
+        const bool thin_buf = thin_buf_env && f->v_rows * static_cast<int64_t>(KB) * 8 <= kBufMax &&
+                              static_cast<int64_t>(s.n) * ldin * 8 <= kBufMax;
 #define EIGD_THIN_FWD(NKS, NSLV)                                                                                        \
   do {                                                                                                                  \
     if (!fa.tri)                                                                                                        \
-      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, false>), dim3(nwave), dim3(64), 0, st, fa, recs, sF, sT, dIn, \
+      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, false>), dim3(nwave), dim3(64), thin_lds, st, fa, recs, sF, sT, dIn, \
                          ldin, alpha, wV, wY, kb, thin_ft);                                                             \
+    else if (one && thin_buf && thin_ft != nullptr)                                                                     \
+      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, true, true>), dim3(nwave), dim3(64), thin_lds, st, fa, recs, \
+                         sF, sT, dIn, ldin, alpha, wV, wY, kb, thin_ft);                                                \
     else if (one)                                                                                                       \
-      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, true>), dim3(nwave), dim3(64), 0, st, fa, recs, sF, sT, dIn,  \
+      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, true>), dim3(nwave), dim3(64), thin_lds, st, fa, recs, sF, sT, dIn,  \
                          ldin, alpha, wV, wY, kb, thin_ft);                                                             \
     else                                                                                                                \
-      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 2, true>), dim3(nwave), dim3(128), 0, st, fa, recs, sF, sT, dIn, \
+      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 2, true>), dim3(nwave), dim3(128), thin_lds, st, fa, recs, sF, sT, dIn, \
                          ldin, alpha, wV, wY, kb, thin_ft);                                                             \
   } while (0)
         if (leaf && nks == 4)
