@@ -48,7 +48,7 @@ constexpr int TLD = TW + 1;  // padded LDS leading dimension
 #define EIGD_THIN_WAVES_LEAF 3  // waves per SIMD asked of the 32-column buffer-access thin forward kernels: leaf fronts ...
 #endif
 #ifndef EIGD_THIN_WAVES_KIDS
-#define EIGD_THIN_WAVES_KIDS 3  // ... and fronts with two carry planes
+#define EIGD_THIN_WAVES_KIDS 1  // ... and fronts with two carry planes
 #endif
 constexpr int KBMAX = 32;    // right-hand sides per sweep
 
@@ -1591,7 +1591,7 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned off
 // Ftp and planes / result blocks below 4 GB: checked by the launcher): one 32-bit offset per access instead of a
 // selected 64-bit address, masked lanes out of range -- the registers that buys are a third wave per SIMD
 template <int KB, int NKS, int NSL, int WPF, bool TRI, bool BUF = false>
-__global__ __launch_bounds__(64 * WPF) __attribute__((amdgpu_waves_per_eu((BUF && KB == 32) ? (NSL == 0 ? EIGD_THIN_WAVES_LEAF : (NSL == 2 ? EIGD_THIN_WAVES_KIDS : 1)) : 1)))
+__global__ __launch_bounds__(64 * WPF) __attribute__((amdgpu_waves_per_eu((BUF && KB == 32) ? (NSL == 0 ? EIGD_THIN_WAVES_LEAF : ((NSL == 2 && NKS <= 8) ? EIGD_THIN_WAVES_KIDS : 1)) : 1)))
 void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
                                                        const double* __restrict__ F, const double* __restrict__ Tb,
                                                        const double* X, int ldx, double alpha, double* V,
@@ -1656,19 +1656,23 @@ void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
   for (int q = 0; q < 6; ++q)
     M[q] = (NSL > 0) ? *((mreg && 64 * q + lane < d) ? fa.cmask + vbase + 64 * q + lane : reinterpret_cast<const int*>(fa.zero)) : 0;
   if constexpr (BUF) {
-    // lane offsets are bytes inside the front's block of Ft (d x ns doubles, row-major), a plane of V or the block Y
+    // lane offsets are bytes inside the front's block of Fb (d x ns doubles), a plane of V or the block Y
     const __amdgpu_buffer_rsrc_t ra = buf_rsrc(Ftp + w.ftoff, static_cast<int64_t>(d) * ns * 8);
     const __amdgpu_buffer_rsrc_t ry = buf_rsrc(Y, (vbase + d) * kb * 8);
     const __amdgpu_buffer_rsrc_t rv = buf_rsrc(Vout, vslot * 8);
     for (int rb = wave; rb < nrb; rb += WPF) {
-      const int r = 16 * rb + li;
       const int smax = (TRI && 16 * rb + 16 <= ns) ? 4 * (rb + 1) : NKS;
-      // rows past the front are past the block (out of range: 0.0); entries past the row's ns columns belong to the
-      // next row and meet the zero rows of v1; K-steps past the diagonal block are not requested (offset out of range)
-      const unsigned aoff = static_cast<unsigned>(r * ns + lk) * 8u;
+      // K-steps past the diagonal block of T are not requested either (offset out of range: 0.0 without a memory access)
+      // (Ftp is the blocked copy Fb here: row block rb at 16 rb ns, column-major with `rows` rows -- the operand of
+      // K-step s is one contiguous piece of 4 x rows doubles, lanes past the block or the front's columns request nothing)
+      const int rows = min(16, d - 16 * rb);
+      const unsigned aoff = (li < rows) ? static_cast<unsigned>(16 * rb * ns + lk * rows + li) * 8u : 0x80000000u;
+      const int nkse = (ns + 3) >> 2, kend = min(smax, nkse);                   // (wave-uniform)
+      const unsigned aoffl = (4 * (nkse - 1) + lk < ns) ? aoff : 0x80000000u;  // the front's last K-step: its existing columns
       double a[NKS];
 #pragma unroll
-      for (int s = 0; s < NKS; ++s) a[s] = buf_load(ra, (s < smax ? aoff : 0x80000000u) + 32u * s);  // (a front's block is far below 2 GB)
+      for (int s = 0; s < NKS; ++s)  // (a front's block is far below 2 GB: the offsets stay out of range once they are)
+        a[s] = buf_load(ra, (s < kend) ? ((s == nkse - 1) ? aoffl : aoff) + static_cast<unsigned>(32 * s * rows) : 0x80000000u);
       int di[4];
       double sg[4], cg[4][NB];
 #pragma unroll
@@ -2056,7 +2060,8 @@ __global__ __launch_bounds__(64 * kSubWaves) void fwd_subtree_kernel(FrontArrays
 __global__ __launch_bounds__(kThreads) void transpose_front_kernel(FrontArrays fa, const int* __restrict__ tr_pref,
                                                                   int nfronts, const int64_t* __restrict__ ftoff,
                                                                   const double* __restrict__ F,
-                                                                  const double* __restrict__ Tb, double* __restrict__ Ft) {
+                                                                  const double* __restrict__ Tb, double* __restrict__ Ft,
+                                                                  double* __restrict__ Fb) {
   __shared__ double tile[TW][TW + 1];
   const int f = find_slot(tr_pref, nfronts, blockIdx.x);
   const int ns = fa.ns[f], d = ns + fa.bs[f];
@@ -2076,6 +2081,15 @@ __global__ __launch_bounds__(kThreads) void transpose_front_kernel(FrontArrays f
   for (int rr = q; rr < TW; rr += kThreads / TW) {  // coalesced along o
     const int gr = r0 + rr, go = o0 + r;
     if (gr < d && go < ns) Ft[ftoff[f] + static_cast<int64_t>(gr) * ns + go] = tile[rr][r];
+  }
+  // Fb: the same entries in blocks of 16 rows, a block stored column-major with its own row count as leading dimension
+  // (the last block of a front may have fewer than 16 rows): entry (r, o) at (r / 16) * 16 * ns + o * rows + r % 16
+  for (int oo = q; oo < TW; oo += kThreads / TW) {  // 16 consecutive lanes write one 128-byte piece
+    const int gr = r0 + r, go = o0 + oo;
+    if (gr < d && go < ns) {
+      const int rb = gr >> 4, rows = min(16, d - 16 * rb);
+      Fb[ftoff[f] + static_cast<int64_t>(rb) * 16 * ns + static_cast<int64_t>(go) * rows + (gr & 15)] = tile[r][oo];
+    }
   }
 }
 
@@ -2190,6 +2204,7 @@ struct eigd_factor {
   int64_t* d_ftoff = nullptr;
   int* d_tr_pref = nullptr;
   double* d_Ft = nullptr;
+  double* d_Fb = nullptr;  // [T; M21] in blocks of 16 rows, each block column-major (thin forward kernels: one contiguous piece per MFMA operand load)
   double *d_Fm = nullptr, *d_Bm = nullptr;  // fragment-major copies (fronts with several column tiles)
   FragFront* d_ff = nullptr;
   int* d_mt_pref = nullptr;
@@ -2313,7 +2328,7 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false, bool piv
   }
   if (f->n_tr > 0) {
     hipLaunchKernelGGL(transpose_front_kernel, dim3(f->n_tr), dim3(kThreads), 0, st, fa, f->d_tr_pref, s.nfronts, f->d_ftoff,
-                       f->d_F, f->d_T, f->d_Ft);
+                       f->d_F, f->d_T, f->d_Ft, f->d_Fb);
     EIGD_LAUNCH_CHECK();
     if (f->d_Pk != nullptr) {
       hipLaunchKernelGGL(pack_front_kernel, dim3(f->n_tr), dim3(kThreads), 0, st, fa, f->d_tr_pref, s.nfronts, f->d_pkoff,
@@ -2491,9 +2506,9 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     if (!fa.tri)                                                                                                        \
       hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, false>), dim3(nwave), dim3(64), thin_lds, st, fa, recs, sF, sT, dIn, \
                          ldin, alpha, wV, wY, kb, thin_ft);                                                             \
-    else if (one && thin_buf && thin_ft != nullptr)                                                                     \
+    else if (one && thin_buf && f->d_Fb != nullptr)                                                                    \
       hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, true, true>), dim3(nwave), dim3(64), thin_lds, st, fa, recs, \
-                         sF, sT, dIn, ldin, alpha, wV, wY, kb, thin_ft);                                                \
+                         sF, sT, dIn, ldin, alpha, wV, wY, kb, f->d_Fb);                                                \
     else if (one)                                                                                                       \
       hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, true>), dim3(nwave), dim3(64), thin_lds, st, fa, recs, sF, sT, dIn,  \
                          ldin, alpha, wV, wY, kb, thin_ft);                                                             \
@@ -2605,13 +2620,17 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
       if constexpr (KPT >= 4) {
         const WgRec* recs = f->d_wave_wg + f->h_wave_ptr[l];
         const int nks = f->h_thin_bwd[l];
+        static const unsigned thin_lds_b = [] {  // occupancy probe, as in the forward direction
+          const char* v = std::getenv("EIGD_THIN_LDS_BWD");
+          return (v && *v) ? static_cast<unsigned>(std::atoi(v)) : 0u;
+        }();
 #define EIGD_THIN_BWD(NOB, CHV)                                                                                   \
   do {                                                                                                            \
     if (fa.tri)                                                                                                   \
-      hipLaunchKernelGGL((bwd_thin_kernel<KB, NOB, CHV, true>), dim3(nwave), dim3(64), 0, st, fa, recs, f->d_Ft, wY, \
+      hipLaunchKernelGGL((bwd_thin_kernel<KB, NOB, CHV, true>), dim3(nwave), dim3(64), thin_lds_b, st, fa, recs, f->d_Ft, wY, \
                          dX, ldx, kb);                                                                            \
     else                                                                                                          \
-      hipLaunchKernelGGL((bwd_thin_kernel<KB, NOB, CHV, false>), dim3(nwave), dim3(64), 0, st, fa, recs, f->d_Ft, \
+      hipLaunchKernelGGL((bwd_thin_kernel<KB, NOB, CHV, false>), dim3(nwave), dim3(64), thin_lds_b, st, fa, recs, f->d_Ft, \
                          wY, dX, ldx, kb);                                                                        \
   } while (0)
         if (nks == 4)
@@ -2733,7 +2752,7 @@ int eigd_factor_free(eigd_factor* f) {
                   f->d_F,         f->d_Inv,         f->d_V,          f->d_Y,        f->d_flag,  f->d_fwd_wg,
                   f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_ov_dst,   f->d_ov_ptr, f->d_ov_src,
                   f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux,      f->d_bout,  f->d_tickets,
-                  f->d_P,         f->d_wave_wg,     f->d_ftoff,      f->d_tr_pref,  f->d_Ft,
+                  f->d_P,         f->d_wave_wg,     f->d_ftoff,      f->d_tr_pref,  f->d_Ft,  f->d_Fb,
                   f->d_Fm,        f->d_Bm,          f->d_ff,         f->d_mt_pref,
                   f->d_pkoff,     f->d_Pk,          f->d_sub_trees,  f->d_sub_fronts};
   for (void* p : ptrs)
@@ -2967,7 +2986,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   size_t free_b = 0, total_b = 0;
   EIGD_HIP(hipMemGetInfo(&free_b, &total_b));
   const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + toff[nf] +
-                                        (packed ? 2 : 1) * ftoff[nf] + fm_doubles + bm_doubles + (2 * nplanes + 1) * v_rows * KBMAX +
+                                        (packed ? 3 : 2) * ftoff[nf] + fm_doubles + bm_doubles + (2 * nplanes + 1) * v_rows * KBMAX +
                                         n_slabs * TW * KBMAX) +
                       16 * s.a_src.size() + (size_t(64) << 20);
   if (need > free_b) {
@@ -3220,6 +3239,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   rc = dmalloc(&f->d_T, static_cast<size_t>(f->t_doubles));
   rc = dmalloc(&f->d_aux, 2);
   rc = dmalloc(&f->d_Ft, static_cast<size_t>(f->ft_doubles));
+  rc = dmalloc(&f->d_Fb, static_cast<size_t>(f->ft_doubles));
   rc = dmalloc(&f->d_Fm, static_cast<size_t>(std::max<int64_t>(f->fm_doubles, 1)));
   rc = dmalloc(&f->d_Bm, static_cast<size_t>(std::max<int64_t>(f->bm_doubles, 1)));
   if (packed) rc = dmalloc(&f->d_Pk, static_cast<size_t>(std::max<int64_t>(pkoff[nf], 1)));
