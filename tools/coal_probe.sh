@@ -12,7 +12,7 @@ for v in ref exp ref exp; do
   timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/coal/p -- python3 tools/sweep_trace.py 32 > gpurun_out/coal/run_$v.log 2>&1 || { tail -5 gpurun_out/coal/run_$v.log; cp /tmp/lib_ref.so eigd_amd/lib/libeigd_hip.so; exit 1; }
   f=$(find gpurun_out/coal/p -name '*kernel_trace.csv' | head -1)
   echo "== $v" >> gpurun_out/coal/summary.txt
-  python3 tools/level_times.py $f 30 | grep -E "fwd_thin|sum" >> gpurun_out/coal/summary.txt
+  python3 tools/level_times.py $f 30 | grep -E "${PAT:-fwd_thin}|sum" >> gpurun_out/coal/summary.txt
   rm -rf gpurun_out/coal/p
 done
 cp /tmp/lib_ref.so eigd_amd/lib/libeigd_hip.so
