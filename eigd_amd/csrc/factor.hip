@@ -44,6 +44,9 @@ constexpr int TLD = TW + 1;  // padded LDS leading dimension
 #ifndef EIGD_FRAG_WAVES
 #define EIGD_FRAG_WAVES 3  // waves per SIMD the direct-fragment level kernels are compiled for
 #endif
+#ifndef EIGD_THIN_GUARD_ALL
+#define EIGD_THIN_GUARD_ALL 0  // 1: buffer-access thin forward kernels skip MFMAs on zero K-steps in every variant (measured: 161 instead of 128 registers, 197-205 against 190 us on the leaf launch)
+#endif
 #ifndef EIGD_THIN_WAVES_LEAF
 #define EIGD_THIN_WAVES_LEAF 3  // waves per SIMD asked of the 32-column buffer-access thin forward kernels: leaf fronts ...
 #endif
@@ -1723,10 +1726,12 @@ void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
       double4_t c[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) c[nb] = double4_t{0.0, 0.0, 0.0, 0.0};
-      const int kmax = (NKS <= 8) ? min(smax, (ns + 3) >> 2) : NKS;
+      // products with K-steps past the front's columns or past the diagonal block of T meet zeros: skipped (wave-uniform
+      // bound; EIGD_THIN_GUARD_ALL=0 at compile time: only in the variants of up to 8 K-steps, as in the selected-address kernels)
+      const int kmax = (NKS <= 8 || EIGD_THIN_GUARD_ALL) ? kend : NKS;
 #pragma unroll
       for (int s = 0; s < NKS; ++s)
-        if (NKS > 8 || s < kmax) {
+        if ((NKS > 8 && !EIGD_THIN_GUARD_ALL) || s < kmax) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) c[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s][nb], c[nb], 0, 0, 0);
         }
@@ -2516,7 +2521,26 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
       hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 2, true>), dim3(nwave), dim3(128), thin_lds, st, fa, recs, sF, sT, dIn, \
                          ldin, alpha, wV, wY, kb, thin_ft);                                                             \
   } while (0)
-        if (leaf && nks == 4)
+        if (!leaf && two && nks >= 12 && fa.tri && thin_buf && f->d_Fb != nullptr) {
+          // fronts of 33 to 64 own columns with carry planes: as many waves per front as give the level >= 2048 waves
+          const int wpf = (nwave >= 2048) ? 1 : (nwave >= 1024) ? 2 : 4;
+#define EIGD_THIN_FWD_W(NKS, WPFV)                                                                                      \
+  hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, 2, WPFV, true, true>), dim3(nwave), dim3(64 * WPFV), thin_lds, st, fa, recs, \
+                     sF, sT, dIn, ldin, alpha, wV, wY, kb, f->d_Fb)
+          if (nks == 12 && wpf == 1)
+            EIGD_THIN_FWD_W(12, 1);
+          else if (nks == 12 && wpf == 2)
+            EIGD_THIN_FWD_W(12, 2);
+          else if (nks == 12)
+            EIGD_THIN_FWD_W(12, 4);
+          else if (wpf == 1)
+            EIGD_THIN_FWD_W(16, 1);
+          else if (wpf == 2)
+            EIGD_THIN_FWD_W(16, 2);
+          else
+            EIGD_THIN_FWD_W(16, 4);
+#undef EIGD_THIN_FWD_W
+        } else if (leaf && nks == 4)
           EIGD_THIN_FWD(4, 0);
         else if (leaf && nks == 8)
           EIGD_THIN_FWD(8, 0);
@@ -3020,11 +3044,16 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     f->h_thin_fwd.assign(static_cast<size_t>(s.nlevels), 0);
     f->h_thin_bwd.assign(static_cast<size_t>(s.nlevels), 0);
     for (int l = 0; l < s.nlevels; ++l) {
-      const int nks = (mxns[l] <= 16) ? 4 : (mxns[l] <= 32) ? 8 : 16;
+      // (fronts with carry planes and 33 to 48 own columns: 12 K-steps -- the buffer-access kernels, several waves per front)
+      const int nks = (mxns[l] <= 16) ? 4 : (mxns[l] <= 32) ? 8 : (mxns[l] <= 48 && !f->h_lvl_leaf[l]) ? 12 : 16;
       // leaf level: K-steps of the forward kernel cut to the widest front (12 / 14 instead of 16: fewer MFMAs on zeros)
       const int nks_leaf = (mxns[l] > 32 && mxns[l] <= 48) ? 12 : (mxns[l] > 48 && mxns[l] <= 56) ? 14 : nks;
       // (with carries to gather, the 16-step forward variant needs 244 VGPRs: those levels stay with the tile kernels)
-      if (mxns[l] > 0 && mxns[l] <= (f->h_lvl_leaf[l] ? thin_fwd : std::min(thin_fwd, 32)))
+      // round 3: levels of binary fronts with up to EIGD_THIN_NS_FWD_KIDS (48) own columns go to the buffer-access thin
+      // kernels too, with two or four waves per front where the level has fewer than 2048 fronts (at C3 the two levels of
+      // 42-column fronts under the multi-tile ones: 61 + 44 us in the tile kernel)
+      const int kids_cap = f->h_lvl_two[l] ? std::max(32, env_int("EIGD_THIN_NS_FWD_KIDS", 48)) : 32;
+      if (mxns[l] > 0 && mxns[l] <= (f->h_lvl_leaf[l] ? thin_fwd : std::min(thin_fwd, kids_cap)))
         f->h_thin_fwd[l] = f->h_lvl_leaf[l] ? nks_leaf : nks;
       // (backward: one wave per front -- with more than 32 own columns only where the level has fronts enough to
       // fill the chip that way)
