@@ -1590,9 +1590,11 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned off
 // forward: wave = 16-row blocks rb, rb + 2, ... of [T; M21] (two waves per front).  K = own columns (NKS steps of 4).
 // WPF: waves per front (1: the right-hand side block is loaded once per front); TRI: T has lower triangular diagonal
 // blocks (Cholesky path) -- false on the Bunch-Kaufman path, whose diagonal blocks are dense
-// BUF: the row blocks' matrix operands, carries and results go through raw buffer accesses (needs the row-major copy
-// Ftp and planes / result blocks below 4 GB: checked by the launcher): one 32-bit offset per access instead of a
-// selected 64-bit address, masked lanes out of range -- the registers that buys are a third wave per SIMD
+// BUF: the right-hand sides, the row blocks' matrix operands, carries and results go through raw buffer accesses (planes
+// and the caller's block below 4 GB: checked by the launcher): one 32-bit offset per access instead of a selected 64-bit
+// address, masked lanes out of range -- the registers that buys are a third and fourth wave per SIMD.  Ftp is then the
+// copy Fb ([T; M21] in blocks of 16 rows, each block column-major: the operand of a K-step is one contiguous piece);
+// with WPF > 1 (levels of fewer than 2048 fronts) the waves of a workgroup share a front's row blocks
 template <int KB, int NKS, int NSL, int WPF, bool TRI, bool BUF = false>
 __global__ __launch_bounds__(64 * WPF) __attribute__((amdgpu_waves_per_eu((BUF && KB == 32) ? (NSL == 0 ? EIGD_THIN_WAVES_LEAF : ((NSL == 2 && NKS <= 8) ? EIGD_THIN_WAVES_KIDS : 1)) : 1)))
 void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
