@@ -3060,7 +3060,8 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
       // (backward: one wave per front -- with more than 32 own columns only where the level has fronts enough to
       // fill the chip that way)
       const int nfl = h_wave_ptr[l + 1] - h_wave_ptr[l];
-      if (mxns[l] > 0 && mxns[l] <= thin_bwd && mxbs[l] <= 320 && (nks < 16 || nfl >= 1024)) f->h_thin_bwd[l] = nks;
+      const int nks_b = (mxns[l] <= 16) ? 4 : (mxns[l] <= 32) ? 8 : 16;  // (the backward kernels know 4, 8 and 16 K-steps)
+      if (mxns[l] > 0 && mxns[l] <= thin_bwd && mxbs[l] <= 320 && (nks_b < 16 || nfl >= 1024)) f->h_thin_bwd[l] = nks_b;
     }
   }
   for (int q = 0; q < nf; ++q) {
