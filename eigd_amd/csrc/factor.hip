@@ -44,6 +44,9 @@ constexpr int TLD = TW + 1;  // padded LDS leading dimension
 #ifndef EIGD_FRAG_WAVES
 #define EIGD_FRAG_WAVES 3  // waves per SIMD the direct-fragment level kernels are compiled for
 #endif
+#ifndef EIGD_FRAG_WAVES_BWD32
+#define EIGD_FRAG_WAVES_BWD32 2  // ... the 32-column backward one: three waves spill four registers (168) and lose 3-6 % to two without spills (176)
+#endif
 #ifndef EIGD_THIN_GUARD_ALL
 #define EIGD_THIN_GUARD_ALL 0  // 1: buffer-access thin forward kernels skip MFMAs on zero K-steps in every variant (measured: 161 instead of 128 registers, 197-205 against 190 us on the leaf launch)
 #endif
@@ -1198,7 +1201,7 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
 // have already written (bout = their row numbers).  The solution goes straight to Out.
 // SINGLE: fronts with one column tile, LDS tiles of la.kd rows; FRAG: as in the forward kernel (Ft = the copy Bm then)
 template <int KPT, bool SINGLE, bool FRAG = false>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FRAG ? EIGD_FRAG_WAVES : 1)))
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FRAG ? (KPT >= 8 ? EIGD_FRAG_WAVES_BWD32 : EIGD_FRAG_WAVES) : 1)))
 void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
                                                             const double* __restrict__ Tb, const double* __restrict__ Ft,
                                                             const double* __restrict__ Y, double* Out, int ldo) {
