@@ -9,8 +9,9 @@ hot path.  Drop-in names (reference eigd/__init__.py:1-3 star-exports its module
 All arithmetic on n-vectors runs in hand-written HIP kernels (libeigd_hip.so, C ABI in
 include/eigd_hip.h).  There is no CPU fallback: without the library or a GPU the calls raise.
 """
-__version__ = "0.1.0"
+__version__ = "1.0.0"   # the reference's (eigd/__init__.py:1)
 
+from . import tuning  # noqa: F401
 from .adjoint import (  # noqa: F401
     add_eig_total_derivative,
     are_eigenvalues_repeated,

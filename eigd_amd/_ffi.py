@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libeigd_hip.so")
+# EIGD_LIB: another build of the shared object (development aid: bitwise comparison of two builds, tools/sweep_digest.py)
+LIB_PATH = os.environ.get("EIGD_LIB") or os.path.join(_HERE, "lib", "libeigd_hip.so")
 
 EIGD_E_INVALID, EIGD_E_HIP, EIGD_E_NOTSPD, EIGD_E_INTERNAL = -1, -2, -3, -4
 
@@ -102,6 +103,11 @@ _SIGNATURES = {
     "eigd_colnorm2_fetch": [c_vp, c_vp, c_int],
     "eigd_scale_inv_norm": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp],
     "eigd_copy_block": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
+    "eigd_cg_state_rows": [],
+    "eigd_cg_alpha": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp],
+    "eigd_cg_update": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp],
+    "eigd_cg_beta": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int],
+    "eigd_cg_direction": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_gather_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
     "eigd_scatter_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
     "eigd_elem_bilinear": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl,

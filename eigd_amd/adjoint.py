@@ -21,6 +21,7 @@ exactly as in the reference.
 
 import numpy as np
 
+from . import tuning
 from .operators import DeviceOperator, FactorApply, SpLuOperator
 
 MODES = ("normal", "buckling")
@@ -607,9 +608,6 @@ def solve_shifted_lstsq(alpha, H, r):
 from scipy.linalg.lapack import dgels as _dgels  # noqa: E402
 
 
-_REORTH_TOL = float(__import__("os").environ.get("EIGD_REORTH_TOL", "1e-13"))
-
-
 def _cgs2(Wst, T, ns, c0=0):
     """
     T <- (I - W W^T) T over the first ns slabs (columns c0.. of the stack); returns the coefficients.
@@ -626,11 +624,11 @@ def _cgs2(Wst, T, ns, c0=0):
         h2 = Wst.dot(T, ns=ns, c0=c0)
         n1 = np.sqrt(np.sum(h1 * h1, axis=0))
         n2 = np.sqrt(np.sum(h2 * h2, axis=0))
-        if not np.any(n2 > _REORTH_TOL * n1):
+        if not np.any(n2 > tuning.reorth_tol * n1):
             return h1
         Wst.axpy_into(T, h2, alpha=-1.0, c0=c0)
         return h1 + h2
-    return Wst.cgs2(T, ns, c0=c0, tol=_REORTH_TOL)[0]  # one call, one host synchronisation
+    return Wst.cgs2(T, ns, c0=c0, tol=tuning.reorth_tol)[0]  # one call, one host synchronisation
 
 
 def _active_range(done):
@@ -639,15 +637,7 @@ def _active_range(done):
     return int(live[0]), int(live[-1]) + 1
 
 
-def _compact_default():
-    import os
-
-    # off by default: measured on C3 (32 modes) the gathers of a repack cost what the narrower passes save (136 ms per
-    # step either way): late iterations are bound by the k-independent part (sweep latency, projections), not by bytes
-    return os.environ.get("EIGD_COMPACT", "0") == "1"
-
-
-def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist, compact=None):
+def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     """
     One attempt of the bs_target=1 solver for all columns of R0 at once.
     Returns (update block dpsi, converged flags, info list).
@@ -655,16 +645,9 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist, compa
     The modes advance in lock step; every operator application acts on the contiguous column
     range that still holds unfinished modes (the range shrinks as the low modes converge), so
     late iterations do not pay for finished columns.
-
-    Column compaction (``compact`` / EIGD_COMPACT=1, off by default): the Krylov histories are row-major n x k slabs, so
-    once most modes have finished a pass over the remaining columns still drags whole 128-byte lines of the finished
-    ones through HBM.  With compaction, whenever the live modes have dropped to half the slab width their columns of W,
-    Z and of the block in flight are gathered into stacks of that width and the iteration goes on there.  Pure data
-    movement: each column's arithmetic is unchanged (tested); measured gain at C3: none (see _compact_default).
     """
     ctx, mode = prob.ctx, prob.mode
     k = R0.k
-    compact = _compact_default() if compact is None else compact
     Kop = prob.opB if mode == "normal" else prob.opA  # Krylov operator P K factor (ref 1249-1252)
     sgn = 1.0 if mode == "normal" else -1.0            # ref 1265-1268
     info = [None] * k
@@ -757,24 +740,6 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist, compa
             with prob.fac.factor._count_lock:
                 prob.fac.factor.count += int(np.count_nonzero(~done))
         if nxt is not None:
-            live = np.flatnonzero(~done[cols])
-            if compact and len(cols) > 1 and 2 * len(live) <= len(cols):
-                # narrower stacks for the live modes: W[0..j], Z[0..j] (Z[j] and the block in flight are enqueued:
-                # stream order makes them visible to the gathers)
-                flush_finished(j)                        # finished columns leave with their share of the update
-                kc = len(live)
-                kw = 1 << max(kc - 1, 0).bit_length()     # stack widths 16, 8, 4, 2, 1: stable shapes for the workspace cache
-                Wn = ctx.workspace_stack(f"krylov_W/{kw}", maxiter + 1, prob.n, kw)
-                Zn = ctx.workspace_stack(f"krylov_Z/{kw}", maxiter, prob.n, kw)
-                Tn = ctx.empty(prob.n, kw)
-                for s_ in range(j + 1):
-                    W[s_].gather_cols_into(Wn[s_].cols(0, kc), live)
-                    Z[s_].gather_cols_into(Zn[s_].cols(0, kc), live)
-                T.gather_cols_into(Tn.cols(0, kc), live)
-                W, Z, T, cols = Wn, Zn, Tn, cols[live]
-                lo, hi = 0, kc
-                Ta = T.cols(0, kc)
-                continue
             # the step in flight keeps the range it was launched with; narrower ranges apply from the step after.
             # Columns that finished meanwhile are zeroed when the next basis vector is formed (scale above).
             nlo, nhi = _active_range(done[cols])
@@ -788,14 +753,6 @@ def _sibk_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist, compa
 
 
 LAST_ROUND = {"steps_per_pass": None, "inner_projections": None}   # what the last lock-step round of the two-step solver ran with (tests)
-
-
-def _sstep_default():
-    import os
-
-    # Krylov steps per Gram-Schmidt pass of the lock-step solver (2: _sibk_round_pair; 1: every step is orthogonalised
-    # before the next operator application, as the reference's loop is written)
-    return int(os.environ.get("EIGD_SSTEP", "2"))
 
 
 def pair_arnoldi_columns(Hc, Czc, j, h1, g1, b1, gamma, b2):
@@ -824,24 +781,6 @@ def pair_arnoldi_columns(Hc, Czc, j, h1, g1, b1, gamma, b2):
     Czc[:, j + 1] = 0.0
     Czc[j + 1, j + 1] = 1.0 / b1
     Czc[:ns, j + 1] -= (Czc[:ns, :ns] @ h1) / b1
-
-
-def _skip_inner_projections():
-    import os
-
-    # one projection of the raw pair in place of the two behind the operator applications (see
-    # _sibk_round_pair.enqueue_cycle).  Measured at C3: 87.8 against 87.9 ms per step with 32 columns (the 64-column
-    # projection of the pair costs what the two 32-column ones cost), 40.3 against 43.8 ms for the four modes of rank 7 of
-    # 8 (narrow blocks: a projection is the stream of Phi and B Phi whatever its width).  EIGD_INNER_PROJ=1: the reference's
-    # placement (1250-1252) whatever the measured invariance of range(P).
-    return os.environ.get("EIGD_INNER_PROJ", "0") != "1"
-
-
-def _pair_defect_tol():
-    import os
-
-    # w_{j+1} . w_{j+2} above which a two-step solve is abandoned for the one-step form (a test sets it to -1)
-    return float(os.environ.get("EIGD_SSTEP_DEFECT_TOL", "1e-10"))
 
 
 def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
@@ -926,7 +865,7 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
         prob.fac.apply_to(W[j].cols(lo, hi), Zj, count=0)
         Kop.apply(Zj, T1)
         if j == 0:
-            if _skip_inner_projections():
+            if not tuning.inner_projections:
                 _, Vp = prob._projector()
                 inner_proj[0] = not (np.max(np.abs(Vp.tdot(T1))) <= 1e-9)
             LAST_ROUND["inner_projections"] = inner_proj[0]
@@ -951,7 +890,7 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
             b1, b2 = np.sqrt(n1sq[q]), np.sqrt(n2sq[q])
             steps = (j + 1, j + 2)
             if b1 > 0.0:
-                if abs(defect[q]) > _pair_defect_tol() * max(b2, np.finfo(float).tiny):
+                if abs(defect[q]) > tuning.pair_defect_tol * max(b2, np.finfo(float).tiny):
                     ok = False                            # (never seen: the pair was not orthogonalised well enough)
             else:
                 steps = (j + 1,)                          # breakdown: the Krylov space is exhausted at step j+1
@@ -992,7 +931,7 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
         TPv = TP.cols(0, 2 * kk)
         if not inner_proj[0] and j > 0:
             prob.project_r(TPv)                                       # ref 1250-1252 for both vectors of the cycle at once
-        h, npass = W.cgs2_pair(TPv, j + 1, c0=lo, tol=_REORTH_TOL)  # ref 1254-1256 for both vectors; one host sync
+        h, npass = W.cgs2_pair(TPv, j + 1, c0=lo, tol=tuning.reorth_tol)  # ref 1254-1256 for both vectors; one host sync
         LAST_ROUND["gs_cycles"] = LAST_ROUND.get("gs_cycles", 0) + 1
         LAST_ROUND["gs_correcting_passes"] = LAST_ROUND.get("gs_correcting_passes", 0) + (npass - (2 if j + 1 <= 32 else 3))
         n2 = prob.project_r_norm2(TPv)                                # ref 1257 + 1259
@@ -1005,7 +944,7 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
             tol_c = max(rtol * rnorm0, atol)
             in_cycle = np.zeros(k, dtype=bool)
             in_cycle[lo:hi] = True                        # (their steps j+1, j+2 are the ones being solved)
-            if _PREDICT_FINISH and j > 0:
+            if tuning.predict_finish and j > 0:
                 stay_lax = ~done & ~_expected_to_finish(hist, done, in_cycle, tol_c, 4.0)
                 stay = ~done & ~_expected_to_finish(hist, done, in_cycle, tol_c, 0.5)
             else:
@@ -1053,7 +992,149 @@ def _sibk_round_pair(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxiter, hist):
     return dpsi, converged, info, ok
 
 
-_PREDICT_FINISH = __import__("os").environ.get("EIGD_PREDICT_FINISH", "1") != "0"
+# ---------------------------------------------------------------------------
+# sibk in short-recurrence form: conjugate gradients in the inner product of the factor (csrc/krylov.hip)
+# ---------------------------------------------------------------------------
+def _short_recurrence_applies(prob):
+    """a native, positive definite, real factor: no negative or static pivots (the shift lies below the spectrum)"""
+    fac = prob.fac
+    if tuning.recurrence == "arnoldi" or fac is None or not fac.native:
+        return False
+    op = fac.factor
+    return not op._pivoted() and op._imag_dev is None and prob.opA.csr is not None and prob.opB.csr is not None
+
+
+_CG_ROWS = {"rho": 0, "a": 1, "b": 2, "done": 3, "tol2": 4, "alpha": 5, "steps": 6, "flag": 7, "den": 8}
+
+
+def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
+    """
+    All columns of R0 (at most 64) by conjugate gradients in the factor inner product, in lock step.  Same Krylov spaces
+    as the Arnoldi form (reference 1246-1277), same stopping rule on the true Euclidean residual (1275), no Krylov
+    history: per step ONE multi-column sweep, one SpMM, one measured projection and four streaming passes over the work
+    blocks; every per-mode scalar stays on the device (krylov.hip), the host reads the residual norms of a step behind
+    the next sweep already in flight.  Returns (update block, converged flags, info list, ok); ok False = a breakdown was
+    flagged (the operator was not positive definite in the deflated space): the caller redoes the solve in the Arnoldi form.
+    """
+    from . import _ffi
+    from ._ffi import call
+
+    ctx, mode = prob.ctx, prob.mode
+    n, k = prob.n, R0.k
+    assert k <= 64
+    Kop = prob.opB if mode == "normal" else prob.opA      # Krylov operator P K factor (ref 1249-1252)
+    sgn = 1.0 if mode == "normal" else -1.0                # ref 1265-1268
+    nrows = int(_ffi.lib().eigd_cg_state_rows())
+    tol = max(rtol * rnorm0, atol)
+    tol2 = tol * tol
+    info = [None] * k
+    done = np.zeros(k, dtype=bool)
+    converged = np.zeros(k, dtype=bool)
+    beta0 = R0.coldot(R0)
+    for c in range(k):
+        hist[c].append(float(np.sqrt(beta0[c])))
+        if beta0[c] < tol2:                                # ref 1223-1225
+            info[c] = 0
+            done[c] = converged[c] = True
+    psi = ctx.zeros(n, k)
+    if done.all():
+        return psi, converged, info, True
+    st_h = np.zeros((nrows, 64))
+    st_h[_CG_ROWS["done"], :k] = done
+    st_h[_CG_ROWS["tol2"], :k] = tol2
+    st_h[_CG_ROWS["alpha"], :k] = sgn * (np.asarray(lam_c, dtype=float) - sigma)   # ref 1264-1269
+    state = ctx.from_host(st_h)
+    r = ctx.empty(n, k).copy_from(R0)
+    zr, p, zp, y = ctx.empty(n, k), ctx.zeros(n, k), ctx.zeros(n, k), ctx.empty(n, k)
+
+    def v(block, lo, hi):
+        return block.cols(lo, hi)
+
+    def sptr(lo):
+        return state.cols(lo, 64).ptr
+
+    def second_half(j, lo, hi, n2, first):
+        """sweep of the residual, rho and b, new directions (no synchronisation)"""
+        kk = hi - lo
+        rv, zrv = v(r, lo, hi), v(zr, lo, hi)
+        prob.fac.apply_to(rv, zrv, count=0)               # ref 1248
+        call("eigd_cg_beta", ctx.h, n, kk, rv.ptr, rv.ld, zrv.ptr, zrv.ld, n2.ptr if n2 is not None else None, sptr(lo), int(j),
+             1 if first else 0)
+        pv, zpv = v(p, lo, hi), v(zp, lo, hi)
+        call("eigd_cg_direction", ctx.h, n, kk, pv.ptr, pv.ld, zpv.ptr, zpv.ld, rv.ptr, rv.ld, zrv.ptr, zrv.ld, sptr(lo),
+             1 if first else 0)
+
+    lo, hi = _active_range(done)
+    prob.project_r_norm2(v(r, lo, hi))                    # ref 1232 (the caller projected already, 1193: measured)
+    ctx.fetch_colnorm2(hi - lo)
+    second_half(0, lo, hi, None, True)
+    nsteps = 0
+    for j in range(1, maxsteps + 1):
+        lo, hi = _active_range(done)
+        kk = hi - lo
+        zpv, pv, yv, rv = v(zp, lo, hi), v(p, lo, hi), v(y, lo, hi), v(r, lo, hi)
+        Kop.apply(zpv, yv)                                # ref 1250 / 1252
+        call("eigd_cg_alpha", ctx.h, n, kk, zpv.ptr, zpv.ld, pv.ptr, pv.ld, yv.ptr, yv.ld, sptr(lo))
+        psv = v(psi, lo, hi)
+        call("eigd_cg_update", ctx.h, n, kk, psv.ptr, psv.ld, rv.ptr, rv.ld, zpv.ptr, zpv.ld, pv.ptr, pv.ld, yv.ptr, yv.ld,
+             sptr(lo))
+        n2 = prob.project_r_norm2(rv)                     # ref 1257 + the residual norm of 1275; measured update
+        nsteps = j
+        # the sweep of this step's residual is only needed if some mode goes on: when every live mode is expected to
+        # finish with this step (its last reduction applied once more, generous margin) the host looks first
+        live = np.flatnonzero(~done)
+        expect_all = tuning.predict_finish and j > 1 and all(
+            len(hist[c]) >= 2 and hist[c][-2] > 0.0 and hist[c][-1] * min(hist[c][-1] / hist[c][-2], 1.0) < 0.25 * tol
+            for c in live)
+        in_flight = False
+        if j < maxsteps and not expect_all:
+            second_half(j, lo, hi, n2, False)
+            in_flight = True
+        norms2 = ctx.fetch_colnorm2(kk)
+        for c in range(lo, hi):
+            if done[c]:
+                continue
+            hist[c].append(float(np.sqrt(max(norms2[c - lo], 0.0))))
+            if norms2[c - lo] < tol2:                     # ref 1275 (the comparison the device makes in eigd_cg_beta)
+                info[c] = j
+                done[c] = converged[c] = True
+        if done.all() or j == maxsteps:
+            LAST_ROUND["cg_sweeps_for_nothing"] = LAST_ROUND.get("cg_sweeps_for_nothing", 0) + int(in_flight)
+            break
+        if not in_flight:
+            LAST_ROUND["cg_waited_for"] = LAST_ROUND.get("cg_waited_for", 0) + 1
+            second_half(j, lo, hi, n2, False)
+    st = state.get()
+    ok = not np.any(st[_CG_ROWS["flag"], :k] != 0.0) and bool(np.all(np.isfinite(st[_CG_ROWS["rho"], :k])))
+    if prob.fac.native and ok:                            # one factor application per step and mode (ref 1248)
+        with prob.fac.factor._count_lock:
+            prob.fac.factor.count += int(sum((i if i is not None else nsteps) for i in info))
+    measured, applied = ctx.project_stats()
+    LAST_ROUND["cg_steps"] = LAST_ROUND.get("cg_steps", 0) + nsteps
+    LAST_ROUND["cg_projections"] = LAST_ROUND.get("cg_projections", 0) + measured
+    LAST_ROUND["cg_projection_updates"] = LAST_ROUND.get("cg_projection_updates", 0) + applied
+    return psi, converged, info, ok
+
+
+def _sibk_cg(prob, R, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
+    """the short-recurrence solver over all columns of R, 64 at a time; (update, converged, info, ok)"""
+    k = R.k
+    upd = prob.ctx.zeros(prob.n, k) if k > 64 else None
+    conv, info, ok = np.zeros(k, dtype=bool), [None] * k, True
+    for a in range(0, k, 64):
+        b = min(k, a + 64)
+        ua, ca, ia, oka = _sibk_cg_round(prob, R.cols(a, b) if k > 64 else R, lam_c[a:b], sigma, rnorm0, rtol, atol, maxsteps,
+                                         hist[a:b])
+        if k > 64:
+            upd.cols(a, b).copy_from(ua)
+        else:
+            upd = ua
+        conv[a:b] = ca
+        info[a:b] = ia
+        ok = ok and oka
+        if not ok:
+            break
+    return upd, conv, info, ok
 
 
 def _expected_to_finish(hist, done, in_cycle, tol, margin):
@@ -1096,7 +1177,7 @@ def _run_groups(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist, s
         # Gram-Schmidt kernels (60 KB of LDS): deeper histories (maxiter > 120 at 32 columns) take the one-step form,
         # whose Gram-Schmidt goes pass by pass beyond that depth
         fits = maxiter * 2 * min(k, 32) * 8 <= 60 * 1024
-        if _sstep_default() == 2 and fits:
+        if tuning.steps_per_pass == 2 and fits:
             keep = [list(hh) for hh in sub_hist]
             if 2 * k <= 64:
                 upd, conv, inf, ok = _sibk_round_pair(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist)
@@ -1125,10 +1206,7 @@ def _run_groups(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist, s
         return _sibk_round(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist)
     import threading
 
-    if __import__("os").environ.get("EIGD_STREAM_SPLIT", "cyclic") == "block":
-        parts = [np.asarray(a) for a in np.array_split(np.arange(k), groups)]
-    else:
-        parts = [np.arange(g, k, groups) for g in range(groups)]
+    parts = [np.arange(g, k, groups) for g in range(groups)]
     Rg = [Rc.gather_cols(part) for part in parts]
     prob.ctx.sync()
     out = [None] * groups
@@ -1143,7 +1221,7 @@ def _run_groups(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist, s
             hg = [sub_hist[c] for c in parts[g]]
             kg = len(parts[g])
             res = None
-            if _sstep_default() == 2 and 2 * kg <= 64 and maxiter * 2 * min(kg, 32) * 8 <= 60 * 1024:
+            if tuning.steps_per_pass == 2 and 2 * kg <= 64 and maxiter * 2 * min(kg, 32) * 8 <= 60 * 1024:
                 keep = [list(hh) for hh in hg]
                 ug, cg, ig, okg = _sibk_round_pair(pg, R0, lam_p[parts[g]], sigma, rnorm0, rtol, atol, maxiter, hg)
                 if okg:
@@ -1190,6 +1268,18 @@ def _sibk_device(prob, dPhib, dpsi, lam_c, sigma, rtol, atol, maxiter, nrestart,
     prob.project_r(R)                                    # ref 1193
     hist = [[] for _ in range(k)]
     info = [None] * k
+    LAST_ROUND["recurrence"] = "arnoldi"
+    if streams == 1 and _short_recurrence_applies(prob):
+        # positive definite shift: conjugate gradients in the factor inner product (same spaces, no history); as many
+        # steps as the reference's restarted loop may take in all (1312-1321)
+        upd, conv, inf, ok = _sibk_cg(prob, R, lam_c, sigma, rnorm0, rtol, atol, maxiter * (nrestart + 1), hist)
+        if ok:
+            LAST_ROUND["recurrence"] = "short"
+            dpsi.assign_lincomb([(1.0, dpsi), (1.0, upd)])
+            _emit(callback, hist, range(k))
+            return [i for i in inf if i is not None]
+        LAST_ROUND["recurrence"] = "arnoldi (the short recurrence broke down)"
+        hist = [[] for _ in range(k)]
     pending = np.arange(k)
     for attempt in range(nrestart + 1):                  # ref 1312-1321: restarts reuse the same residual
         Rc = R if len(pending) == k else R.gather_cols(pending)

@@ -961,19 +961,11 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
     if (dres) *dres = res;
     return EIGD_OK;
   }
-  static const bool staged_tn = [] {  // EIGD_TN_STAGED=0: wide results through the direct form too
-    const char* v = std::getenv("EIGD_TN_STAGED");
-    return (v && *v) ? std::atoi(v) != 0 : true;
-  }();
   // few tiles (narrow X): the direct form, whose waves share the rows of a tile -- measured against the staged form at
-  // 64 x 8: 137 against 165 us per call (EIGD_TN_STAGED_MIN: widest row-major U that still takes the direct form then;
-  // default 64 = always)
-  static const int staged_min = [] {
-    const char* v = std::getenv("EIGD_TN_STAGED_MIN");
-    return (v && *v) ? std::atoi(v) : 64;
-  }();
+  // 64 x 8: 137 against 165 us per call; wide results from a row-major U: staged through LDS
+  constexpr bool staged_tn = true;
   const bool few = ((ku + 15) / 16) * ((kx + 15) / 16) <= 4;
-  if (few && !(csu == 1 && staged_tn && ku > staged_min))
+  if (few)
     hipLaunchKernelGGL(gemm_tn_kernel<1>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, csu, dX, ldx,
                        partial);
   else if (csu == 1 && staged_tn)
@@ -1092,15 +1084,12 @@ int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, i
   // The projection behind a Gram-Schmidt step (reference 1257) meets a block that is already B-orthogonal to Phi up to
   // rounding: the vectors it was built from were projected before.  Whether the update X -= U (V^T X) matters is
   // MEASURED: the coefficient pass delivers the squared column norms of X as well, a one-workgroup kernel compares
-  // every coefficient with tol * |x_b| / uscale (EIGD_PROJ_SKIP_TOL, default 1e-13; 0: always update; uscale = the
+  // every coefficient with tol * |x_b| / uscale (tol = 1e-13; uscale = the
   // largest Euclidean column norm of U, so that what is compared is the size of the update |u_a| |c_ab| against |x_b|
   // whatever the scale of the inner product), and the update pass -- the stream of U and two passes over X -- returns
   // at once when none does; the norms of the pass already made are then the result.
-  static const double skip_tol = [] {
-    const char* v = std::getenv("EIGD_PROJ_SKIP_TOL");
-    return (v && *v) ? std::atof(v) : 1e-13;
-  }();
-  const bool measured = skip_tol > 0.0;
+  constexpr double skip_tol = 1e-13;
+  constexpr bool measured = true;
   // scratch: [C tile (<= kMaxK x kx)] [partials of C, later the partial squared norms]
   const int nbd = grid_for_rows(n, 64);
   int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(kMaxK) * kx + static_cast<size_t>(nbd) * kx));

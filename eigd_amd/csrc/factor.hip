@@ -38,24 +38,11 @@ namespace eigd {
 
 constexpr int TW = 64;       // tile edge == max panel width == row chunk
 constexpr int TLD = TW + 1;  // padded LDS leading dimension
-#ifndef EIGD_FRAG_WAVES_FWD
-#define EIGD_FRAG_WAVES_FWD 2  // (32 columns, forward: 168 registers would spill)
-#endif
-#ifndef EIGD_FRAG_WAVES
-#define EIGD_FRAG_WAVES 3  // waves per SIMD the direct-fragment level kernels are compiled for
-#endif
-#ifndef EIGD_FRAG_WAVES_BWD32
-#define EIGD_FRAG_WAVES_BWD32 2  // ... the 32-column backward one: three waves spill four registers (168) and lose 3-6 % to two without spills (176)
-#endif
-#ifndef EIGD_THIN_GUARD_ALL
-#define EIGD_THIN_GUARD_ALL 0  // 1: buffer-access thin forward kernels skip MFMAs on zero K-steps in every variant (measured: 161 instead of 128 registers, 197-205 against 190 us on the leaf launch)
-#endif
-#ifndef EIGD_THIN_WAVES_LEAF
-#define EIGD_THIN_WAVES_LEAF 3  // waves per SIMD asked of the 32-column buffer-access thin forward kernels: leaf fronts ...
-#endif
-#ifndef EIGD_THIN_WAVES_KIDS
-#define EIGD_THIN_WAVES_KIDS 1  // ... and fronts with two carry planes
-#endif
+// waves per SIMD the kernels are compiled for (measured, docs/LOG.md): the 32-column forward fragment kernel would spill at
+// 168 registers (2), the other fragment kernels run three; the 32-column backward one loses 3-6 % at three (four spilled
+// registers) to two without spills; the 32-column buffer-access thin forward kernels: leaf fronts 3, fronts with two
+// carry planes 1
+constexpr int kFragWavesFwd = 2, kFragWaves = 3, kFragWavesBwd32 = 2, kThinWavesLeaf = 3, kThinWavesKids = 1;
 constexpr int KBMAX = 32;    // right-hand sides per sweep
 
 struct FrontArrays {
@@ -747,7 +734,7 @@ struct WgRec {
   int64_t pvoff;         // the parent's first row in V, -1 for a root
   int64_t scratch;       // 1: surplus child (slot >= kMaxS): its carry goes to the scratch plane, at its own border rows
   int64_t ftoff;         // the front's block in the transposed copy Ft
-  int64_t ldt;           // leading dimension of T as the sweeps read it: d in the packed panel
+  int64_t ldt;           // leading dimension of T as the sweeps read it (ns)
   int64_t moff;          // fronts with several column tiles: first tile of this record's chain in the fragment-major copy
 };
 
@@ -867,8 +854,8 @@ __device__ __forceinline__ bool fold_groups(const WgRec& w, const LevelArgs& la,
 // around the load would serialise the loads of a tile.
 // NSL: carry planes compiled in (2: binary trees, else kMaxS + 1); FRAG (fronts with several column tiles, MFMA widths):
 // matrix operands straight from the fragment-major copy instead of staged through LDS
-template <int KPT, bool SINGLE, bool DEEP, int NSL, bool FRAG = false>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(((SINGLE && (KPT == 4 || (KPT == 8 && !DEEP))) || (FRAG && KPT >= 4)) ? ((FRAG && KPT >= 8) ? EIGD_FRAG_WAVES_FWD : 3) : 1)))
+template <int KPT, bool SINGLE, int NSL, bool FRAG = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(((SINGLE && KPT >= 4) || (FRAG && KPT >= 4)) ? ((FRAG && KPT >= 8) ? kFragWavesFwd : 3) : 1)))
 void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
                                                             const double* __restrict__ Tb, const double* X, int ldx,
                                                             double alpha, double* V, double* __restrict__ Y) {
@@ -1096,18 +1083,8 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
     fetch_idx(0);
     fetch_b(0);
     fetch_a(w.s0, 0, av);
-    if constexpr (DEEP) {  // two matrix tiles in flight
-      double av2[TILE_IT];
-      if (w.s0 + 1 < w.s1) fetch_a(w.s0 + 1, 0, av2);
-      commit_b();
-      for (int rt = w.s0; rt < w.s1; rt += 2) {
-        step(rt, av, rt + 2);
-        if (rt + 1 < w.s1) step(rt + 1, av2, rt + 3);
-      }
-    } else {
-      commit_b();
-      for (int rt = w.s0; rt < w.s1; ++rt) step(rt, av, rt + 1);
-    }
+    commit_b();
+    for (int rt = w.s0; rt < w.s1; ++rt) step(rt, av, rt + 1);
   } else if constexpr (FRAG) {
     static_assert(!FRAG || T::kMfma, "fragments feed MFMAs");
     // Several column tiles, MFMA path: the chain over the column tiles with the matrix operands loaded from global
@@ -1201,7 +1178,7 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
 // have already written (bout = their row numbers).  The solution goes straight to Out.
 // SINGLE: fronts with one column tile, LDS tiles of la.kd rows; FRAG: as in the forward kernel (Ft = the copy Bm then)
 template <int KPT, bool SINGLE, bool FRAG = false>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FRAG ? (KPT >= 8 ? EIGD_FRAG_WAVES_BWD32 : EIGD_FRAG_WAVES) : 1)))
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FRAG ? (KPT >= 8 ? kFragWavesBwd32 : kFragWaves) : 1)))
 void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
                                                             const double* __restrict__ Tb, const double* __restrict__ Ft,
                                                             const double* __restrict__ Y, double* Out, int ldo) {
@@ -1590,20 +1567,19 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned off
 // memory straight into the operand layout (lane (i, k) of v_mfma_f64_16x16x4: A[i][k] and B[k][i]), everything a
 // wave needs is requested in one or two rounds, and 12 to 16 waves per CU are in flight.
 //
-// forward: wave = 16-row blocks rb, rb + 2, ... of [T; M21] (two waves per front).  K = own columns (NKS steps of 4).
-// WPF: waves per front (1: the right-hand side block is loaded once per front); TRI: T has lower triangular diagonal
-// blocks (Cholesky path) -- false on the Bunch-Kaufman path, whose diagonal blocks are dense
-// BUF: the right-hand sides, the row blocks' matrix operands, carries and results go through raw buffer accesses (planes
-// and the caller's block below 4 GB: checked by the launcher): one 32-bit offset per access instead of a selected 64-bit
-// address, masked lanes out of range -- the registers that buys are a third and fourth wave per SIMD.  Ftp is then the
-// copy Fb ([T; M21] in blocks of 16 rows, each block column-major: the operand of a K-step is one contiguous piece);
-// with WPF > 1 (levels of fewer than 2048 fronts) the waves of a workgroup share a front's row blocks
-template <int KB, int NKS, int NSL, int WPF, bool TRI, bool BUF = false>
-__global__ __launch_bounds__(64 * WPF) __attribute__((amdgpu_waves_per_eu((BUF && KB == 32) ? (NSL == 0 ? EIGD_THIN_WAVES_LEAF : ((NSL == 2 && NKS <= 8) ? EIGD_THIN_WAVES_KIDS : 1)) : 1)))
-void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
-                                                       const double* __restrict__ F, const double* __restrict__ Tb,
-                                                       const double* X, int ldx, double alpha, double* V,
-                                                       double* __restrict__ Y, int kb, const double* __restrict__ Ftp) {
+// forward: wave = 16-row blocks rb, rb + WPF, ... of [T; M21].  K = own columns (NKS steps of 4).
+// WPF: waves per front (1: the right-hand side block is loaded once per front; more on levels of fewer than 2048 fronts:
+// the waves of a workgroup share a front's row blocks); TRI: T has lower triangular diagonal blocks (Cholesky path) --
+// false on the Bunch-Kaufman path, whose diagonal blocks are dense.
+// The right-hand sides, the row blocks' matrix operands, carries and results go through raw buffer accesses (planes and
+// the caller's block below 4 GB: checked by the launcher, which sends larger problems to the tile kernels): one 32-bit
+// offset per access instead of a selected 64-bit address, masked lanes out of range -- the registers that buys are a
+// third and fourth wave per SIMD.  Fb is [T; M21] in blocks of 16 rows, each block column-major: the operand of a
+// K-step is one contiguous piece.
+template <int KB, int NKS, int NSL, int WPF, bool TRI>
+__global__ __launch_bounds__(64 * WPF) __attribute__((amdgpu_waves_per_eu((KB == 32) ? (NSL == 0 ? kThinWavesLeaf : ((NSL == 2 && NKS <= 8) ? kThinWavesKids : 1)) : 1)))
+void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs, const double* X, int ldx, double alpha, double* V,
+                     double* __restrict__ Y, int kb, const double* __restrict__ Fb) {
   constexpr int NB = KB / 16;
   const WgRec w = recs[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1620,7 +1596,7 @@ void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
       xi[s] = *((4 * s + lk < ns) ? fa.v_src + vbase + 4 * s + lk : fa.neg1);
       mo[s] = (NSL > 0) ? *((4 * s + lk < ns && nslot > 0) ? fa.cmask + vbase + 4 * s + lk : reinterpret_cast<const int*>(fa.zero)) : 0;
     }
-    if constexpr (BUF) {  // (the launcher has checked that the caller's block and a plane stay below 4 GB)
+    {  // (the launcher has checked that the caller's block and a plane stay below 4 GB)
       const __amdgpu_buffer_rsrc_t rx = buf_rsrc(X, kBufMax);
 #pragma unroll
       for (int s = 0; s < NKS; ++s)
@@ -1636,25 +1612,9 @@ void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
             v += buf_load(buf_rsrc(V + sl * vslot, vslot * 8), (ok && ((mo[s] >> sl) & 1)) ? coff : kBufOob);
           b[s][nb] = xv + v;
         }
-    } else {
-#pragma unroll
-    for (int s = 0; s < NKS; ++s)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int o = 4 * s + lk, n = 16 * nb + li;
-        const bool ok = xi[s] >= 0 && n < kb;
-        const double xv = alpha * *(ok ? X + static_cast<int64_t>(xi[s]) * ldx + n : fa.zero);
-        const double* cp = V + (vbase + o) * KB + n;
-        double v = 0.0;
-#pragma unroll
-        for (int sl = 0; sl < NSL; ++sl) v += *((ok && ((mo[s] >> sl) & 1)) ? cp + sl * vslot : fa.zero);
-        b[s][nb] = xv + v;
-      }
     }
   }
   double* Vout = V + static_cast<int64_t>(w.slot) * vslot;
-  const double* Tf = Tb + w.toff;
-  const double* Ff = F + w.foff;
   const int nrb = (d + 15) >> 4;
   // the plane masks of all rows, lane by lane (fronts of up to 384 rows): read with ds_bpermute in the row blocks, so
   // that their carry loads do not wait for a mask load of their own
@@ -1663,15 +1623,15 @@ void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
 #pragma unroll
   for (int q = 0; q < 6; ++q)
     M[q] = (NSL > 0) ? *((mreg && 64 * q + lane < d) ? fa.cmask + vbase + 64 * q + lane : reinterpret_cast<const int*>(fa.zero)) : 0;
-  if constexpr (BUF) {
+  {
     // lane offsets are bytes inside the front's block of Fb (d x ns doubles), a plane of V or the block Y
-    const __amdgpu_buffer_rsrc_t ra = buf_rsrc(Ftp + w.ftoff, static_cast<int64_t>(d) * ns * 8);
+    const __amdgpu_buffer_rsrc_t ra = buf_rsrc(Fb + w.ftoff, static_cast<int64_t>(d) * ns * 8);
     const __amdgpu_buffer_rsrc_t ry = buf_rsrc(Y, (vbase + d) * kb * 8);
     const __amdgpu_buffer_rsrc_t rv = buf_rsrc(Vout, vslot * 8);
     for (int rb = wave; rb < nrb; rb += WPF) {
       const int smax = (TRI && 16 * rb + 16 <= ns) ? 4 * (rb + 1) : NKS;
       // K-steps past the diagonal block of T are not requested either (offset out of range: 0.0 without a memory access)
-      // (Ftp is the blocked copy Fb here: row block rb at 16 rb ns, column-major with `rows` rows -- the operand of
+      // (row block rb of Fb at 16 rb ns, column-major with `rows` rows -- the operand of
       // K-step s is one contiguous piece of 4 x rows doubles, lanes past the block or the front's columns request nothing)
       const int rows = min(16, d - 16 * rb);
       const unsigned aoff = (li < rows) ? static_cast<unsigned>(16 * rb * ns + lk * rows + li) * 8u : 0x80000000u;
@@ -1732,11 +1692,11 @@ void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) c[nb] = double4_t{0.0, 0.0, 0.0, 0.0};
       // products with K-steps past the front's columns or past the diagonal block of T meet zeros: skipped (wave-uniform
-      // bound; EIGD_THIN_GUARD_ALL=0 at compile time: only in the variants of up to 8 K-steps, as in the selected-address kernels)
-      const int kmax = (NKS <= 8 || EIGD_THIN_GUARD_ALL) ? kend : NKS;
+      // bound; only in the variants of up to 8 K-steps: guarding all costs 33 registers, 197-205 against 190 us on the leaf launch)
+      const int kmax = (NKS <= 8) ? kend : NKS;
 #pragma unroll
       for (int s = 0; s < NKS; ++s)
-        if ((NKS > 8 && !EIGD_THIN_GUARD_ALL) || s < kmax) {
+        if (NKS > 8 || s < kmax) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) c[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s][nb], c[nb], 0, 0, 0);
         }
@@ -1753,86 +1713,6 @@ void fwd_thin_kernel(FrontArrays fa, const WgRec* __restrict__ recs,
             const int64_t drow = (w.scratch != 0) ? vbase + ro : w.pvoff + di[reg];
             buf_store(rv, (di[reg] >= 0 && n < kb) ? static_cast<unsigned>((drow * KB + n) * 8) : kBufOob, cg[reg][nb] - c[nb][reg]);
           }
-        }
-      }
-    }
-    return;
-  }
-  for (int rb = wave; rb < nrb; rb += WPF) {
-    const int r = 16 * rb + li;  // the row this lane feeds as A operand
-    // a block of 16 own rows meets only zeros of T past its diagonal block (T is lower triangular): those K-steps
-    // read the zero word instead of streaming zeros from HBM (wave-uniform bound)
-    const int smax = (TRI && 16 * rb + 16 <= ns) ? 4 * (rb + 1) : NKS;
-    double a[NKS];
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      const int o = 4 * s + lk;
-      // (Ftp: the row-major copy Ft -- a block of 16 rows is one contiguous piece of memory there)
-      const double* p = Ftp ? Ftp + w.ftoff + static_cast<int64_t>(r) * ns + o
-                            : (r < ns) ? Tf + static_cast<int64_t>(o) * w.ldt + r : Ff + static_cast<int64_t>(o) * d + r;
-      a[s] = *((o < ns && r < d && s < smax) ? p : fa.zero);
-    }
-    // what the results meet: lane (reg, nb) <-> row 16 rb + lk + 4 reg, column 16 nb + li
-    int di[4], mk[4];
-    double sg[4], cg[4][NB];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int ro = 16 * rb + lk + 4 * reg;
-      const bool border = ro >= ns && ro < d;
-      di[reg] = *(border ? fa.rel + w.bptr + (ro - ns) : fa.neg1);
-      mk[reg] = (NSL > 0) ? *((border && nslot > 0 && !mreg) ? fa.cmask + vbase + ro : reinterpret_cast<const int*>(fa.zero)) : 0;
-      sg[reg] = *((ro < ns) ? fa.sgn + w.c0 + ro : fa.zero);
-    }
-    if (NSL > 0 && mreg) {
-      const int q = rb >> 2;  // the row block's rows sit in one of the six registers
-      const int Mq = (q == 0) ? M[0] : (q == 1) ? M[1] : (q == 2) ? M[2] : (q == 3) ? M[3] : (q == 4) ? M[4] : M[5];
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int ro = 16 * rb + lk + 4 * reg;
-        const int m = __shfl(Mq, ro & 63);
-        mk[reg] = (ro >= ns && ro < d) ? m : 0;
-      }
-    }
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int ro = 16 * rb + lk + 4 * reg;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int n = 16 * nb + li;
-        const double* cp = V + (vbase + ro) * KB + n;
-        double v = 0.0;
-#pragma unroll
-        for (int sl = 0; sl < NSL; ++sl) v += *((n < kb && ((mk[reg] >> sl) & 1)) ? cp + sl * vslot : fa.zero);
-        cg[reg][nb] = v;
-      }
-    }
-    double4_t c[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) c[nb] = double4_t{0.0, 0.0, 0.0, 0.0};
-    // K-steps past the front's columns or (own rows) past the diagonal block multiply zeros: skipped (wave-uniform
-    // bound; on gfx950 an fp64 MFMA holds the SIMD's matrix pipe for 64 cycles -- at the leaf level they were a third
-    // of the SIMD time, 40 % of them on zeros)
-    // (not in the 12- to 16-step variants: the guarded form costs them 40 registers and a wave per SIMD; the leaf
-    // level gets a variant with as many K-steps as its widest front needs instead)
-    const int kmax = (NKS <= 8) ? min(smax, (ns + 3) >> 2) : NKS;
-#pragma unroll
-    for (int s = 0; s < NKS; ++s)
-      if (NKS > 8 || s < kmax) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) c[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s][nb], c[nb], 0, 0, 0);
-      }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one wait, then the stores back to back
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int ro = 16 * rb + lk + 4 * reg;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int n = 16 * nb + li;
-        if (ro < ns) {
-          if (n < kb) Y[(vbase + ro) * kb + n] = sg[reg] * c[nb][reg];
-        } else if (di[reg] >= 0 && n < kb) {
-          const int64_t drow = (w.scratch != 0) ? vbase + ro : w.pvoff + di[reg];
-          Vout[drow * KB + n] = cg[reg][nb] - c[nb][reg];
         }
       }
     }
@@ -1923,149 +1803,6 @@ __global__ __launch_bounds__(64) void bwd_thin_kernel(FrontArrays fa, const WgRe
 }
 
 
-// ------------------------------------------------------------------ fused bottom subtrees (forward)
-// The levels next to the leaves hold most of the factor AND most of the carry traffic: a front's carry is written to
-// a plane in HBM by its level's launch and read back by the parent's launch one level up.  A fused subtree keeps
-// those carries on the chip: ONE workgroup walks a whole bottom subtree (its fronts level by level, a barrier
-// between levels); a front adds its carry into the parent's accumulator in LDS (ds_add_f64: every parent row receives
-// at most one value from each of its at most two children, and an addition of two numbers does not depend on the
-// order), the parent reads its right-hand side and its border carries from there.  Only the subtree root writes a
-// carry to HBM (into its plane, as before).  Per front the arithmetic is that of fwd_thin_kernel -- MFMA operands
-// straight from global memory, v1 = alpha x + (p0 + p1) -- so the result is bitwise the one of the level-by-level path.
-struct SubFront {
-  WgRec w;     // the front's numbers, as in the per-level records
-  int acc;     // first row of this front's accumulator in the workgroup's LDS block; -1: no children
-  int pacc;    // first row of the parent's accumulator; -1: the subtree root (its carry goes to the global plane)
-  int nks;     // K-steps of 4 own columns the front needs: 4, 8 or 16
-  int w0, wpf; // the waves [w0, w0 + wpf) of the workgroup share this front's blocks of 16 rows
-  int phase;   // level inside the subtree
-  int pad0, pad1;
-};
-struct SubTree {
-  int first, count, rows, nphase;  // its SubFront records (phases ascending), accumulator rows, number of phases
-};
-
-constexpr int kSubWaves = 4;
-
-template <int KB, int NKS>
-__device__ __forceinline__ void subtree_front_fwd(const FrontArrays& fa, const SubFront& sf, int sub,
-                                                  const double* __restrict__ F, const double* __restrict__ Tb,
-                                                  const double* X, int ldx, double alpha, double* V,
-                                                  double* __restrict__ Y, int kb, double* acc) {
-  constexpr int NB = KB / 16;
-  const WgRec& w = sf.w;
-  const int lane = threadIdx.x & 63;
-  const int li = lane & 15, lk = lane >> 4;
-  const int ns = w.ns, d = ns + w.bs;
-  const int64_t vslot = fa.vrows * KB, vbase = w.voff;
-  const bool kids = sf.acc >= 0;
-  const double* accf = acc + static_cast<int64_t>(kids ? sf.acc : 0) * KB;
-  // v1 = alpha * X[own rows] + (the children's carries, summed in LDS), as B operands
-  double b[NKS][NB];
-  {
-    int xi[NKS];
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) xi[s] = *((4 * s + lk < ns) ? fa.v_src + vbase + 4 * s + lk : fa.neg1);
-#pragma unroll
-    for (int s = 0; s < NKS; ++s)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int o = 4 * s + lk, n = 16 * nb + li;
-        const bool ok = xi[s] >= 0 && n < kb;
-        const double xv = alpha * *(ok ? X + static_cast<int64_t>(xi[s]) * ldx + n : fa.zero);
-        const double cv = (kids && ok) ? accf[o * KB + n] : 0.0;
-        b[s][nb] = xv + cv;
-      }
-  }
-  double* Vout = V + static_cast<int64_t>(w.slot) * vslot;
-  const double* Tf = Tb + w.toff;
-  const double* Ff = F + w.foff;
-  const int nrb = (d + 15) >> 4;
-  for (int rb = sub; rb < nrb; rb += sf.wpf) {
-    const int r = 16 * rb + li;
-    const int smax = (fa.tri && 16 * rb + 16 <= ns) ? 4 * (rb + 1) : NKS;
-    double a[NKS];
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      const int o = 4 * s + lk;
-      const double* p = (r < ns) ? Tf + static_cast<int64_t>(o) * w.ldt + r : Ff + static_cast<int64_t>(o) * d + r;
-      a[s] = *((o < ns && r < d && s < smax) ? p : fa.zero);
-    }
-    int di[4];
-    double sg[4], cg[4][NB];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int ro = 16 * rb + lk + 4 * reg;
-      const bool border = ro >= ns && ro < d;
-      di[reg] = *(border ? fa.rel + w.bptr + (ro - ns) : fa.neg1);
-      sg[reg] = *((ro < ns) ? fa.sgn + w.c0 + ro : fa.zero);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int n = 16 * nb + li;
-        cg[reg][nb] = (kids && border && n < kb) ? accf[ro * KB + n] : 0.0;
-      }
-    }
-    double4_t c[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) c[nb] = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < NKS; ++s)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) c[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s][nb], c[nb], 0, 0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one wait, then the stores back to back
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int ro = 16 * rb + lk + 4 * reg;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int n = 16 * nb + li;
-        if (ro < ns) {
-          if (n < kb) Y[(vbase + ro) * kb + n] = sg[reg] * c[nb][reg];
-        } else if (di[reg] >= 0 && n < kb) {
-          const double val = cg[reg][nb] - c[nb][reg];
-          if (sf.pacc >= 0)
-            __hip_atomic_fetch_add(acc + (static_cast<int64_t>(sf.pacc) + di[reg]) * KB + n, val, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-          else
-            Vout[(w.pvoff + di[reg]) * KB + n] = val;
-        }
-      }
-    }
-  }
-}
-
-template <int KB>
-__global__ __launch_bounds__(64 * kSubWaves) void fwd_subtree_kernel(FrontArrays fa, const SubTree* __restrict__ trees,
-                                                                     const SubFront* __restrict__ fronts,
-                                                                     const double* __restrict__ F,
-                                                                     const double* __restrict__ Tb, const double* X,
-                                                                     int ldx, double alpha, double* V,
-                                                                     double* __restrict__ Y, int kb) {
-  extern __shared__ double sub_acc[];
-  const SubTree st = trees[blockIdx.x];
-  for (int i = threadIdx.x; i < st.rows * KB; i += 64 * kSubWaves) sub_acc[i] = 0.0;
-  __syncthreads();
-  const int wave = threadIdx.x >> 6;
-  int q = st.first;
-  const int qend = st.first + st.count;
-  for (int ph = 0; ph < st.nphase; ++ph) {
-    while (q < qend && fronts[q].phase == ph) {
-      const int w0 = fronts[q].w0, wpf = fronts[q].wpf;
-      if (wave >= w0 && wave < w0 + wpf) {
-        const SubFront sf = fronts[q];
-        if (sf.nks == 4)
-          subtree_front_fwd<KB, 4>(fa, sf, wave - w0, F, Tb, X, ldx, alpha, V, Y, kb, sub_acc);
-        else if (sf.nks == 8)
-          subtree_front_fwd<KB, 8>(fa, sf, wave - w0, F, Tb, X, ldx, alpha, V, Y, kb, sub_acc);
-        else
-          subtree_front_fwd<KB, 16>(fa, sf, wave - w0, F, Tb, X, ldx, alpha, V, Y, kb, sub_acc);
-      }
-      ++q;
-    }
-    __syncthreads();
-  }
-}
-
 // Ft(r, o) = [T; M21](r, o), row-major d x ns per front: 64 x 64 tiles through LDS
 __global__ __launch_bounds__(kThreads) void transpose_front_kernel(FrontArrays fa, const int* __restrict__ tr_pref,
                                                                   int nfronts, const int64_t* __restrict__ ftoff,
@@ -2101,26 +1838,6 @@ __global__ __launch_bounds__(kThreads) void transpose_front_kernel(FrontArrays f
       Fb[ftoff[f] + static_cast<int64_t>(rb) * 16 * ns + static_cast<int64_t>(go) * rows + (gr & 15)] = tile[r][oo];
     }
   }
-}
-
-// Pk(r, o) = [T; M21](r, o), column-major d x ns per front: the panel the sweeps stream, one contiguous block per
-// front, the fronts of a level next to each other in the order their workgroups are launched
-__global__ __launch_bounds__(kThreads) void pack_front_kernel(FrontArrays fa, const int* __restrict__ tr_pref,
-                                                             int nfronts, const int64_t* __restrict__ pkoff,
-                                                             const double* __restrict__ F,
-                                                             const double* __restrict__ Tb, double* __restrict__ Pk) {
-  const int f = find_slot(tr_pref, nfronts, blockIdx.x);
-  const int ns = fa.ns[f], d = ns + fa.bs[f];
-  const int nct = (ns + TW - 1) / TW;
-  const int local = blockIdx.x - tr_pref[f];
-  const int rt = local / nct, ct = local - rt * nct;
-  const int gr = rt * TW + (threadIdx.x & (TW - 1));
-  if (gr >= d) return;
-  const double* src = (gr < ns) ? Tb + fa.toff[f] + gr : F + fa.foff[f] + gr;
-  const int64_t lds = (gr < ns) ? ns : d;
-  double* dst = Pk + pkoff[f] + gr;
-  for (int go = ct * TW + (threadIdx.x >> 6); go < min(ns, (ct + 1) * TW); go += kThreads / TW)
-    dst[static_cast<int64_t>(go) * d] = src[static_cast<int64_t>(go) * lds];
 }
 
 // Fragment-major copies of [T; M21] for the fronts with several column tiles.  The level kernels of those fronts feed
@@ -2206,11 +1923,6 @@ struct eigd_factor {
   // narrow sweeps (k <= 8): one record per single-tile front and level, the transposed copy of [T; M21]
   WgRec* d_wave_wg = nullptr;
   std::vector<int> h_wave_ptr;
-  // fused bottom subtrees (sweeps of 16 / 32 columns): their fronts sit at the END of each level's wave records
-  SubTree* d_sub_trees = nullptr;
-  SubFront* d_sub_fronts = nullptr;
-  int n_subtrees = 0, sub_rows_max = 0;
-  std::vector<int> h_wave_free;  // per level: leading records of fronts outside the fused subtrees
   int64_t* d_ftoff = nullptr;
   int* d_tr_pref = nullptr;
   double* d_Ft = nullptr;
@@ -2220,8 +1932,6 @@ struct eigd_factor {
   int* d_mt_pref = nullptr;
   int n_ff = 0, n_mt = 0;
   int64_t fm_doubles = 0, bm_doubles = 0;
-  int64_t* d_pkoff = nullptr;  // packed sweep panels (level-major), nullptr: the sweeps read F and T
-  double* d_Pk = nullptr;
   int64_t ft_doubles = 0;
   int n_tr = 0;
   std::vector<int> ov_lvl_ptr;       // per level: range of overflow rows (extra rows of V after the sumd front rows)
@@ -2340,11 +2050,6 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false, bool piv
     hipLaunchKernelGGL(transpose_front_kernel, dim3(f->n_tr), dim3(kThreads), 0, st, fa, f->d_tr_pref, s.nfronts, f->d_ftoff,
                        f->d_F, f->d_T, f->d_Ft, f->d_Fb);
     EIGD_LAUNCH_CHECK();
-    if (f->d_Pk != nullptr) {
-      hipLaunchKernelGGL(pack_front_kernel, dim3(f->n_tr), dim3(kThreads), 0, st, fa, f->d_tr_pref, s.nfronts, f->d_pkoff,
-                         f->d_F, f->d_T, f->d_Pk);
-      EIGD_LAUNCH_CHECK();
-    }
   }
   if (f->n_mt > 0) {
     hipLaunchKernelGGL(pack_frag_kernel, dim3(f->n_mt), dim3(kThreads), 0, st, fa, f->d_ff, f->d_mt_pref, f->n_ff, f->d_F,
@@ -2378,6 +2083,11 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false, bool piv
 }
 
 
+// Launch policy of the sweeps (all measured on the 1 M-dof benchmark; the experiments behind each number are in
+// docs/LOG.md).  Sweeps of up to 8 columns run their single-tile fronts wave by wave (VALU, readlane broadcast); 5 to 8
+// columns otherwise go through the 16-column MFMA kernels.
+constexpr int kWaveMaxKpt = 2;   // widest sweep (units of 4 columns) whose single-tile fronts use the readlane wave kernels
+
 template <int KPT>
 int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, int* wT, const double* dIn, int ldin,
           double* dX, int ldx, int kb, double alpha) {
@@ -2387,19 +2097,7 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
   // entries no child writes stay zero for good
   constexpr int KB = 4 * KPT;
   wV += static_cast<int64_t>(f->nplanes) * f->v_rows * (KB - 4);  // 4 + 8 + ... below KB = KB - 4
-  static const int wave_max_kpt = [] {  // widest sweep that uses the wave-per-tile kernels for single-tile fronts
-    const char* v = std::getenv("EIGD_WAVE_MAX_KPT");
-    return (v && *v) ? std::atoi(v) : 2;
-  }();
-  // second matrix tile in flight in the single-column-tile forward kernel: off, the registers buy a third workgroup per CU
-  static const bool deep_single = [] {
-    const char* v = std::getenv("EIGD_DEEP");
-    return (v && *v) ? std::atoi(v) != 0 : false;
-  }();
-  static const bool xcd_ranges = [] {  // EIGD_XCD=0: records in launch order (round-robin over the XCDs)
-    const char* v = std::getenv("EIGD_XCD");
-    return (v && *v) ? std::atoi(v) != 0 : true;
-  }();
+  // multi-tile levels: every XCD gets a contiguous range of the level's records (see xcd_record)
   auto level_args = [&](const WgRec* wg, int kd = TW, int nwg = 0, bool multi = false) {
     LevelArgs la;
     la.wg = wg;
@@ -2408,35 +2106,19 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     la.kb = kb;
     la.kd = kd;
     la.nwg = nwg;
-    la.per_xcd = (multi && xcd_ranges) ? (nwg + 7) / 8 : 0;
+    la.per_xcd = multi ? (nwg + 7) / 8 : 0;
     return la;
   };
-  auto multi_grid = [&](int nwg) { return dim3(xcd_ranges ? 8 * ((nwg + 7) / 8) : nwg); };
+  auto multi_grid = [&](int nwg) { return dim3(8 * ((nwg + 7) / 8)); };
   auto lds_bytes = [](int kd) { return static_cast<unsigned>(sizeof(double) * (kd + 1) * (TLD + Tile<KPT>::BLD)); };
   // fronts with several column tiles, MFMA widths: matrix operands straight from the fragment-major copies (only the
-  // vector block in LDS); EIGD_FRAG=0: staged through LDS from the column-major panels
-  static const bool frag = [] {
-    const char* v = std::getenv("EIGD_FRAG");
-    return (v && *v) ? std::atoi(v) != 0 : true;
-  }();
+  // vector block in LDS); the vector-FMA widths stage the column-major panels through LDS
   const unsigned lds_frag = static_cast<unsigned>(sizeof(double) * (TW + 1) * Tile<KPT>::BLD);
-  const double* sF = f->d_Pk ? f->d_Pk : f->d_F;  // the panels [T; M21]: packed copy, or in place (F and T)
-  const double* sT = f->d_Pk ? f->d_Pk : f->d_T;
-  // fused bottom subtrees (16 / 32 columns): one launch for all their levels; the per-level launches below then
-  // only see the fronts outside them (a prefix of each level's wave records)
-  static const bool fuse_fwd = [] {
-    const char* v = std::getenv("EIGD_FUSE_FWD");
-    return (v && *v) ? std::atoi(v) != 0 : true;
-  }();
-  const bool fused_f = KPT >= 4 && fuse_fwd && f->n_subtrees > 0;
-  if constexpr (KPT >= 4) {
-    if (fused_f) {
-      hipLaunchKernelGGL((fwd_subtree_kernel<KB>), dim3(f->n_subtrees), dim3(64 * kSubWaves),
-                         sizeof(double) * f->sub_rows_max * KB, st, fa, f->d_sub_trees, f->d_sub_fronts, sF, sT, dIn, ldin,
-                         alpha, wV, wY, kb);
-      EIGD_LAUNCH_CHECK();
-    }
-  }
+  const double* sF = f->d_F;  // the panels [T; M21] in place (F and T)
+  const double* sT = f->d_T;
+  // raw buffer accesses take 32-bit byte offsets: a carry plane and the caller's block must stay below 4 GB, else the
+  // single-tile fronts of the MFMA widths go through the tile kernels
+  const bool thin_buf = f->v_rows * static_cast<int64_t>(KB) * 8 <= kBufMax && static_cast<int64_t>(s.n) * ldin * 8 <= kBufMax;
   // ---- forward: leaves -> root.  Y receives S z, the border rows of V the carries.
   for (int l = 0; l < s.nlevels; ++l) {
     const int nov = f->ov_lvl_ptr[l + 1] - f->ov_lvl_ptr[l];
@@ -2452,121 +2134,72 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     const bool leaf = f->h_lvl_leaf[l] != 0;  // ... has children at all
     const int nwave = f->h_wave_ptr[l + 1] - f->h_wave_ptr[l];
     bool narrow = false;
-    if (KPT <= wave_max_kpt) {
-      if (nwave > 0) {  // narrow sweep: one wave per tile of the single-tile fronts
-        static const int wave_wpf = [] {
-          const char* v = std::getenv("EIGD_WAVE_WPF");
-          return (v && *v) ? std::atoi(v) : 2;
-        }();
-#define EIGD_WAVE_FWD(NSLV)                                                                                           \
-  do {                                                                                                                \
-    if (wave_wpf == 1)                                                                                                \
-      hipLaunchKernelGGL((fwd_wave_kernel<KB, NSLV, 1>), dim3(nwave), dim3(64), 0, st, fa,                            \
-                         f->d_wave_wg + f->h_wave_ptr[l], sF, sT, dIn, ldin, alpha, wV, wY, kb);                      \
-    else                                                                                                              \
-      hipLaunchKernelGGL((fwd_wave_kernel<KB, NSLV, 2>), dim3(nwave), dim3(128), 0, st, fa,                           \
-                         f->d_wave_wg + f->h_wave_ptr[l], sF, sT, dIn, ldin, alpha, wV, wY, kb);                      \
-  } while (0)
+    if (KPT <= kWaveMaxKpt) {
+      if (nwave > 0) {  // narrow sweep: one wave per tile of the single-tile fronts, two waves per front
+        const WgRec* recs = f->d_wave_wg + f->h_wave_ptr[l];
         if (leaf)
-          EIGD_WAVE_FWD(0);
+          hipLaunchKernelGGL((fwd_wave_kernel<KB, 0, 2>), dim3(nwave), dim3(128), 0, st, fa, recs, sF, sT, dIn, ldin, alpha, wV,
+                             wY, kb);
         else if (two)
-          EIGD_WAVE_FWD(2);
+          hipLaunchKernelGGL((fwd_wave_kernel<KB, 2, 2>), dim3(nwave), dim3(128), 0, st, fa, recs, sF, sT, dIn, ldin, alpha, wV,
+                             wY, kb);
         else
-          EIGD_WAVE_FWD(kMaxS + 1);
-#undef EIGD_WAVE_FWD
+          hipLaunchKernelGGL((fwd_wave_kernel<KB, kMaxS + 1, 2>), dim3(nwave), dim3(128), 0, st, fa, recs, sF, sT, dIn, ldin,
+                             alpha, wV, wY, kb);
         EIGD_LAUNCH_CHECK();
         narrow = true;
       }
     }
     if constexpr (KPT >= 4) {
       const int nks = f->h_thin_fwd[l];
-      if (!narrow && nwave > 0 && nks > 0 && fused_f && f->h_wave_free[l] == 0) narrow = true;  // the whole level is fused
-      if (!narrow && nwave > 0 && nks > 0) {  // thin fronts: one wave per block of rows, operands straight from memory
+      if (!narrow && nwave > 0 && nks > 0 && thin_buf) {  // thin fronts: one wave per block of rows, operands straight from memory
         const WgRec* recs = f->d_wave_wg + f->h_wave_ptr[l];
-        const int nwave_all = nwave;
-        const int nwave = fused_f ? f->h_wave_free[l] : nwave_all;  // (shadows: the launches below take the unfused prefix)
-        // waves per front: with one, the front's right-hand side block (and its carries) is loaded once instead of
-        // once per wave (measured on C3, 32 columns: 1.654 -> 1.606 ms per sweep; EIGD_THIN_WPF=2 restores two)
-        static const int thin_wpf = [] {
-          const char* v = std::getenv("EIGD_THIN_WPF");
-          return (v && *v) ? std::atoi(v) : 1;
-        }();
-        const bool one = thin_wpf != 2;
-        // matrix operands from the row-major copy Ft (16 rows of [T; M21] = one contiguous piece: every line is fetched
-        // once -- from the column-major panels a line shared by two row blocks often came from HBM twice, and M21
-        // sits strided inside F): -0.28 GB per 32-column sweep, time unchanged.  EIGD_THIN_ROWM=0: column-major, 1: leaf level only
-        static const int thin_rowm = [] {
-          const char* v = std::getenv("EIGD_THIN_ROWM");
-          return (v && *v) ? std::atoi(v) : 2;
-        }();
-        const double* thin_ft = (thin_rowm == 2 || (thin_rowm == 1 && leaf)) ? f->d_Ft : nullptr;
-        static const unsigned thin_lds = [] {  // occupancy probe: dynamic LDS the thin forward launches reserve (unused)
-          const char* v = std::getenv("EIGD_THIN_LDS");
-          return (v && *v) ? static_cast<unsigned>(std::atoi(v)) : 0u;
-        }();
-        // raw buffer accesses in the row blocks (EIGD_THIN_BUF=0: selected 64-bit addresses): planes and result block below 4 GB
-        static const bool thin_buf_env = [] {
-          const char* v = std::getenv("EIGD_THIN_BUF");
-          return (v && *v) ? std::atoi(v) != 0 : true;
-        }();
-        const bool thin_buf = thin_buf_env && f->v_rows * static_cast<int64_t>(KB) * 8 <= kBufMax &&
-                              static_cast<int64_t>(s.n) * ldin * 8 <= kBufMax;
-#define EIGD_THIN_FWD(NKS, NSLV)                                                                                        \
-  do {                                                                                                                  \
-    if (!fa.tri)                                                                                                        \
-      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, false>), dim3(nwave), dim3(64), thin_lds, st, fa, recs, sF, sT, dIn, \
-                         ldin, alpha, wV, wY, kb, thin_ft);                                                             \
-    else if (one && thin_buf && f->d_Fb != nullptr)                                                                    \
-      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, true, true>), dim3(nwave), dim3(64), thin_lds, st, fa, recs, \
-                         sF, sT, dIn, ldin, alpha, wV, wY, kb, f->d_Fb);                                                \
-    else if (one)                                                                                                       \
-      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 1, true>), dim3(nwave), dim3(64), thin_lds, st, fa, recs, sF, sT, dIn,  \
-                         ldin, alpha, wV, wY, kb, thin_ft);                                                             \
-    else                                                                                                                \
-      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, 2, true>), dim3(nwave), dim3(128), thin_lds, st, fa, recs, sF, sT, dIn, \
-                         ldin, alpha, wV, wY, kb, thin_ft);                                                             \
+#define EIGD_THIN_FWD(NKS, NSLV, WPFV)                                                                                   \
+  do {                                                                                                                   \
+    if (fa.tri)                                                                                                          \
+      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, WPFV, true>), dim3(nwave), dim3(64 * WPFV), 0, st, fa, recs, dIn, ldin, \
+                         alpha, wV, wY, kb, f->d_Fb);                                                                    \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, NSLV, WPFV, false>), dim3(nwave), dim3(64 * WPFV), 0, st, fa, recs, dIn, ldin, \
+                         alpha, wV, wY, kb, f->d_Fb);                                                                    \
   } while (0)
-        if (!leaf && two && nks >= 12 && fa.tri && thin_buf && f->d_Fb != nullptr) {
+        if (!leaf && two && nks >= 12) {
           // fronts of 33 to 64 own columns with carry planes: as many waves per front as give the level >= 2048 waves
           const int wpf = (nwave >= 2048) ? 1 : (nwave >= 1024) ? 2 : 4;
-#define EIGD_THIN_FWD_W(NKS, WPFV)                                                                                      \
-  hipLaunchKernelGGL((fwd_thin_kernel<KB, NKS, 2, WPFV, true, true>), dim3(nwave), dim3(64 * WPFV), thin_lds, st, fa, recs, \
-                     sF, sT, dIn, ldin, alpha, wV, wY, kb, f->d_Fb)
           if (nks == 12 && wpf == 1)
-            EIGD_THIN_FWD_W(12, 1);
+            EIGD_THIN_FWD(12, 2, 1);
           else if (nks == 12 && wpf == 2)
-            EIGD_THIN_FWD_W(12, 2);
+            EIGD_THIN_FWD(12, 2, 2);
           else if (nks == 12)
-            EIGD_THIN_FWD_W(12, 4);
+            EIGD_THIN_FWD(12, 2, 4);
           else if (wpf == 1)
-            EIGD_THIN_FWD_W(16, 1);
+            EIGD_THIN_FWD(16, 2, 1);
           else if (wpf == 2)
-            EIGD_THIN_FWD_W(16, 2);
+            EIGD_THIN_FWD(16, 2, 2);
           else
-            EIGD_THIN_FWD_W(16, 4);
-#undef EIGD_THIN_FWD_W
+            EIGD_THIN_FWD(16, 2, 4);
         } else if (leaf && nks == 4)
-          EIGD_THIN_FWD(4, 0);
+          EIGD_THIN_FWD(4, 0, 1);
         else if (leaf && nks == 8)
-          EIGD_THIN_FWD(8, 0);
+          EIGD_THIN_FWD(8, 0, 1);
         else if (leaf && nks == 12)
-          EIGD_THIN_FWD(12, 0);
+          EIGD_THIN_FWD(12, 0, 1);
         else if (leaf && nks == 14)
-          EIGD_THIN_FWD(14, 0);
+          EIGD_THIN_FWD(14, 0, 1);
         else if (leaf)
-          EIGD_THIN_FWD(16, 0);
+          EIGD_THIN_FWD(16, 0, 1);
         else if (nks == 4 && two)
-          EIGD_THIN_FWD(4, 2);
+          EIGD_THIN_FWD(4, 2, 1);
         else if (nks == 4)
-          EIGD_THIN_FWD(4, kMaxS + 1);
+          EIGD_THIN_FWD(4, kMaxS + 1, 1);
         else if (nks == 8 && two)
-          EIGD_THIN_FWD(8, 2);
+          EIGD_THIN_FWD(8, 2, 1);
         else if (nks == 8)
-          EIGD_THIN_FWD(8, kMaxS + 1);
+          EIGD_THIN_FWD(8, kMaxS + 1, 1);
         else if (two)
-          EIGD_THIN_FWD(16, 2);
+          EIGD_THIN_FWD(16, 2, 1);
         else
-          EIGD_THIN_FWD(16, kMaxS + 1);
+          EIGD_THIN_FWD(16, kMaxS + 1, 1);
 #undef EIGD_THIN_FWD
         EIGD_LAUNCH_CHECK();
         narrow = true;
@@ -2579,39 +2212,31 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
         return static_cast<unsigned>(sizeof(double) * (kd + 1) * ((KPT == 4 ? 0 : TLD) + Tile<KPT>::BLD));
       };
       if (leaf)
-        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, false, 0>), dim3(nsingle), dim3(kThreads), lds_bytes(kd), st, fa, la,
-                           sF, sT, dIn, ldin, alpha, wV, wY);
-      else if (two && deep_single)
-        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, true, 2>), dim3(nsingle), dim3(kThreads), lds_bytes(kd), st, fa, la,
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, 0>), dim3(nsingle), dim3(kThreads), lds_bytes(kd), st, fa, la,
                            sF, sT, dIn, ldin, alpha, wV, wY);
       else if (two)
-        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, false, 2>), dim3(nsingle), dim3(kThreads), lds_bytes(kd), st, fa, la,
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, 2>), dim3(nsingle), dim3(kThreads), lds_bytes(kd), st, fa, la,
                            sF, sT, dIn, ldin, alpha, wV, wY);
       else
-        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, false, kMaxS + 1>), dim3(nsingle), dim3(kThreads), lds_bytes(kd), st,
+        hipLaunchKernelGGL((fwd_level_kernel<KPT, true, kMaxS + 1>), dim3(nsingle), dim3(kThreads), lds_bytes(kd), st,
                            fa, la, sF, sT, dIn, ldin, alpha, wV, wY);
       EIGD_LAUNCH_CHECK();
     }
     if (nwg > nsingle) {
       const LevelArgs la = level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle, TW, nwg - nsingle, true);
-      bool done = false;
       if constexpr (Tile<KPT>::kMfma) {
-        if (frag) {
-          if (two)
-            hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, 2, true>), multi_grid(nwg - nsingle), dim3(kThreads),
-                               lds_frag, st, fa, la, f->d_Fm, sT, dIn, ldin, alpha, wV, wY);
-          else
-            hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, kMaxS + 1, true>), multi_grid(nwg - nsingle),
-                               dim3(kThreads), lds_frag, st, fa, la, f->d_Fm, sT, dIn, ldin, alpha, wV, wY);
-          done = true;
-        }
-      }
-      if (!done) {
         if (two)
-          hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, 2>), multi_grid(nwg - nsingle), dim3(kThreads),
+          hipLaunchKernelGGL((fwd_level_kernel<KPT, false, 2, true>), multi_grid(nwg - nsingle), dim3(kThreads),
+                             lds_frag, st, fa, la, f->d_Fm, sT, dIn, ldin, alpha, wV, wY);
+        else
+          hipLaunchKernelGGL((fwd_level_kernel<KPT, false, kMaxS + 1, true>), multi_grid(nwg - nsingle),
+                             dim3(kThreads), lds_frag, st, fa, la, f->d_Fm, sT, dIn, ldin, alpha, wV, wY);
+      } else {
+        if (two)
+          hipLaunchKernelGGL((fwd_level_kernel<KPT, false, 2>), multi_grid(nwg - nsingle), dim3(kThreads),
                              lds_bytes(TW), st, fa, la, sF, sT, dIn, ldin, alpha, wV, wY);
         else
-          hipLaunchKernelGGL((fwd_level_kernel<KPT, false, false, kMaxS + 1>), multi_grid(nwg - nsingle), dim3(kThreads),
+          hipLaunchKernelGGL((fwd_level_kernel<KPT, false, kMaxS + 1>), multi_grid(nwg - nsingle), dim3(kThreads),
                              lds_bytes(TW), st, fa, la, sF, sT, dIn, ldin, alpha, wV, wY);
       }
       EIGD_LAUNCH_CHECK();
@@ -2623,20 +2248,15 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     if (nwg == 0) continue;
     const int nwave = f->h_wave_ptr[l + 1] - f->h_wave_ptr[l];
     const int nsb = f->h_bwd_nsingle[l];
-    const bool narrow = KPT <= wave_max_kpt && nwave > 0;  // narrow sweep: the single-tile fronts go wave by wave
+    const bool narrow = KPT <= kWaveMaxKpt && nwave > 0;  // narrow sweep: the single-tile fronts go wave by wave
     bool thin = false;
     if constexpr (KPT >= 4) thin = !narrow && nwave > 0 && f->h_thin_bwd[l] > 0;
     if (nwg > nsb) {  // fronts with several column tiles: full 64-row tiles
       const LevelArgs la = level_args(f->d_bwd_wg + f->h_bwd_ptr[l] + nsb, TW, nwg - nsb, true);
-      bool done = false;
-      if constexpr (Tile<KPT>::kMfma) {
-        if (frag) {
-          hipLaunchKernelGGL((bwd_level_kernel<KPT, false, true>), multi_grid(nwg - nsb), dim3(kThreads), lds_frag, st, fa, la,
-                             sF, sT, f->d_Bm, wY, dX, ldx);
-          done = true;
-        }
-      }
-      if (!done)
+      if constexpr (Tile<KPT>::kMfma)
+        hipLaunchKernelGGL((bwd_level_kernel<KPT, false, true>), multi_grid(nwg - nsb), dim3(kThreads), lds_frag, st, fa, la,
+                           sF, sT, f->d_Bm, wY, dX, ldx);
+      else
         hipLaunchKernelGGL((bwd_level_kernel<KPT, false>), multi_grid(nwg - nsb), dim3(kThreads), lds_bytes(TW), st, fa, la, sF,
                            sT, f->d_Ft, wY, dX, ldx);
       EIGD_LAUNCH_CHECK();
@@ -2649,17 +2269,13 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
       if constexpr (KPT >= 4) {
         const WgRec* recs = f->d_wave_wg + f->h_wave_ptr[l];
         const int nks = f->h_thin_bwd[l];
-        static const unsigned thin_lds_b = [] {  // occupancy probe, as in the forward direction
-          const char* v = std::getenv("EIGD_THIN_LDS_BWD");
-          return (v && *v) ? static_cast<unsigned>(std::atoi(v)) : 0u;
-        }();
 #define EIGD_THIN_BWD(NOB, CHV)                                                                                   \
   do {                                                                                                            \
     if (fa.tri)                                                                                                   \
-      hipLaunchKernelGGL((bwd_thin_kernel<KB, NOB, CHV, true>), dim3(nwave), dim3(64), thin_lds_b, st, fa, recs, f->d_Ft, wY, \
+      hipLaunchKernelGGL((bwd_thin_kernel<KB, NOB, CHV, true>), dim3(nwave), dim3(64), 0, st, fa, recs, f->d_Ft, wY, \
                          dX, ldx, kb);                                                                            \
     else                                                                                                          \
-      hipLaunchKernelGGL((bwd_thin_kernel<KB, NOB, CHV, false>), dim3(nwave), dim3(64), thin_lds_b, st, fa, recs, f->d_Ft, \
+      hipLaunchKernelGGL((bwd_thin_kernel<KB, NOB, CHV, false>), dim3(nwave), dim3(64), 0, st, fa, recs, f->d_Ft, \
                          wY, dX, ldx, kb);                                                                        \
   } while (0)
         if (nks == 4)
@@ -2782,8 +2398,7 @@ int eigd_factor_free(eigd_factor* f) {
                   f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_ov_dst,   f->d_ov_ptr, f->d_ov_src,
                   f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux,      f->d_bout,  f->d_tickets,
                   f->d_P,         f->d_wave_wg,     f->d_ftoff,      f->d_tr_pref,  f->d_Ft,  f->d_Fb,
-                  f->d_Fm,        f->d_Bm,          f->d_ff,         f->d_mt_pref,
-                  f->d_pkoff,     f->d_Pk,          f->d_sub_trees,  f->d_sub_fronts};
+                  f->d_Fm,        f->d_Bm,          f->d_ff,         f->d_mt_pref};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;
@@ -2890,35 +2505,18 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   std::vector<int> h_fwd_ptr(static_cast<size_t>(s.nlevels) + 1, 0), h_bwd_ptr(static_cast<size_t>(s.nlevels) + 1, 0);
   int64_t fwd_slabs = 0, bwd_slabs = 0;
   int n_tickets = 0;
-  auto env_int = [](const char* name, int dflt) {
-    const char* v = std::getenv(name);
-    return (v && *v) ? std::atoi(v) : dflt;
-  };
-  // chains longer than split_min tiles are cut into groups of about split_len tiles (at most split_maxg groups)
-  const int split_min = env_int("EIGD_SPLIT_MIN", 3), split_len = std::max(1, env_int("EIGD_SPLIT_LEN", 3));
-  const int split_maxg = std::max(1, env_int("EIGD_SPLIT_MAXG", 12)), split_nfl = env_int("EIGD_SPLIT_NFL", 128);
-  // packed sweep panels: level by level in launch order, every front one contiguous d x ns block
-  const bool packed = env_int("EIGD_PACKED", 0) != 0;
-  std::vector<int64_t> pkoff(static_cast<size_t>(nf) + 1, 0);
-  {
-    int64_t off = 0;
-    for (int l = 0; l < s.nlevels; ++l)
-      for (int q = s.lvl_ptr[l]; q < s.lvl_ptr[l + 1]; ++q) {
-        const int fr = s.lvl_fronts[q];
-        pkoff[fr] = off;
-        off += (static_cast<int64_t>(s.f_ns[fr]) + s.f_bs[fr]) * s.f_ns[fr];
-      }
-    pkoff[nf] = off;
-  }
+  // chains longer than split_min tiles are cut into groups of about split_len tiles (at most split_maxg groups) on
+  // levels of at most split_nfl fronts (swept over eight settings on the benchmark: these stay the best)
+  constexpr int split_min = 3, split_len = 3, split_maxg = 12, split_nfl = 128;
   auto front_numbers = [&](WgRec& w, int fr) {
     w.f = fr;
     w.ns = s.f_ns[fr];
     w.bs = s.f_bs[fr];
     w.c0 = s.f_c0[fr];
     w.voff = s.f_voff[fr];
-    w.foff = packed ? pkoff[fr] : s.f_foff[fr];
-    w.toff = packed ? pkoff[fr] : toff[fr];
-    w.ldt = packed ? s.f_ns[fr] + s.f_bs[fr] : s.f_ns[fr];
+    w.foff = s.f_foff[fr];
+    w.toff = toff[fr];
+    w.ldt = s.f_ns[fr];
     w.bptr = s.f_bptr[fr];
     w.ftoff = ftoff[fr];
     w.moff = 0;
@@ -3015,7 +2613,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   size_t free_b = 0, total_b = 0;
   EIGD_HIP(hipMemGetInfo(&free_b, &total_b));
   const size_t need = sizeof(double) * (static_cast<size_t>(s.front_doubles) + s.inv_doubles + toff[nf] +
-                                        (packed ? 3 : 2) * ftoff[nf] + fm_doubles + bm_doubles + (2 * nplanes + 1) * v_rows * KBMAX +
+                                        2 * ftoff[nf] + fm_doubles + bm_doubles + (2 * nplanes + 1) * v_rows * KBMAX +
                                         n_slabs * TW * KBMAX) +
                       16 * s.a_src.size() + (size_t(64) << 20);
   if (need > free_b) {
@@ -3037,9 +2635,9 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   f->h_fwd_kd.assign(static_cast<size_t>(s.nlevels), 8);
   f->h_bwd_kd.assign(static_cast<size_t>(s.nlevels), 8);
   {
-    // levels for the wave-per-block kernels: every single-column-tile front has at most EIGD_THIN_NS_FWD / _BWD own
+    // levels for the wave-per-block kernels: every single-column-tile front has at most thin_fwd / thin_bwd own
     // columns and (backward) a border of <= 320
-    const int thin_fwd = std::min(TW, env_int("EIGD_THIN_NS_FWD", TW)), thin_bwd = std::min(TW, env_int("EIGD_THIN_NS_BWD", TW));
+    constexpr int thin_fwd = TW, thin_bwd = TW;
     std::vector<int> mxns(static_cast<size_t>(s.nlevels), 0), mxbs(static_cast<size_t>(s.nlevels), 0);
     for (int q = 0; q < nf; ++q) {
       if (s.f_ns[q] > TW) continue;
@@ -3054,10 +2652,10 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
       // leaf level: K-steps of the forward kernel cut to the widest front (12 / 14 instead of 16: fewer MFMAs on zeros)
       const int nks_leaf = (mxns[l] > 32 && mxns[l] <= 48) ? 12 : (mxns[l] > 48 && mxns[l] <= 56) ? 14 : nks;
       // (with carries to gather, the 16-step forward variant needs 244 VGPRs: those levels stay with the tile kernels)
-      // round 3: levels of binary fronts with up to EIGD_THIN_NS_FWD_KIDS (48) own columns go to the buffer-access thin
+      // levels of binary fronts with up to 48 own columns go to the buffer-access thin
       // kernels too, with two or four waves per front where the level has fewer than 2048 fronts (at C3 the two levels of
       // 42-column fronts under the multi-tile ones: 61 + 44 us in the tile kernel)
-      const int kids_cap = f->h_lvl_two[l] ? std::max(32, env_int("EIGD_THIN_NS_FWD_KIDS", 48)) : 32;
+      const int kids_cap = f->h_lvl_two[l] ? 48 : 32;
       if (mxns[l] > 0 && mxns[l] <= (f->h_lvl_leaf[l] ? thin_fwd : std::min(thin_fwd, kids_cap)))
         f->h_thin_fwd[l] = f->h_lvl_leaf[l] ? nks_leaf : nks;
       // (backward: one wave per front -- with more than 32 own columns only where the level has fronts enough to
@@ -3092,113 +2690,6 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   f->n_tri = tri_pref[nf];
   f->n_m21 = m_pref[nf];
 
-  // ---- fused bottom subtrees (see fwd_subtree_kernel).  Roots are chosen top-down: the highest fronts whose whole
-  // subtree consists of single-column-tile fronts on levels the wave-per-block kernels serve, with at most two
-  // children each, and whose accumulators (one block of own + border rows per front that has children) fit the LDS budget.
-  std::vector<SubTree> sub_trees;
-  std::vector<SubFront> sub_fronts;
-  std::vector<int> h_wave_free(static_cast<size_t>(s.nlevels), 0);
-  int sub_rows_max = 0;
-  {
-    // OFF by default (EIGD_FUSE=1 turns it on): measured on the 1 M-dof benchmark the fused launch takes 665 us where
-    // the three level launches it replaces take 410 us (32 columns; 1.88 against 1.58 ms per sweep) -- 65 KB of
-    // accumulators per workgroup leave two workgroups per CU, and every level of the subtree adds a barrier and a round
-    // of dependent loads (record -> indices -> operands) that the wave-per-block kernels overlap across 12 waves per
-    // CU.  The bytes saved (15 % of a sweep) do not pay for that; kept as a tested option for narrower accumulators.
-    const int fuse_levels = env_int("EIGD_FUSE", 0) != 0 ? env_int("EIGD_FUSE_LEVELS", 2) : -1;
-    const int fuse_rows = std::min(255, env_int("EIGD_FUSE_ROWS", 255));  // 255 rows x 32 columns x 8 B < 64 KiB
-    std::vector<std::vector<int>> kidsof(static_cast<size_t>(nf));
-    for (int c = 0; c < nf; ++c)
-      if (s.f_parent[c] >= 0 && s.f_bs[c] > 0) kidsof[s.f_parent[c]].push_back(c);
-    // rows[q]: accumulator rows of the subtree below q if every front in it qualifies, -1 otherwise (postorder: children first)
-    std::vector<int> rows(static_cast<size_t>(nf), -1);
-    for (int q = 0; q < nf; ++q) {
-      const int l = s.f_level[q];
-      bool ok = s.f_ns[q] <= TW && s.f_ns[q] > 0 && l <= fuse_levels && f->h_thin_fwd[l] > 0 && f->h_thin_bwd[l] > 0 &&
-                kidsof[q].size() <= 2 && child_no[q] < kMaxS;
-      int r = kidsof[q].empty() ? 0 : s.f_ns[q] + s.f_bs[q];
-      for (int c : kidsof[q]) {
-        if (rows[c] < 0) ok = false;
-        else r += rows[c];
-      }
-      // a child that is not a carry child (no border) hangs below q in the tree only formally: nothing to check
-      rows[q] = (ok && r <= fuse_rows) ? r : -1;
-    }
-    std::vector<char> fused(static_cast<size_t>(nf), 0);
-    for (int q = nf - 1; q >= 0; --q) {
-      if (fused[q] || rows[q] <= 0) continue;  // (rows == 0: a leaf on its own -- nothing to fuse)
-      // collect the subtree, levels ascending
-      std::vector<int> members, stack{q};
-      while (!stack.empty()) {
-        const int x = stack.back();
-        stack.pop_back();
-        members.push_back(x);
-        fused[x] = 1;
-        for (int c : kidsof[x]) stack.push_back(c);
-      }
-      std::stable_sort(members.begin(), members.end(), [&](int a, int b) {
-        return s.f_level[a] != s.f_level[b] ? s.f_level[a] < s.f_level[b] : a < b;
-      });
-      std::vector<int> accoff(members.size(), -1);
-      int off = 0;
-      for (size_t i = 0; i < members.size(); ++i)
-        if (!kidsof[members[i]].empty()) {
-          accoff[i] = off;
-          off += s.f_ns[members[i]] + s.f_bs[members[i]];
-        }
-      auto acc_of = [&](int fr) {
-        for (size_t i = 0; i < members.size(); ++i)
-          if (members[i] == fr) return accoff[i];
-        return -1;
-      };
-      SubTree st;
-      st.first = static_cast<int>(sub_fronts.size());
-      st.count = static_cast<int>(members.size());
-      st.rows = off;
-      int phase = -1, lastlvl = -1;
-      size_t i = 0;
-      while (i < members.size()) {
-        size_t j = i;
-        while (j < members.size() && s.f_level[members[j]] == s.f_level[members[i]]) ++j;
-        ++phase;
-        lastlvl = s.f_level[members[i]];
-        const int nfp = static_cast<int>(j - i);
-        const int wpf = nfp >= kSubWaves ? 1 : kSubWaves / nfp;
-        for (size_t t = i; t < j; ++t) {
-          const int fr = members[t];
-          SubFront sf;
-          front_numbers(sf.w, fr);
-          sf.w.tile = 0;
-          sf.w.s0 = sf.w.s1 = 0;
-          sf.w.slab = sf.w.cnt = 0;
-          sf.w.G = 1;
-          sf.w.flags = 1 | (kidsof[fr].empty() ? 0 : 2);
-          sf.acc = accoff[t];
-          sf.pacc = (fr == q) ? -1 : acc_of(s.f_parent[fr]);
-          sf.nks = (s.f_ns[fr] <= 16) ? 4 : (s.f_ns[fr] <= 32) ? 8 : 16;
-          sf.wpf = wpf;
-          sf.w0 = nfp >= kSubWaves ? static_cast<int>((t - i) % kSubWaves) : static_cast<int>(t - i) * wpf;
-          sf.phase = phase;
-          sf.pad0 = sf.pad1 = 0;
-          sub_fronts.push_back(sf);
-        }
-        i = j;
-      }
-      (void)lastlvl;
-      st.nphase = phase + 1;
-      sub_rows_max = std::max(sub_rows_max, st.rows);
-      sub_trees.push_back(st);
-    }
-    // the fused fronts go to the end of their level's wave records: the per-level launches then take a prefix
-    for (int l = 0; l < s.nlevels; ++l) {
-      auto b = wave_wg.begin() + h_wave_ptr[l], e = wave_wg.begin() + h_wave_ptr[l + 1];
-      auto mid = std::stable_partition(b, e, [&](const WgRec& w) { return !fused[w.f]; });
-      h_wave_free[l] = static_cast<int>(mid - b);
-    }
-  }
-  f->h_wave_free = h_wave_free;
-  f->n_subtrees = static_cast<int>(sub_trees.size());
-  f->sub_rows_max = sub_rows_max;
   int rc = EIGD_OK;
 #define UP(dst, vec)                          \
   if (rc == EIGD_OK) rc = upload(f, &f->dst, vec);
@@ -3217,12 +2708,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   UP(d_fwd_wg, fwd_wg)
   UP(d_bwd_wg, bwd_wg)
   UP(d_wave_wg, wave_wg)
-  UP(d_sub_trees, sub_trees)
-  UP(d_sub_fronts, sub_fronts)
   UP(d_ftoff, ftoff)
-  if (packed) {
-    UP(d_pkoff, pkoff)
-  }
   UP(d_tr_pref, tr_pref)
   UP(d_mt_pref, mt_pref)
   if (!ffr.empty()) {
@@ -3277,7 +2763,6 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   rc = dmalloc(&f->d_Fb, static_cast<size_t>(f->ft_doubles));
   rc = dmalloc(&f->d_Fm, static_cast<size_t>(std::max<int64_t>(f->fm_doubles, 1)));
   rc = dmalloc(&f->d_Bm, static_cast<size_t>(std::max<int64_t>(f->bm_doubles, 1)));
-  if (packed) rc = dmalloc(&f->d_Pk, static_cast<size_t>(std::max<int64_t>(pkoff[nf], 1)));
   rc = dmalloc(&f->d_P, static_cast<size_t>(n_slabs) * TW * KBMAX);
   if (rc == EIGD_OK) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_tickets), sizeof(int) * f->n_tickets);
@@ -3351,18 +2836,9 @@ static int solve_blocks(eigd_factor* f, hipStream_t st, double* wV, double* wY, 
   for (int c0 = 0; c0 < k; c0 += KBMAX) {
     const int kb = std::min(KBMAX, k - c0);
     int rc;
-    static const int min_kpt = [] {  // EIGD_SWEEP_MIN_KPT: development knob (route narrow sweeps through a wider kernel)
-      const char* v = std::getenv("EIGD_SWEEP_MIN_KPT");
-      return (v && *v) ? std::atoi(v) : 1;
-    }();
-    static const bool kpt2 = [] {  // EIGD_SWEEP_KPT2: the 8-column kernels (off: 5..8 columns run through the 16-column
-      const char* v = std::getenv("EIGD_SWEEP_KPT2");  // kernels, whose single-tile levels are MFMA wave kernels)
-      return (v && *v) ? std::atoi(v) != 0 : false;
-    }();
-    if (kb <= 4 && min_kpt <= 1)
+    // 5 to 8 columns go through the 16-column kernels, whose single-tile levels are MFMA wave kernels (1.26 -> 1.09 ms)
+    if (kb <= 4)
       rc = sweep<1>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
-    else if (kb <= 8 && min_kpt <= 2 && kpt2)
-      rc = sweep<2>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else if (kb <= 16)
       rc = sweep<4>(f, st, wV, wY, wP, wT, dIn + c0, ldin, dOut + c0, ldout, kb, alpha);
     else

@@ -480,12 +480,8 @@ int eigd_spmm_on(eigd_ctx* ctx, eigd_mat* A, const double* dX, int ldx, double* 
     const int kp = std::max(2, next_pow2(kb));
     const int rp = kThreads / kp;
     const dim3 grid((A->n + rp - 1) / rp);
-    // lanes per matrix row in the product phase (EIGD_SPMM_LANES=0: one lane per column, the round-2 mapping)
-    static const int lanes = [] {
-      const char* v = std::getenv("EIGD_SPMM_LANES");
-      return (v && *v) ? std::atoi(v) : 8;
-    }();
-    const int cpl = (lanes == 8 && kp >= 8) ? kp / 8 : 1;
+    // eight lanes per matrix row in the product phase, k/8 neighbouring columns each
+    const int cpl = (kp >= 8) ? kp / 8 : 1;
     const size_t tile_lds = sizeof(double) * static_cast<size_t>(A->umax) * (cpl >= 2 ? kp + 4 : kp + 1);  // SpmmTile::LD
     const size_t tile_lds_all = tile_lds + static_cast<size_t>(A->tnz_cap) * (sizeof(double) + sizeof(uint16_t));
     if (A->ntiles > 0 && tile_lds <= static_cast<size_t>(kTileLds)) {
@@ -493,14 +489,9 @@ int eigd_spmm_on(eigd_ctx* ctx, eigd_mat* A, const double* dX, int ldx, double* 
       const dim3 tgrid(per_xcd * 8);
 #define EIGD_SPMM_TILED(KP)                                                                                            \
   case KP:                                                                                                             \
-    if (lanes == 8)                                                                                                    \
-      hipLaunchKernelGGL((spmm_tiled_kernel<KP, 8>), tgrid, dim3(kThreads), tile_lds_all, st, A->n, kb, A->ntiles,     \
-                         per_xcd, A->tile_ptr, A->ucols, A->indptr, A->lidx, A->data, dX + c0, ldx, dY + c0, ldy,      \
-                         alpha, beta, A->umax, A->tnz_cap);                                                            \
-    else                                                                                                               \
-      hipLaunchKernelGGL((spmm_tiled_kernel<KP, 1024>), tgrid, dim3(kThreads), tile_lds_all, st, A->n, kb, A->ntiles,  \
-                         per_xcd, A->tile_ptr, A->ucols, A->indptr, A->lidx, A->data, dX + c0, ldx, dY + c0, ldy,      \
-                         alpha, beta, A->umax, A->tnz_cap);                                                            \
+    hipLaunchKernelGGL((spmm_tiled_kernel<KP, 8>), tgrid, dim3(kThreads), tile_lds_all, st, A->n, kb, A->ntiles,       \
+                       per_xcd, A->tile_ptr, A->ucols, A->indptr, A->lidx, A->data, dX + c0, ldx, dY + c0, ldy,        \
+                       alpha, beta, A->umax, A->tnz_cap);                                                              \
     break;
       switch (kp) {
         EIGD_SPMM_TILED(2)

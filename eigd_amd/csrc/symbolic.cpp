@@ -134,7 +134,6 @@ struct ND {
   int next_region = 1;
   const double* coords = nullptr;  // optional: dim coordinates per compressed vertex
   int dim = 0;
-  int merge_rounds = 0;            // dissection rounds from the root that take two cuts at once (geometric ordering)
 
   ND(const Graph& gg, int leaf) : g(gg), leaf_size(leaf) {
     region.assign(g.nv, 0);
@@ -369,33 +368,9 @@ struct ND {
         int r1 = next_region++, r2 = next_region++;
         for (int v : p1) region[v] = r1;
         for (int v : p2) region[v] = r2;
-        // Near the root two dissection rounds are merged into one front (geometric ordering only): each half is cut
-        // again right away and its separator joins this one -- a cross instead of a line, four children instead of
-        // two.  About the same fill, half as many tree levels where the levels are latency bound (one launch per
-        // level and direction in the sweeps).
         std::vector<std::vector<int>> parts;
-        if (coords != nullptr && task.depth < merge_rounds) {
-          for (auto* side : {&p1, &p2}) {
-            const int rs = (side == &p1) ? r1 : r2;
-            int64_t ws = 0;
-            for (int v : *side) ws += g.vw[v];
-            std::vector<int> s2, q1, q2;
-            if (ws > 8 * static_cast<int64_t>(leaf_size) && geometric_split(*side, rs, ws, s2, q1, q2)) {
-              sep.insert(sep.end(), s2.begin(), s2.end());
-              for (int v : s2) region[v] = -1;
-              for (auto* q : {&q1, &q2}) {
-                const int rq = next_region++;
-                for (int v : *q) region[v] = rq;
-                parts.push_back(std::move(*q));
-              }
-            } else {
-              parts.push_back(std::move(*side));
-            }
-          }
-        } else {
-          parts.push_back(std::move(p1));
-          parts.push_back(std::move(p2));
-        }
+        parts.push_back(std::move(p1));
+        parts.push_back(std::move(p2));
         int snode = add_node(task.parent, sep.data(), static_cast<int64_t>(sep.size()));
         for (auto& pv : parts) {
           Task t;
@@ -454,7 +429,6 @@ bool analyze(int n, const int32_t* ip, const int32_t* ix, int leaf_size, int pan
       for (int a = 0; a < dim; ++a) vcoords[static_cast<size_t>(v) * dim + a] = dof_coords[static_cast<size_t>(g.cv_dofs[g.cv_ptr[v]]) * dim + a];
     nd.coords = vcoords.data();
     nd.dim = dim;
-    if (const char* e = std::getenv("EIGD_ND_MERGE")) nd.merge_rounds = std::atoi(e);
   }
   nd.run();
 

@@ -23,6 +23,7 @@ import numpy as np
 from scipy.sparse.linalg import aslinearoperator
 
 from . import adjoint as adj
+from . import tuning
 from .adjoint import DeviceProblem, _is_close
 from .device import DeviceBlock, default_context
 from .operators import SpLuOperator
@@ -577,12 +578,10 @@ class _AdjointAPI:
         device problem for the adjoint stage's deflation.  None if the cut N | N+1 runs through a numerically repeated
         cluster (the reference warns there; nothing is added to what it does).
         """
-        import os
-
         N = self.N
         self.n_extra = 0
         prob.set_extra(None, None)
-        if extra_max <= 0 or os.environ.get("EIGD_DEFLATE_EXTRA", "1") == "0":
+        if extra_max <= 0 or not tuning.deflate_extra:
             return
         idx = []
         for q in range(N, min(N + extra_max, m)):
@@ -649,7 +648,7 @@ class _AdjointAPI:
                 # the solver's own, larger basis (nobody replaced the Lanczos data since solve()): first guess only --
                 # method "laa" itself answers from the m-vector contract basis
                 Vg, mg, th_g, Y_g, idx_g, T_g, C_g, p_g = g
-                if __import__("os").environ.get("EIGD_LAA_RELATION", "1") != "0":
+                if tuning.laa_relation:
                     # ... through the Lanczos relation of that basis: no product with B, no sweep for the guess
                     psi_c = adj._laa_relation_device(prob, Vg, mg, p_g, T_g, C_g, dPhib, lam, self.sigma, Y_g, th_g, idx_g,
                                                      self.mode, cols=cols)
@@ -1042,14 +1041,12 @@ class IRAM(_AdjointAPI):
         """
         (block size p, extra pairs to converge, internal basis size).  A triangular sweep of 4-8 columns costs what a
         one-column sweep costs (it is bound by the latency chain through the tree levels, not by bytes), so large
-        problems run the restarted Lanczos with blocks: several new basis vectors per sweep.  EIGD_IRAM_BLOCK /
-        EIGD_IRAM_EXTRA override (1 / 0 = the single-vector solver on exactly m vectors).
+        problems run the restarted Lanczos with blocks: several new basis vectors per sweep.  tuning.iram_block /
+        tuning.iram_extra override (1 / 0 = the single-vector solver on exactly m vectors).
         """
-        import os
-
         N, m = self.N, self.m
-        p = int(os.environ.get("EIGD_IRAM_BLOCK", "0")) or (8 if n >= 200_000 else (4 if n >= 50_000 else 1))
-        extra = os.environ.get("EIGD_IRAM_EXTRA")
+        p = int(tuning.iram_block) or (8 if n >= 200_000 else (4 if n >= 50_000 else 1))
+        extra = tuning.iram_extra
         # (automatic: as many extra pairs as requested ones, 32 at most -- what fits one 64-column projector next to 32
         # modes; converging more costs the eigensolve more than it saves the adjoint stage)
         extra = int(extra) if extra is not None else (self.extra if self.extra is not None else (0 if p == 1 else min(N, 32)))
@@ -1057,7 +1054,7 @@ class IRAM(_AdjointAPI):
         if p == 1:
             return 1, extra, m
         k_want = N + extra
-        m_int = int(os.environ.get("EIGD_IRAM_BASIS", "0")) or max(m, 2 * k_want + p)
+        m_int = int(tuning.iram_basis) or max(m, 2 * k_want + p)
         m_int = p * (-(-m_int // p))
         if m_int + p > n:
             return 1, min(extra, max(0, m - 1 - N)), m
@@ -1084,11 +1081,10 @@ class IRAM(_AdjointAPI):
         eps = np.finfo(float).eps
         tol = self.tol if self.tol > 0 else eps
         max_restarts = self.maxiter if self.maxiter is not None else min(10 * n, 1000)  # (scipy's default for eigsh: 10 n)
-        tol_x = float(__import__("os").environ.get("EIGD_IRAM_EXTRA_TOL", "1e-11"))
+        tol_x = float(tuning.iram_extra_tol)
 
-        # (fixed start block; EIGD_IRAM_SEED: development aid for noise studies -- the spread of a result over start vectors)
-        V0 = np.random.default_rng(int(__import__("os").environ.get("EIGD_IRAM_SEED", "12345"))).uniform(size=(n, p), low=-1.0,
-                                                                                                      high=1.0)
+        # (fixed start block; tuning.iram_seed: development aid for noise studies -- the spread of a result over start vectors)
+        V0 = np.random.default_rng(int(tuning.iram_seed)).uniform(size=(n, p), low=-1.0, high=1.0)
         dev.start(V0)
 
         def trace(r, nconv, kw, worst):
@@ -1112,7 +1108,7 @@ class IRAM(_AdjointAPI):
         if p == 1 and c == m:
             beta_m = float(C[0, 0])
         else:
-            if __import__("os").environ.get("EIGD_LAA_INTERNAL", "1") != "0":
+            if tuning.laa_internal:
                 # the block run's own basis (c vectors, more than the m of the contract) holds partly converged
                 # approximations of the eigenvectors beyond the converged ones: kept for the Lanczos adjoint
                 # approximation (laa's closed form only uses V^T B V = I and T = V^T B OP V), the better first guess

@@ -1,0 +1,30 @@
+"""
+Solver switches of the host layer.  Plain module attributes: the defaults are the measured best (docs/LOG.md has the
+experiments); tests and probes change them with ``monkeypatch.setattr(eigd_amd.tuning, name, value)``.  None of them
+changes what is computed beyond rounding -- they select between equivalent forms of the same algorithm.
+
+Environment variables the package reads (all optional): EIGD_DEVICE (device of the default context, else LOCAL_RANK),
+EIGD_STREAMS (concurrent mode groups of the lock-step solvers, default 1), EIGD_COMM_DIR / EIGD_COMM_INIT_TIMEOUT
+(rendezvous directory and watchdog of the RCCL communicator), EIGD_TRACE_IRAM (restart log of the block eigensolver);
+bench.py adds EIGD_LAUNCH_TIMEOUT.
+"""
+
+# ---- sibk, lock-step form (adjoint.py)
+recurrence = "auto"        # "auto": conjugate gradients in the factor inner product when the shift is positive definite
+                           # (short recurrence, no Krylov history), else the Arnoldi form; "arnoldi": always the
+                           # reference's form (full Gram-Schmidt against the history, Hessenberg least squares)
+steps_per_pass = 2         # Arnoldi form: Krylov steps per Gram-Schmidt pass (1 = orthogonalise every step)
+inner_projections = False  # Arnoldi form: True keeps the projections behind both operator applications (ref 1250-1252)
+pair_defect_tol = 1e-10    # Arnoldi form: w_{j+1}.w_{j+2} above which a two-step solve is redone in the one-step form
+predict_finish = True      # enqueue the next cycle only for the modes not expected to finish in the current one
+reorth_tol = 1e-13         # measured second Gram-Schmidt pass: applied where |h2| > reorth_tol |h1|
+
+# ---- restarted block Lanczos (lanczos.py)
+iram_block = 0             # block size (0: 8 for n >= 200 000, 4 for n >= 50 000, else the single-vector solver)
+iram_extra = None          # converged pairs beyond N kept for the adjoint stage's deflation (None: min(N, 32) with blocks)
+iram_basis = 0             # internal basis size (0: max(m, 2 (N + extra) + block))
+iram_extra_tol = 1e-11     # convergence tolerance of the extra pairs (relative to |theta|)
+iram_seed = 12345          # seed of the start block
+deflate_extra = True       # the adjoint stage deflates the extra pairs and adds their share of psi in closed form
+laa_internal = True        # the block run's own basis serves the first guess of solve_adjoint
+laa_relation = True        # ... formed through the Lanczos relation of that basis (no factor application)

@@ -1088,34 +1088,6 @@ def test_c3_full_size_properties():
     assert abs(float(dfdx @ p) - fd) < 1e-5 * abs(fd)
 
 
-def test_column_compaction_of_the_krylov_stacks_changes_no_column():
-    """EIGD_COMPACT=1: the live columns move to narrower stacks once half have finished -- same psi, data, histories"""
-    import eigd_amd as eg
-    import eigd_amd.adjoint as adj
-
-    g = load_golden("g4_laplace900_basiclanczos")
-    K, M = csr_from(g, "K"), csr_from(g, "M")
-    fac = eg.SpLuOperator((K + 0.1 * M).tocsc())
-    s = eg.BasicLanczos(N=6, m=60)
-    s.solve(K, M, fac, -0.1)
-    out = {}
-    orig = adj._compact_default
-    try:
-        for flag in (False, True):
-            adj._compact_default = lambda flag=flag: flag
-            hist = []
-            fac.count = 0
-            psi, data = s.solve_adjoint(g["Phib"], method="sibk", rtol=1e-12, lanczos_guess=False, callback=hist.append)
-            out[flag] = (psi, data, hist, fac.count)
-    finally:
-        adj._compact_default = orig
-    assert relerr(out[True][0], out[False][0]) < 1e-12
-    assert index_sets(out[True][1]) == index_sets(out[False][1])
-    assert len(out[True][2]) == len(out[False][2]) and np.allclose(out[True][2], out[False][2], rtol=1e-6, atol=1e-14)
-    assert out[True][3] == out[False][3]
-    assert relerr(out[True][0], g["normal_sibk_psi"]) < 1e-8
-
-
 @pytest.mark.parametrize("mode", ["buckling", "normal"])
 def test_deflating_extra_converged_pairs_leaves_psi_unchanged(monkeypatch, mode):
     """
@@ -1141,7 +1113,7 @@ def test_deflating_extra_converged_pairs_leaves_psi_unchanged(monkeypatch, mode)
     n = B.shape[0]
     P = (B + sigma * A) if mode == "buckling" else (A - sigma * B)
     fac = eg.SpLuOperator(P.tocsr(), ctx=ctx, check_symmetry=False)
-    monkeypatch.setenv("EIGD_IRAM_BLOCK", "4")            # (small problem: the block solver is not the automatic choice)
+    monkeypatch.setattr(eg.tuning, "iram_block", 4)       # (small problem: the block solver is not the automatic choice)
     Phib = rng.uniform(-1, 1, size=(n, N))
     out = {}
     for extra in (0, 9):
@@ -1216,7 +1188,7 @@ def test_first_guess_through_the_lanczos_relation_needs_no_factor_application(mo
     assert relerr(g_rel, g_fac) < 1e-10
     runs = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("EIGD_LAA_RELATION", flag)
+        monkeypatch.setattr(eg.tuning, "laa_relation", flag == "1")
         fac.count = 0
         psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1)
         runs[flag] = (psi, list(s.last_info), fac.count)
@@ -1274,7 +1246,7 @@ def test_lock_step_cycles_follow_predicted_column_ranges_and_survive_wrong_predi
 @pytest.mark.parametrize("mode", ["buckling", "normal"])
 def test_two_krylov_steps_per_gram_schmidt_pass_match_the_one_step_solver(monkeypatch, mode):
     """
-    The lock-step sibk with two operator applications per Gram-Schmidt pass (EIGD_SSTEP=2, the default) against the
+    The lock-step sibk with two operator applications per Gram-Schmidt pass (tuning.steps_per_pass = 2, the default of the Arnoldi form) against the
     one-step form (the reference's loop order, eigenvector_derivatives.py:1246-1260): same iteration count for every
     mode, same residual histories, psi equal far below the 1e-8 of north_star -- odd and even stopping steps, modes that
     are converged before the first step, a maxiter that cuts a cycle in two, more than 32 modes (chunks), and the
@@ -1304,10 +1276,11 @@ def test_two_krylov_steps_per_gram_schmidt_pass_match_the_one_step_solver(monkey
     Phib = rng.uniform(-1, 1, size=(n, N))
     Phib[:, 3] = 0.0                                           # a right-hand side that needs no Krylov step at all
     runs = {}
-    for name, env in (("one", {"EIGD_SSTEP": "1"}), ("two", {"EIGD_SSTEP": "2"}),
-                      ("fallback", {"EIGD_SSTEP": "2", "EIGD_SSTEP_DEFECT_TOL": "-1"})):
+    monkeypatch.setattr(eg.tuning, "recurrence", "arnoldi")   # (the forms compared here are the two Arnoldi forms)
+    for name, env in (("one", {"steps_per_pass": 1}), ("two", {"steps_per_pass": 2}),
+                      ("fallback", {"steps_per_pass": 2, "pair_defect_tol": -1.0})):
         for kname, v in env.items():
-            monkeypatch.setenv(kname, v)
+            monkeypatch.setattr(eg.tuning, kname, v)
         hist = []
         fac.count = 0
         psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, callback=hist.append)
@@ -1315,7 +1288,7 @@ def test_two_krylov_steps_per_gram_schmidt_pass_match_the_one_step_solver(monkey
         from eigd_amd import adjoint as _adj
 
         assert _adj.LAST_ROUND["steps_per_pass"] == (2 if name == "two" else 1), name   # the form asked for (or the fall-back) ran
-        monkeypatch.delenv("EIGD_SSTEP_DEFECT_TOL", raising=False)
+        monkeypatch.setattr(eg.tuning, "pair_defect_tol", 1e-10)
     psi1, data1, info1, hist1, count1 = runs["one"]
     psi2, data2, info2, hist2, count2 = runs["two"]
     assert info2 == info1 and len(set(i % 2 for i in info1 if i)) == 2          # odd and even stopping steps
@@ -1327,20 +1300,19 @@ def test_two_krylov_steps_per_gram_schmidt_pass_match_the_one_step_solver(monkey
     assert count1 == count2 == count3, (count1, count2, count3)               # applications per mode (ref 19-22): an
     # abandoned two-step attempt is not counted on top of the one-step solve that replaces it
     # a maxiter inside a cycle: both forms keep the same best iterates
-    monkeypatch.setenv("EIGD_SSTEP", "1")
+    monkeypatch.setattr(eg.tuning, "steps_per_pass", 1)
     pa, _ = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, maxiter=7, nrestart=0)
-    monkeypatch.setenv("EIGD_SSTEP", "2")
+    monkeypatch.setattr(eg.tuning, "steps_per_pass", 2)
     pb, _ = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, maxiter=7, nrestart=0)
     assert relerr(pb, pa) < 1e-10
     # ONE projection of the raw pair in place of the two behind the operator applications (1250-1252) when the measured
     # invariance of range(P) allows (converged eigenvectors; the default): same counts, same psi as the reference's placement
-    monkeypatch.setenv("EIGD_SSTEP", "2")
     assert _adj.LAST_ROUND["inner_projections"] is False
-    monkeypatch.setenv("EIGD_INNER_PROJ", "1")
+    monkeypatch.setattr(eg.tuning, "inner_projections", True)
     pd, _ = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1)
     assert _adj.LAST_ROUND["inner_projections"] is True and list(s.last_info) == info2
     assert relerr(psi2, pd) < 1e-11
-    monkeypatch.delenv("EIGD_INNER_PROJ")
+    monkeypatch.setattr(eg.tuning, "inner_projections", False)
     # a Krylov history deeper than one coefficient block of the pair kernels (maxiter > 120 at 32 columns): the one-step
     # form is chosen up front, nothing raises in mid-solve
     pc, _ = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, maxiter=130)
