@@ -286,6 +286,7 @@ def main():
     ap.add_argument("--emulate-rank", default=None, help="r/P: time the mode share of rank r of P on this GPU (development aid)")
     ap.add_argument("--trace", default=None, help="write the per-iteration host timeline of one extra step to this file")
     ap.add_argument("--no-fd-check", action="store_true", help="skip the directional finite-difference check of df/dx")
+    ap.add_argument("--no-arnoldi-leg", action="store_true", help="skip the untimed comparison solve in the Arnoldi form")
     ap.add_argument("--dump-dfdx", default=None, help="rank 0 saves the df/dx of the last timed step to this .npy file")
     ap.add_argument("--force-launch", action="store_true",
                     help="start the rank processes through the launcher even for --gpus 1 (test of the launcher)")
@@ -412,6 +413,8 @@ def main():
         _adj.LAST_ROUND["gs_cycles"] = _adj.LAST_ROUND["gs_correcting_passes"] = 0
         _adj.LAST_ROUND["post_gs_projections"] = _adj.LAST_ROUND["post_gs_updates_applied"] = 0
         _adj.LAST_ROUND["cycles_enqueued_for_nothing"] = _adj.LAST_ROUND["cycles_waited_for"] = 0
+        for key in ("cg_steps", "cg_projections", "cg_projection_updates", "cg_sweeps_for_nothing", "cg_waited_for"):
+            _adj.LAST_ROUND[key] = 0
         dpsi, data = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1,
                                           comm=comm, streams=args.streams)
         dfdx = solver.add_total_derivative(lamb, dPhib, dpsi, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data,
@@ -440,6 +443,7 @@ def main():
         elapsed = comm.allreduce_max(elapsed)       # the slowest rank's wall time
     adj_count = factor.count
     last_round = dict(_adj.LAST_ROUND)              # the counters of the last timed step (later legs run more solves)
+    sibk_iterations = [int(i) for i in solver.last_info]
     ms_per_step = 1e3 * elapsed / args.steps
     value = N * args.steps / elapsed
 
@@ -493,6 +497,35 @@ def main():
         pr.disable()
         with open(args.pyprofile, "w") as fh:
             pstats.Stats(pr, stream=fh).sort_stats("cumulative").print_stats(45)
+    # ------------------------------------------------------------------ the Arnoldi form of the same solve, for comparison
+    # (outside the timed region: the reference's recurrence with full Gram-Schmidt, two steps per pass -- round 3's solver)
+    arnoldi_form = None
+    if world == 1 and comm is None and last_round.get("recurrence") == "short" and not args.emulate_rank \
+            and not args.no_arnoldi_leg:
+        import eigd_amd as _eg
+
+        it_short = [int(i) for i in solver.last_info]
+        keep = _eg.tuning.recurrence
+        _eg.tuning.recurrence = "arnoldi"
+        try:
+            step()                                       # (allocates the Krylov stacks)
+            ctx.sync()
+            t0 = time.perf_counter()
+            dpsi_a, _, dfdx_a = step()
+            ctx.sync()
+            t_a = time.perf_counter() - t0
+            it_arn = [int(i) for i in solver.last_info]
+        finally:
+            _eg.tuning.recurrence = keep
+        da, ds = dpsi_a.get(), dpsi.get()
+        arnoldi_form = {"ms_per_step": round(1e3 * t_a, 3), "sibk_iterations": it_arn,
+                        "total_iterations": int(sum(it_arn)), "total_iterations_short_recurrence": int(sum(it_short)),
+                        "psi_rel_diff": float(np.linalg.norm(da - ds) / np.linalg.norm(da)),
+                        "dfdx_rel_diff": float(np.linalg.norm(dfdx_a - dfdx) / np.linalg.norm(dfdx_a))}
+        del da, ds, dpsi_a
+        ctx.release_workspaces()                         # the Krylov stacks of the Arnoldi form (26 GB at C3) go back
+        log(rank, f"Arnoldi form: {arnoldi_form['ms_per_step']} ms/step, iterations {sum(it_arn)} against {sum(it_short)}, "
+                  f"psi rel diff {arnoldi_form['psi_rel_diff']:.1e}")
     # ------------------------------------------------------------------ the reference's call surface: numpy in, numpy out
     # (the timed value keeps the operands resident in HBM; callers of the reference hand numpy arrays to solve_adjoint
     # and add_total_derivative, which adds the H2D of Phib and the D2H / H2D of psi: reported next to the value)
@@ -701,10 +734,14 @@ def main():
         "accuracy": accuracy,
         "preamble_s": {k: round(v, 3) for k, v in timing.items()},
         "factor_sweeps_per_step": int(adj_count),
-        "sibk_iterations": [int(i) for i in solver.last_info],
+        "sibk_iterations": sibk_iterations,
+        "arnoldi_form": arnoldi_form,
         "eigensolve_sweeps": int(eig_count),
         "eigensolver": eig_info,
-        "lock_step": {"steps_per_gram_schmidt_pass": last_round.get("steps_per_pass"),
+        "lock_step": {"recurrence": last_round.get("recurrence"),
+                      "cg": {key[3:]: last_round.get(key) for key in ("cg_steps", "cg_projections", "cg_projection_updates",
+                                                                      "cg_sweeps_for_nothing", "cg_waited_for")},
+                      "steps_per_gram_schmidt_pass": last_round.get("steps_per_pass"),
                       "inner_projections": last_round.get("inner_projections"),
                       "cycles": last_round.get("gs_cycles"),
                       "correcting_gram_schmidt_passes": last_round.get("gs_correcting_passes"),

@@ -77,7 +77,7 @@ _SIGNATURES = {
     "eigd_gemm_tn": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_int, c_vp],
     "eigd_gemm_nn": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_dbl, c_dbl],
     "eigd_project": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int],
-    "eigd_project_norm2": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_dbl],
+    "eigd_project_norm2": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_dbl, c_dbl],
     "eigd_project_stats": [c_vp, c_vp],
     "eigd_svqb_step": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_project_to": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_dbl, c_vp, c_vp],
@@ -104,10 +104,9 @@ _SIGNATURES = {
     "eigd_scale_inv_norm": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp],
     "eigd_copy_block": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_cg_state_rows": [],
-    "eigd_cg_alpha": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp],
-    "eigd_cg_update": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp],
-    "eigd_cg_beta": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int],
-    "eigd_cg_direction": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int],
+    "eigd_cg_coefficients": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int],
+    "eigd_cg_update": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp,
+                       c_int],
     "eigd_gather_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
     "eigd_scatter_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
     "eigd_elem_bilinear": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl,

@@ -106,14 +106,14 @@ class DeviceProblem:
         U, V = self._projector()
         return X.project(U, V)
 
-    def project_r_norm2(self, X):
+    def project_r_norm2(self, X, tol=0.0):
         """project_r followed by the squared column norms of the result (device block; see DeviceBlock.project_norm2)"""
         U, V = self._projector()
         # the measured update compares |u_a| |c_ab| with |x_b|: the largest column norm of U, once per projector
         which = "D" if U is self.BPhiD else "N"
         if self._uscale.get(which) is None:
             self._uscale[which] = float(np.max(U.colnorms()))
-        return X.project_norm2(U, V, uscale=self._uscale[which])
+        return X.project_norm2(U, V, uscale=self._uscale[which], tol=tol)
 
     def project_s(self, X):
         """X <- X - Phi (BPhi^T X)   (solution-side projector P^T)"""
@@ -1004,17 +1004,18 @@ def _short_recurrence_applies(prob):
     return not op._pivoted() and op._imag_dev is None and prob.opA.csr is not None and prob.opB.csr is not None
 
 
-_CG_ROWS = {"rho": 0, "a": 1, "b": 2, "done": 3, "tol2": 4, "alpha": 5, "steps": 6, "flag": 7, "den": 8}
+_CG_ROWS = {"rr": 0, "gam": 1, "rho": 2, "done": 3, "tol2": 4, "alpha": 5, "steps": 6, "flag": 7}
 
 
 def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     """
     All columns of R0 (at most 64) by conjugate gradients in the factor inner product, in lock step.  Same Krylov spaces
     as the Arnoldi form (reference 1246-1277), same stopping rule on the true Euclidean residual (1275), no Krylov
-    history: per step ONE multi-column sweep, one SpMM, one measured projection and four streaming passes over the work
-    blocks; every per-mode scalar stays on the device (krylov.hip), the host reads the residual norms of a step behind
-    the next sweep already in flight.  Returns (update block, converged flags, info list, ok); ok False = a breakdown was
-    flagged (the operator was not positive definite in the deflated space): the caller redoes the solve in the Arnoldi form.
+    history: per step ONE multi-column sweep, one SpMM, one measured projection and three streaming kernels over the
+    work blocks (three-term recurrences for residual and solution, csrc/krylov.hip); every per-mode scalar stays on the
+    device, the host reads the residual norms of a step behind the next step already in flight.  Returns (update block,
+    converged flags, info list, ok); ok False = a breakdown was flagged (the operator was not positive definite in the
+    deflated space): the caller redoes the solve in the Arnoldi form.
     """
     from . import _ffi
     from ._ffi import call
@@ -1045,67 +1046,78 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     st_h[_CG_ROWS["alpha"], :k] = sgn * (np.asarray(lam_c, dtype=float) - sigma)   # ref 1264-1269
     state = ctx.from_host(st_h)
     r = ctx.empty(n, k).copy_from(R0)
-    zr, p, zp, y = ctx.empty(n, k), ctx.zeros(n, k), ctx.zeros(n, k), ctx.empty(n, k)
-
-    def v(block, lo, hi):
-        return block.cols(lo, hi)
+    r_old, psi_old, z, y = ctx.empty(n, k), ctx.zeros(n, k), ctx.empty(n, k), ctx.empty(n, k)
+    # what the measured projection lets pass: a component along B Phi_D of relative size 1e-11 grows by |1 - alpha theta_j|
+    # per step until it is taken out again; psi carries it at that relative size at most, and is projected once at the end
+    proj_tol = 1e-11
 
     def sptr(lo):
         return state.cols(lo, 64).ptr
 
-    def second_half(j, lo, hi, n2, first):
-        """sweep of the residual, rho and b, new directions (no synchronisation)"""
+    def first_part(j, lo, hi, n2, n2_lo):
+        """sweep of the residual of step j - 1, product, coefficients, the two recurrences (no synchronisation)"""
+        nonlocal r, r_old, psi, psi_old
         kk = hi - lo
-        rv, zrv = v(r, lo, hi), v(zr, lo, hi)
-        prob.fac.apply_to(rv, zrv, count=0)               # ref 1248
-        call("eigd_cg_beta", ctx.h, n, kk, rv.ptr, rv.ld, zrv.ptr, zrv.ld, n2.ptr if n2 is not None else None, sptr(lo), int(j),
-             1 if first else 0)
-        pv, zpv = v(p, lo, hi), v(zp, lo, hi)
-        call("eigd_cg_direction", ctx.h, n, kk, pv.ptr, pv.ld, zpv.ptr, zpv.ld, rv.ptr, rv.ld, zrv.ptr, zrv.ld, sptr(lo),
-             1 if first else 0)
+        rv, zv, yv = r.cols(lo, hi), z.cols(lo, hi), y.cols(lo, hi)
+        prob.fac.apply_to(rv, zv, count=0)                # ref 1248
+        Kop.apply(zv, yv)                                 # ref 1250 / 1252
+        n2p = None if n2 is None else n2.cols(lo - n2_lo, hi - n2_lo).ptr
+        call("eigd_cg_coefficients", ctx.h, n, kk, zv.ptr, zv.ld, rv.ptr, rv.ld, yv.ptr, yv.ld, n2p, sptr(lo), int(j),
+             1 if j == 1 else 0)
+        rov, psv, pov = r_old.cols(lo, hi), psi.cols(lo, hi), psi_old.cols(lo, hi)
+        call("eigd_cg_update", ctx.h, n, kk, rv.ptr, rv.ld, rov.ptr, rov.ld, psv.ptr, psv.ld, pov.ptr, pov.ld, zv.ptr, zv.ld,
+             yv.ptr, yv.ld, sptr(lo), 1 if j == 1 else 0)
+        r, r_old = r_old, r                                # (all columns of a block share the parity: the ranges lag one
+        psi, psi_old = psi_old, psi                        # step behind the flags, see below)
 
     lo, hi = _active_range(done)
-    prob.project_r_norm2(v(r, lo, hi))                    # ref 1232 (the caller projected already, 1193: measured)
+    prob.project_r_norm2(r.cols(lo, hi))                  # ref 1232 (the caller projected already, 1193: measured)
     ctx.fetch_colnorm2(hi - lo)
-    second_half(0, lo, hi, None, True)
+    # Pipeline.  Step j = first_part(j) [sweep .. recurrences] + projection of the new residual, whose norms the host
+    # needs to know who has finished.  first_part(j + 1) is put in flight BEFORE the host waits for the norms of step j
+    # (unless every live mode is expected to finish with step j -- its last reduction applied once more, within a factor
+    # of four of the tolerance: a wrong 'finishes' costs a pipeline bubble of ~0.1 ms, a wrong 'goes on' a narrow step of ~1.3 ms --),
+    # on the column range of the modes that were unfinished after step j - 1 (speculative or not): a mode that finishes in
+    # step j is frozen on the device in step j + 1 (its psi copied into both buffers of the recurrence) and leaves the
+    # range in step j + 2, so every column of a block has seen the same number of buffer swaps when it stops moving.
+    first_part(1, lo, hi, None, lo)
+    rng_j = (lo, hi)                                       # range of the step whose projection is next
     nsteps = 0
-    for j in range(1, maxsteps + 1):
-        lo, hi = _active_range(done)
-        kk = hi - lo
-        zpv, pv, yv, rv = v(zp, lo, hi), v(p, lo, hi), v(y, lo, hi), v(r, lo, hi)
-        Kop.apply(zpv, yv)                                # ref 1250 / 1252
-        call("eigd_cg_alpha", ctx.h, n, kk, zpv.ptr, zpv.ld, pv.ptr, pv.ld, yv.ptr, yv.ld, sptr(lo))
-        psv = v(psi, lo, hi)
-        call("eigd_cg_update", ctx.h, n, kk, psv.ptr, psv.ld, rv.ptr, rv.ld, zpv.ptr, zpv.ld, pv.ptr, pv.ld, yv.ptr, yv.ld,
-             sptr(lo))
-        n2 = prob.project_r_norm2(rv)                     # ref 1257 + the residual norm of 1275; measured update
+    j = 1
+    while True:
+        lo, hi = rng_j
+        n2 = prob.project_r_norm2(r.cols(lo, hi), tol=proj_tol)   # ref 1257 + the residual norm of 1275; measured update
         nsteps = j
-        # the sweep of this step's residual is only needed if some mode goes on: when every live mode is expected to
-        # finish with this step (its last reduction applied once more, generous margin) the host looks first
         live = np.flatnonzero(~done)
         expect_all = tuning.predict_finish and j > 1 and all(
-            len(hist[c]) >= 2 and hist[c][-2] > 0.0 and hist[c][-1] * min(hist[c][-1] / hist[c][-2], 1.0) < 0.25 * tol
+            len(hist[c]) >= 2 and hist[c][-2] > 0.0 and hist[c][-1] * min(hist[c][-1] / hist[c][-2], 1.0) < 4.0 * tol
             for c in live)
+        nxt = _active_range(done)                          # (flags after step j - 1)
         in_flight = False
         if j < maxsteps and not expect_all:
-            second_half(j, lo, hi, n2, False)
+            # (the pinned copy of the norms was issued behind the projection: nothing enqueued here overwrites it)
+            first_part(j + 1, nxt[0], nxt[1], n2, lo)
             in_flight = True
-        norms2 = ctx.fetch_colnorm2(kk)
+        norms2 = ctx.fetch_colnorm2(hi - lo)
         for c in range(lo, hi):
             if done[c]:
                 continue
             hist[c].append(float(np.sqrt(max(norms2[c - lo], 0.0))))
-            if norms2[c - lo] < tol2:                     # ref 1275 (the comparison the device makes in eigd_cg_beta)
+            if norms2[c - lo] < tol2:                     # ref 1275 (the comparison the device makes in eigd_cg_coefficients)
                 info[c] = j
                 done[c] = converged[c] = True
         if done.all() or j == maxsteps:
+            # (a step in flight behind the last one only copies: every column is frozen by then, both buffers hold psi)
             LAST_ROUND["cg_sweeps_for_nothing"] = LAST_ROUND.get("cg_sweeps_for_nothing", 0) + int(in_flight)
             break
         if not in_flight:
             LAST_ROUND["cg_waited_for"] = LAST_ROUND.get("cg_waited_for", 0) + 1
-            second_half(j, lo, hi, n2, False)
+            first_part(j + 1, nxt[0], nxt[1], n2, lo)
+        rng_j = nxt
+        j += 1
     st = state.get()
-    ok = not np.any(st[_CG_ROWS["flag"], :k] != 0.0) and bool(np.all(np.isfinite(st[_CG_ROWS["rho"], :k])))
+    ok = not np.any(st[_CG_ROWS["flag"], :k] != 0.0) and bool(np.all(np.isfinite(st[_CG_ROWS["rr"], :k])))
+    prob.project_s(psi)                                    # what the measured projections let pass (see proj_tol)
     if prob.fac.native and ok:                            # one factor application per step and mode (ref 1248)
         with prob.fac.factor._count_lock:
             prob.fac.factor.count += int(sum((i if i is not None else nsteps) for i in info))

@@ -1076,7 +1076,7 @@ int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu
 static int publish_norm2(eigd_ctx* ctx, const double* dOut, int k);
 
 int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv,
-                       double* dX, int ldx, double* dOut, double uscale) {
+                       double* dX, int ldx, double* dOut, double uscale, double tol) {
   EIGD_REQUIRE(ctx && dU && dV && dX && dOut, "null argument");
   EIGD_REQUIRE(uscale >= 0.0, "uscale = largest Euclidean column norm of U (0: unknown, taken as 1)");
   EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= 2 * kMaxK && kx >= 1 && kx <= kMaxK && ldx >= kx && ldu >= ku && ldv >= ku,
@@ -1084,11 +1084,12 @@ int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, i
   // The projection behind a Gram-Schmidt step (reference 1257) meets a block that is already B-orthogonal to Phi up to
   // rounding: the vectors it was built from were projected before.  Whether the update X -= U (V^T X) matters is
   // MEASURED: the coefficient pass delivers the squared column norms of X as well, a one-workgroup kernel compares
-  // every coefficient with tol * |x_b| / uscale (tol = 1e-13; uscale = the
+  // every coefficient with tol * |x_b| / uscale (tol: 1e-13 unless the caller says otherwise; uscale = the
   // largest Euclidean column norm of U, so that what is compared is the size of the update |u_a| |c_ab| against |x_b|
   // whatever the scale of the inner product), and the update pass -- the stream of U and two passes over X -- returns
   // at once when none does; the norms of the pass already made are then the result.
-  constexpr double skip_tol = 1e-13;
+  EIGD_REQUIRE(tol >= 0.0, "tol = relative size of an update that matters (0: the default, 1e-13)");
+  const double skip_tol = tol > 0.0 ? tol : 1e-13;
   constexpr bool measured = true;
   // scratch: [C tile (<= kMaxK x kx)] [partials of C, later the partial squared norms]
   const int nbd = grid_for_rows(n, 64);

@@ -5,20 +5,23 @@
 // (eigd/eigenvector_derivatives.py:1246-1277).  With F symmetric positive definite, OP is self-adjoint in the F inner
 // product <u, v>_F = u^T F v and C_i = I - alpha_i OP (alpha_i = +-(lam_i - sigma), 1264-1269) is positive definite there
 // once every eigenpair with lam_j <= lam_i is deflated by P -- the N requested pairs are.  The Krylov space is the same;
-// conjugate gradients in that inner product needs no history:
+// conjugate gradients in that inner product needs no history.  The iterates are formed by the three-term recurrences
+// (Rutishauser's form of CG: residual and solution directly, no direction vectors -- 11 streaming passes over the work
+// blocks per step where the two-term form with p, F p needs 18; same iterates, measured: same step counts and psi):
 //
-//     r = b,  zr = F r,  p = r,  zp = zr,  rho = r.zr
-//     y = K zp                                       (SpMM, 1250-1252)
-//     a = rho / (zp.p - alpha zp.y)                  (= rho / <p, C p>_F)
-//     psi += a zp;   r -= a (p - alpha y);   r <- P r   (1257; |r| is the true Euclidean residual of 1275)
-//     zr = F r                                       (the sweep, 1248)
-//     rho' = r.zr;  b = rho'/rho;  p = r + b p;  zp = zr + b zp
+//     z = F r_k                                         (the sweep, 1248)
+//     y = K z                                           (SpMM, 1250-1252)
+//     rr = r_k.z,  gam = rr / (rr - alpha z.y)          (= <r,r>_F / <r, C r>_F)
+//     rho = 1 / (1 - (gam/gam') (rr/rr') / rho')        (primes: previous step; rho = 1 in the first)
+//     r_{k+1}   = rho (r_k - gam (r_k - alpha y)) + (1 - rho) r_{k-1};   r_{k+1} <- P r_{k+1}   (1257)
+//     psi_{k+1} = rho (psi_k + gam z)             + (1 - rho) psi_{k-1}
 //
-// All modes advance in lock step as columns of n x k row-major blocks; every scalar above is a per-column number that
-// never leaves the device: state[row][column], rows below.  A column is frozen (a = b = 0) from the step on in which its
-// residual norm meets the tolerance, so its psi does not depend on how long its block mates run.
-// The kernels are single streaming passes (HBM bound); cross-workgroup sums go through partial slabs that ONE workgroup
-// adds in a fixed order and turns into the coefficients in the same launch.  No atomics: bitwise reproducible.
+// |r_{k+1}| is the true Euclidean residual norm of 1275.  All modes advance in lock step as columns of n x k row-major
+// blocks; every scalar above is a per-column number that never leaves the device: state[row][column], rows below.  A
+// column is frozen from the step on in which its residual norm meets the tolerance, so its psi does not depend on how
+// long its block mates run.  The kernels are single streaming passes (HBM bound); cross-workgroup sums go through partial
+// slabs that ONE workgroup adds in a fixed order and turns into the coefficients in the same launch.  No atomics:
+// bitwise reproducible.
 #include <algorithm>
 #include <cstdint>
 #include <type_traits>
@@ -28,7 +31,8 @@
 namespace eigd {
 
 // rows of the per-column state block (leading dimension kMaxK)
-enum CgRow { kRho = 0, kA = 1, kB = 2, kDone = 3, kTol2 = 4, kAlpha = 5, kSteps = 6, kFlag = 7, kDen = 8, kCgRows = 9 };
+enum CgRow { kRr = 0, kGam = 1, kRho = 2, kDone = 3, kTol2 = 4, kAlpha = 5, kSteps = 6, kFlag = 7, kGamNow = 8, kRhoNow = 9,
+             kCgRows = 10 };
 
 constexpr int kCgMaxBlocks = 1024;
 
@@ -56,11 +60,11 @@ __device__ __forceinline__ double wave_sum_partials(const double* __restrict__ p
   return __shfl(s, 0, 64);
 }
 
-// partial sums of up to two column-wise dot products with a shared left factor: X.Y1 and X.Y2
-template <int KP, int NQ>
-__global__ __launch_bounds__(kThreads) void cg_dots_kernel(int n, int k, const double* __restrict__ X, int ldx,
-                                                          const double* __restrict__ Y1, int ld1,
-                                                          const double* __restrict__ Y2, int ld2,
+// partial sums of z.r and z.y, one pass over the three blocks
+template <int KP>
+__global__ __launch_bounds__(kThreads) void cg_dots_kernel(int n, int k, const double* __restrict__ Z, int ldz,
+                                                          const double* __restrict__ R, int ldr,
+                                                          const double* __restrict__ Y, int ldy,
                                                           double* __restrict__ partial) {
   constexpr int RP = kThreads / KP;
   __shared__ double red[kThreads];
@@ -68,26 +72,27 @@ __global__ __launch_bounds__(kThreads) void cg_dots_kernel(int n, int k, const d
   double s1 = 0.0, s2 = 0.0;
   if (c < k)
     for (int64_t r = static_cast<int64_t>(blockIdx.x) * RP + rr; r < n; r += static_cast<int64_t>(gridDim.x) * RP) {
-      const double x = X[r * ldx + c];
-      s1 += x * Y1[r * ld1 + c];
-      if (NQ > 1) s2 += x * Y2[r * ld2 + c];
+      const double z = Z[r * ldz + c];
+      s1 += z * R[r * ldr + c];
+      s2 += z * Y[r * ldy + c];
     }
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
+  for (int q = 0; q < 2; ++q) {
     red[threadIdx.x] = (q == 0) ? s1 : s2;
     __syncthreads();
     if (rr == 0 && c < k) {
       double t = 0.0;
       for (int z = 0; z < RP; ++z) t += red[z * KP + c];
-      partial[(static_cast<int64_t>(blockIdx.x) * NQ + q) * k + c] = t;
+      partial[(static_cast<int64_t>(blockIdx.x) * 2 + q) * k + c] = t;
     }
     __syncthreads();
   }
 }
 
-// one workgroup: the partial sums of zp.p and zp.y -> a = rho / (zp.p - alpha zp.y) per column
-__global__ __launch_bounds__(kThreads) void cg_alpha_kernel(const double* __restrict__ partial, int nblocks, int k,
-                                                           double* __restrict__ state) {
+// one workgroup: |r_k|^2 against the tolerance -> done, step; the partial sums -> gam, rho of this step
+__global__ __launch_bounds__(kThreads) void cg_coef_kernel(const double* __restrict__ partial, int nblocks, int k,
+                                                          const double* __restrict__ norm2, double* __restrict__ state,
+                                                          int step, int first) {
   __shared__ double sums[2 * kMaxK];
   const int wave = threadIdx.x >> 6;
   for (int o = wave; o < 2 * k; o += kThreads / 64) {
@@ -97,95 +102,70 @@ __global__ __launch_bounds__(kThreads) void cg_alpha_kernel(const double* __rest
   __syncthreads();
   const int c = threadIdx.x;
   if (c >= k) return;
-  const double den = sums[c] - state[kAlpha * kMaxK + c] * sums[k + c];
-  const double rho = state[kRho * kMaxK + c];
-  const bool done = state[kDone * kMaxK + c] != 0.0;
-  double a = 0.0;
-  if (!done) {
-    // <p, C p>_F must be positive: the operator is positive definite in the deflated space.  Anything else (an
-    // eigenvalue below lam_i that is not deflated, an indefinite factor) is reported; the caller falls back to the
-    // Arnoldi form.  rho == 0: the residual vanished exactly, nothing left to do for this column.
-    if (den > 0.0 && rho >= 0.0)
-      a = rho / den;
-    else if (rho != 0.0)
-      state[kFlag * kMaxK + c] = 1.0;
-  }
-  state[kA * kMaxK + c] = a;
-  state[kDen * kMaxK + c] = den;
-}
-
-// psi += a zp;  r -= a (p - alpha y)
-template <int KP>
-__global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, int k, double* __restrict__ psi, int ldpsi,
-                                                            double* __restrict__ r, int ldr,
-                                                            const double* __restrict__ zp, int ldzp,
-                                                            const double* __restrict__ p, int ldp,
-                                                            const double* __restrict__ y, int ldy,
-                                                            const double* __restrict__ state) {
-  constexpr int RP = kThreads / KP;
-  const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
-  if (c >= k) return;
-  const double a = state[kA * kMaxK + c];
-  if (a == 0.0) return;  // frozen column: nothing moves (and whatever its work blocks hold is never read)
-  const double al = state[kAlpha * kMaxK + c];
-  for (int64_t row = static_cast<int64_t>(blockIdx.x) * RP + rr; row < n; row += static_cast<int64_t>(gridDim.x) * RP) {
-    const double zv = zp[row * ldzp + c], pv = p[row * ldp + c], yv = y[row * ldy + c];
-    const double rv = r[row * ldr + c], sv = psi[row * ldpsi + c];
-    psi[row * ldpsi + c] = sv + a * zv;
-    r[row * ldr + c] = rv - a * (pv - al * yv);
-  }
-}
-
-// one workgroup: |r|^2 against the tolerance -> done, steps; the partial sums of r.zr -> rho' ; b = rho' / rho
-__global__ __launch_bounds__(kThreads) void cg_beta_kernel(const double* __restrict__ partial, int nblocks, int k,
-                                                          const double* __restrict__ norm2, double* __restrict__ state,
-                                                          int step, int first) {
-  __shared__ double sums[kMaxK];
-  const int wave = threadIdx.x >> 6;
-  for (int o = wave; o < k; o += kThreads / 64) {
-    const double s = wave_sum_partials(partial, nblocks, k, o);
-    if ((threadIdx.x & 63) == 0) sums[o] = s;
-  }
-  __syncthreads();
-  const int c = threadIdx.x;
-  if (c >= k) return;
   bool done = state[kDone * kMaxK + c] != 0.0;
-  if (!done && norm2 != nullptr && norm2[c] < state[kTol2 * kMaxK + c]) {  // reference 1275 (1223-1225 for step 0)
+  if (!done && norm2 != nullptr && norm2[c] < state[kTol2 * kMaxK + c]) {  // reference 1275: the residual this step started from
     done = true;
     state[kDone * kMaxK + c] = 1.0;
-    state[kSteps * kMaxK + c] = static_cast<double>(step);
+    state[kSteps * kMaxK + c] = static_cast<double>(step - 1);
   }
-  const double rho_new = sums[c], rho_old = state[kRho * kMaxK + c];
-  double b = 0.0;
-  if (!done && !first && rho_old > 0.0) b = rho_new / rho_old;
+  double gam = 0.0, rho = 1.0;
   if (!done) {
-    if (rho_new < 0.0) state[kFlag * kMaxK + c] = 1.0;  // r^T F r < 0: the factor is not positive definite
-    state[kRho * kMaxK + c] = rho_new;
+    const double rr = sums[c];
+    const double den = rr - state[kAlpha * kMaxK + c] * sums[k + c];  // <r, C r>_F
+    // rr = r^T F r and <r, C r>_F must be positive: F is positive definite and so is C in the deflated space.  Anything
+    // else (an eigenvalue below lam_i that is not deflated, an indefinite factor) is reported; the caller falls back
+    // to the Arnoldi form.  rr == 0: the residual vanished exactly, nothing left to do for this column.
+    if (rr > 0.0 && den > 0.0) {
+      gam = rr / den;
+      if (!first) {
+        const double q = 1.0 - (gam / state[kGam * kMaxK + c]) * (rr / state[kRr * kMaxK + c]) / state[kRho * kMaxK + c];
+        if (q > 0.0)
+          rho = 1.0 / q;
+        else
+          state[kFlag * kMaxK + c] = 1.0;
+      }
+      state[kRr * kMaxK + c] = rr;
+      state[kGam * kMaxK + c] = gam;
+      state[kRho * kMaxK + c] = rho;
+    } else if (rr != 0.0) {
+      state[kFlag * kMaxK + c] = 1.0;
+    }
   }
-  state[kB * kMaxK + c] = b;
+  state[kGamNow * kMaxK + c] = gam;  // gam == 0: the column does not move in this step
+  state[kRhoNow * kMaxK + c] = rho;
 }
 
-// p = r + b p;  zp = zr + b zp   (first step: b = 0, p and zp need not be initialised)
+// r_{k+1} = rho (r - gam (r - alpha y)) + (1 - rho) r_old  and  psi_{k+1} = rho (psi + gam z) + (1 - rho) psi_old, written
+// over r_old / psi_old (the caller swaps the roles of the buffers); columns that do not move are copied
 template <int KP>
-__global__ __launch_bounds__(kThreads) void cg_direction_kernel(int n, int k, double* __restrict__ p, int ldp,
-                                                               double* __restrict__ zp, int ldzp,
-                                                               const double* __restrict__ r, int ldr,
-                                                               const double* __restrict__ zr, int ldzr,
-                                                               const double* __restrict__ state, int first) {
+__global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, int k, const double* __restrict__ r, int ldr,
+                                                            double* __restrict__ ro, int ldro,
+                                                            const double* __restrict__ psi, int ldpsi,
+                                                            double* __restrict__ pso, int ldpso,
+                                                            const double* __restrict__ z, int ldz,
+                                                            const double* __restrict__ y, int ldy,
+                                                            const double* __restrict__ state, int first) {
   constexpr int RP = kThreads / KP;
   const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
   if (c >= k) return;
-  if (state[kDone * kMaxK + c] != 0.0 && !first) return;  // frozen column
-  const double b = state[kB * kMaxK + c];
+  const double gam = state[kGamNow * kMaxK + c], rho = state[kRhoNow * kMaxK + c];
+  const double al = state[kAlpha * kMaxK + c];
+  const bool moves = gam != 0.0;
+  const bool three = moves && !first && rho != 1.0;
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * RP + rr; row < n; row += static_cast<int64_t>(gridDim.x) * RP) {
-    const double rv = r[row * ldr + c], zv = zr[row * ldzr + c];
-    if (first || b == 0.0) {
-      p[row * ldp + c] = rv;
-      zp[row * ldzp + c] = zv;
-    } else {
-      p[row * ldp + c] = rv + b * p[row * ldp + c];
-      zp[row * ldzp + c] = zv + b * zp[row * ldzp + c];
+    const double rv = r[row * ldr + c], sv = psi[row * ldpsi + c];
+    double rn = rv, sn = sv;
+    if (moves) {
+      const double zv = z[row * ldz + c], yv = y[row * ldy + c];
+      rn = rv - gam * (rv - al * yv);
+      sn = sv + gam * zv;
+      if (three) {
+        rn = rho * rn + (1.0 - rho) * ro[row * ldro + c];
+        sn = rho * sn + (1.0 - rho) * pso[row * ldpso + c];
+      }
     }
+    ro[row * ldro + c] = rn;
+    pso[row * ldpso + c] = sn;
   }
 }
 
@@ -213,71 +193,37 @@ extern "C" {
 
 int eigd_cg_state_rows(void) { return kCgRows; }
 
-int eigd_cg_alpha(eigd_ctx* ctx, int n, int k, const double* dZp, int ldzp, const double* dP, int ldp, const double* dY,
-                  int ldy, double* dState) {
-  EIGD_REQUIRE(ctx && dZp && dP && dY && dState, "null argument");
-  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldzp >= k && ldp >= k && ldy >= k, "bad shape n=%d k=%d", n, k);
+int eigd_cg_coefficients(eigd_ctx* ctx, int n, int k, const double* dZ, int ldz, const double* dR, int ldr, const double* dY,
+                         int ldy, const double* dNorm2, double* dState, int step, int first) {
+  EIGD_REQUIRE(ctx && dZ && dR && dY && dState, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldz >= k && ldr >= k && ldy >= k, "bad shape n=%d k=%d", n, k);
   const int kp = next_pow2(k);
   const int nb = cg_grid(n, (kThreads / kp) * 8);
   int rc = ctx->ensure_scratch(sizeof(double) * static_cast<size_t>(nb) * 2 * k);
   if (rc) return rc;
   double* partial = ctx->scratch;
   rc = cg_dispatch_kp(k, [&](auto KP) {
-    hipLaunchKernelGGL((cg_dots_kernel<decltype(KP)::value, 2>), dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dZp, ldzp, dP,
-                       ldp, dY, ldy, partial);
+    hipLaunchKernelGGL(cg_dots_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dZ, ldz, dR, ldr,
+                       dY, ldy, partial);
   });
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, partial, nb, k, dState);
+  hipLaunchKernelGGL(cg_coef_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, partial, nb, k, dNorm2, dState, step, first);
   EIGD_LAUNCH_CHECK();
   return EIGD_OK;
 }
 
-int eigd_cg_update(eigd_ctx* ctx, int n, int k, double* dPsi, int ldpsi, double* dR, int ldr, const double* dZp, int ldzp,
-                   const double* dP, int ldp, const double* dY, int ldy, const double* dState) {
-  EIGD_REQUIRE(ctx && dPsi && dR && dZp && dP && dY && dState, "null argument");
-  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldpsi >= k && ldr >= k && ldzp >= k && ldp >= k && ldy >= k,
+int eigd_cg_update(eigd_ctx* ctx, int n, int k, const double* dR, int ldr, double* dRold, int ldro, const double* dPsi,
+                   int ldpsi, double* dPsiOld, int ldpso, const double* dZ, int ldz, const double* dY, int ldy,
+                   const double* dState, int first) {
+  EIGD_REQUIRE(ctx && dR && dRold && dPsi && dPsiOld && dZ && dY && dState, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldr >= k && ldro >= k && ldpsi >= k && ldpso >= k && ldz >= k && ldy >= k,
                "bad shape n=%d k=%d", n, k);
   const int kp = next_pow2(k);
   const int nb = cg_grid(n, (kThreads / kp) * 4);
   int rc = cg_dispatch_kp(k, [&](auto KP) {
-    hipLaunchKernelGGL(cg_update_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dPsi, ldpsi, dR,
-                       ldr, dZp, ldzp, dP, ldp, dY, ldy, dState);
-  });
-  if (rc) return rc;
-  EIGD_LAUNCH_CHECK();
-  return EIGD_OK;
-}
-
-int eigd_cg_beta(eigd_ctx* ctx, int n, int k, const double* dR, int ldr, const double* dZr, int ldzr, const double* dNorm2,
-                 double* dState, int step, int first) {
-  EIGD_REQUIRE(ctx && dR && dZr && dState, "null argument");
-  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldr >= k && ldzr >= k, "bad shape n=%d k=%d", n, k);
-  const int kp = next_pow2(k);
-  const int nb = cg_grid(n, (kThreads / kp) * 8);
-  int rc = ctx->ensure_scratch(sizeof(double) * static_cast<size_t>(nb) * k);
-  if (rc) return rc;
-  double* partial = ctx->scratch;
-  rc = cg_dispatch_kp(k, [&](auto KP) {
-    hipLaunchKernelGGL((cg_dots_kernel<decltype(KP)::value, 1>), dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dR, ldr, dZr,
-                       ldzr, dZr, ldzr, partial);
-  });
-  if (rc) return rc;
-  EIGD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, partial, nb, k, dNorm2, dState, step, first);
-  EIGD_LAUNCH_CHECK();
-  return EIGD_OK;
-}
-
-int eigd_cg_direction(eigd_ctx* ctx, int n, int k, double* dP, int ldp, double* dZp, int ldzp, const double* dR, int ldr,
-                      const double* dZr, int ldzr, const double* dState, int first) {
-  EIGD_REQUIRE(ctx && dP && dZp && dR && dZr && dState, "null argument");
-  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldp >= k && ldzp >= k && ldr >= k && ldzr >= k, "bad shape n=%d k=%d", n, k);
-  const int kp = next_pow2(k);
-  const int nb = cg_grid(n, (kThreads / kp) * 4);
-  int rc = cg_dispatch_kp(k, [&](auto KP) {
-    hipLaunchKernelGGL(cg_direction_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dP, ldp, dZp,
-                       ldzp, dR, ldr, dZr, ldzr, dState, first);
+    hipLaunchKernelGGL(cg_update_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dR, ldr, dRold,
+                       ldro, dPsi, ldpsi, dPsiOld, ldpso, dZ, ldz, dY, ldy, dState, first);
   });
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();

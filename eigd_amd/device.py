@@ -495,15 +495,16 @@ class DeviceBlock:
              flag.ptr, 1 if update_bx else 0)
         return self
 
-    def project_norm2(self, U, V, uscale=0.0):
+    def project_norm2(self, U, V, uscale=0.0, tol=0.0):
         """project(U, V), then the squared column norms of the result: as colnorm2_dev (device block + pinned copy for
         ctx.fetch_colnorm2), but formed while the projection writes the block -- no extra pass over it.  ``uscale``: the
-        largest Euclidean column norm of U (makes the measured update independent of the scale of the inner product)"""
+        largest Euclidean column norm of U (makes the measured update independent of the scale of the inner product);
+        ``tol``: relative size of an update that matters (0: 1e-13)"""
         if U.k > 128 or self.k > 64:
             return self.project(U, V).colnorm2_dev()
         out = self.ctx.empty(1, self.k)
         call("eigd_project_norm2", self.ctx.h, self.n, U.k, self.k, U.ptr, U.ld, V.ptr, V.ld, self.ptr, self.ld, out.ptr,
-             float(uscale))
+             float(uscale), float(tol))
         return out
 
     def gather_cols(self, cols):

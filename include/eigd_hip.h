@@ -158,13 +158,13 @@ int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu
 /* the projector followed by the squared column norms of the result (1257 + 1259 of sibk in one pass over X):
  * dOut (device, kx) receives them; a pinned copy is left for eigd_colnorm2_fetch as after eigd_colnorm2_dev.
  * The update pass is MEASURED: the coefficient pass also forms the column norms of X, and when no coefficient exceeds
- * 1e-13 times the norm of its column divided by uscale -- the block was built
+ * tol (0: 1e-13) times the norm of its column divided by uscale -- the block was built
  * from projected vectors -- X is left as it is and those norms are the result.  uscale = the largest Euclidean column
  * norm of U (0: unknown, 1 is used): the test then compares the size of the update, |u_a| |C[a][b]|, with |x_b| and does
  * not depend on how B scales against the Euclidean norm.  eigd_project_stats: out[0] = projections measured,
  * out[1] = updates applied since the last call (resets both). */
 int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv,
-                       double* dX, int ldx, double* dOut, double uscale);
+                       double* dX, int ldx, double* dOut, double uscale, double tol);
 int eigd_project_stats(eigd_ctx* ctx, int* out);
 /* One step of block Gram-Schmidt against a panel of the Lanczos basis with the coefficients KEPT ON THE DEVICE (the
  * restarted block eigensolver that stands in for ARPACK's dsaitr reorthogonalisation, eigenvector_derivatives.py:1908-
@@ -237,24 +237,23 @@ int eigd_scale_inv_norm(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, 
  * For a positive definite shift the Krylov operator P K factor of sibk (eigenvector_derivatives.py:1246-1252) is
  * self-adjoint in the inner product of the factor and I - alpha_i OP is positive definite in the deflated space: the
  * Arnoldi process with its Gram-Schmidt loops (1254-1260) and the least-squares problem (1262-1270) collapse to
- * conjugate gradients in that inner product, one multi-column step per factor application, no Krylov history.
- * All per-mode scalars live in dState (device, eigd_cg_state_rows() rows of 64 doubles, one column per mode:
- * rho, a, b, done, tol^2, alpha_i = +-(lam_i - sigma) of 1264-1269, step at which the mode met 1275, breakdown flag,
- * <p, C p>); the caller passes dState + first column of the block it works on.
- *   eigd_cg_alpha     a = rho / (zp.p - alpha zp.y)  with y = K zp            (0 for finished modes)
- *   eigd_cg_update    psi += a zp;  r -= a (p - alpha y)                      (psi of 1277, the residual of 1275)
- *   eigd_cg_beta      dNorm2 (device, |r|^2 per column from eigd_project_norm2, or null) < tol^2 -> done, step;
- *                     rho' = r.zr with zr = factor(r) (1248);  b = rho'/rho (0 when first != 0);  rho = rho'
- *   eigd_cg_direction p = r + b p;  zp = zr + b zp                            (first != 0: p = r, zp = zr) */
+ * conjugate gradients in that inner product (three-term form: residual and solution directly), one multi-column step
+ * per factor application, no Krylov history.  All per-mode scalars live in dState (device, eigd_cg_state_rows() rows of
+ * 64 doubles, one column per mode: r.z, gam, rho of the previous step, done, tol^2, alpha_i = +-(lam_i - sigma) of
+ * 1264-1269, steps taken when the mode met 1275, breakdown flag, gam and rho of the current step); the caller passes
+ * dState + first column of the block it works on.
+ *   eigd_cg_coefficients  dNorm2 (device, |r_k|^2 per column from eigd_project_norm2, or null) < tol^2 -> done;
+ *                         with z = factor(r_k) (1248) and y = K z (1250-1252): gam = r.z / (r.z - alpha z.y) and
+ *                         rho = 1 / (1 - (gam/gam')(r.z / r'.z') / rho')  (rho = 1 when first != 0)
+ *   eigd_cg_update        r_old <- rho (r - gam (r - alpha y)) + (1 - rho) r_old,
+ *                         psi_old <- rho (psi + gam z) + (1 - rho) psi_old  (psi of 1277; finished modes: copies) --
+ *                         the caller swaps the roles of the two buffers afterwards */
 int eigd_cg_state_rows(void);
-int eigd_cg_alpha(eigd_ctx* ctx, int n, int k, const double* dZp, int ldzp, const double* dP, int ldp, const double* dY,
-                  int ldy, double* dState);
-int eigd_cg_update(eigd_ctx* ctx, int n, int k, double* dPsi, int ldpsi, double* dR, int ldr, const double* dZp, int ldzp,
-                   const double* dP, int ldp, const double* dY, int ldy, const double* dState);
-int eigd_cg_beta(eigd_ctx* ctx, int n, int k, const double* dR, int ldr, const double* dZr, int ldzr, const double* dNorm2,
-                 double* dState, int step, int first);
-int eigd_cg_direction(eigd_ctx* ctx, int n, int k, double* dP, int ldp, double* dZp, int ldzp, const double* dR, int ldr,
-                      const double* dZr, int ldzr, const double* dState, int first);
+int eigd_cg_coefficients(eigd_ctx* ctx, int n, int k, const double* dZ, int ldz, const double* dR, int ldr, const double* dY,
+                         int ldy, const double* dNorm2, double* dState, int step, int first);
+int eigd_cg_update(eigd_ctx* ctx, int n, int k, const double* dR, int ldr, double* dRold, int ldro, const double* dPsi,
+                   int ldpsi, double* dPsiOld, int ldpso, const double* dZ, int ldz, const double* dY, int ldy,
+                   const double* dState, int first);
 /* copy an n x k block between buffers with different leading dimensions / column offsets */
 int eigd_copy_block(eigd_ctx* ctx, int n, int k, const double* dSrc, int lds, double* dDst, int ldd);
 /* gather columns: Dst[r, j] = Src[r, cols[j]] (compaction of the active modes) */

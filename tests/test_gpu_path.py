@@ -1221,6 +1221,7 @@ def test_lock_step_cycles_follow_predicted_column_ranges_and_survive_wrong_predi
     Phib = np.random.default_rng(7).uniform(-1, 1, size=(B.shape[0], N))
     hooks = {"default": None, "all finish": lambda c, v: True, "edges finish": lambda c, v: c in (0, 1, N - 1),
              "nobody finishes": lambda c, v: False}
+    monkeypatch.setattr(eg.tuning, "recurrence", "arnoldi")    # (the cycle pipeline of the Arnoldi form)
     runs = {}
     for name, hook in hooks.items():
         monkeypatch.setattr(_adj, "_PREDICT_HOOK", hook)

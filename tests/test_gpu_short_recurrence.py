@@ -1,0 +1,167 @@
+"""
+sibk in short-recurrence form (conjugate gradients in the inner product of the factor, csrc/krylov.hip) against the
+Arnoldi form that restates the reference's loop (eigd/eigenvector_derivatives.py:1246-1277), against the reference's
+own psi in the golden fixtures, and against the CPU oracle.  Tolerance on psi: 1e-8 relative (north_star).
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import corr_from, csr_from, index_sets, load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-8
+
+
+def _adopt(s, g, prefix=""):
+    m = int(g[prefix + "m"])
+    if hasattr(s, "lam0"):
+        s.lam0 = g[prefix + "lam"].copy()
+    else:
+        s.lam = g[prefix + "lam"].copy()
+    s.Phi = g[prefix + "Phi"].copy()
+    s.m = s._m = m
+    s.V = g[prefix + "V"]
+    s.Y, s.theta = g[prefix + "Y"].copy(), g[prefix + "theta"].copy()
+    s.indices, s.T = g[prefix + "indices"].copy(), g[prefix + "T"].copy()
+
+
+def _both_forms(monkeypatch, solve):
+    """run ``solve()`` (-> psi, data, info, history) in both forms; checks which form ran"""
+    import eigd_amd as eg
+    from eigd_amd import adjoint as adj
+
+    out = {}
+    for form in ("auto", "arnoldi"):
+        monkeypatch.setattr(eg.tuning, "recurrence", form)
+        out[form] = solve()
+        assert adj.LAST_ROUND["recurrence"] == ("short" if form == "auto" else "arnoldi"), adj.LAST_ROUND["recurrence"]
+    return out["auto"], out["arnoldi"]
+
+
+@pytest.mark.parametrize("case", ["g1_buckling", "g4_normal", "g4_buckling", "g2_normal", "g3_repeated"])
+def test_short_recurrence_reproduces_the_reference_psi_and_the_arnoldi_form(monkeypatch, case):
+    import eigd_amd as eg
+
+    first = 0
+    if case == "g1_buckling":
+        g = load_golden("g1_buckling50_basiclanczos")
+        A, B, mode, p = csr_from(g, "G"), csr_from(g, "K"), "buckling", ""
+        sigma, N, rhs, want, corr = float(g["sigma"]), 6, g["Qrb"], g["psir"], corr_from(g, "corr")
+    elif case.startswith("g4"):
+        g = load_golden("g4_laplace900_basiclanczos")
+        K, M = csr_from(g, "K"), csr_from(g, "M")
+        mode = case.split("_")[1]
+        A, B = (K, M) if mode == "normal" else ((-0.005 * M).tocsr(), K)
+        p = mode + "_"
+        sigma, N, rhs, want, corr = float(g[p + "sigma"]), 6, g["Phib"], g[p + "sibk_psi"], corr_from(g, p + "sibk_corr")
+    elif case == "g2_normal":
+        g = load_golden("g2_natfreq32x16_basiclanczos")       # (three rigid-body modes at lam ~ 1e-15, dropped afterwards)
+        A, B, mode, p = csr_from(g, "K"), csr_from(g, "M"), "normal", ""
+        sigma, N, rhs, want, corr = float(g["sigma"]), 13, g["Q0b"], g["psi"], corr_from(g, "corr")
+        first = 3
+    else:
+        g = load_golden("g3_thermal32_eps1e-8_basiclanczos")
+        A, B, mode, p = csr_from(g, "K"), csr_from(g, "M"), "normal", ""
+        sigma, N, rhs, want, corr = float(g["sigma"]), 8, g["Qb"], g["psi"], corr_from(g, "corr")
+    P = (A - sigma * B) if mode == "normal" else (B + sigma * A)
+    fac = eg.SpLuOperator(P.tocsc())
+    assert fac.negative_pivots == 0 and fac.static_pivots == 0
+    s = eg.BasicLanczos(N=N, m=60, mode=mode)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        s.solve(A, B, fac, sigma)
+    _adopt(s, g, p)                                     # the reference's own eigenvectors and Lanczos data
+
+    def solve():
+        hist = []
+        fac.count = 0
+        psi, data = s.solve_adjoint(rhs.copy(), method="sibk", rtol=1e-12, update_guess=False, bs_target=1,
+                                    callback=hist.append)
+        return psi, data, list(s.last_info), hist, fac.count
+
+    (psi_s, data_s, info_s, hist_s, cnt_s), (psi_a, data_a, info_a, hist_a, cnt_a) = _both_forms(monkeypatch, solve)
+    assert index_sets(data_s) == index_sets(corr) == index_sets(data_a)
+    assert relerr(psi_s[:, first:], want) < RTOL and relerr(psi_a[:, first:], want) < RTOL
+    assert relerr(psi_s, psi_a) < 1e-9
+    # same Krylov spaces: the step counts agree up to what the two minimisation properties differ by
+    assert len(info_s) == len(info_a)
+    assert sum(info_s) <= 1.1 * sum(info_a) + len(info_a), (info_s, info_a)
+    # one factor application per step and mode (reference 19-22, 1248) on top of the first guess's
+    assert cnt_s - sum(info_s) == cnt_a - sum(info_a) >= 0
+    # the residuals handed to ``callback`` are true Euclidean residual norms: the last one of every mode meets 1275
+    res, _ = s.eval_adjoint_residual_norm(rhs, psi_s, b_ortho=True)
+    rn0 = np.sqrt(np.max(np.sum(rhs * rhs, axis=0)))
+    assert res.max() < 1e-9 * rn0
+
+
+def test_short_recurrence_on_a_column_with_deflated_extra_pairs_matches_the_arnoldi_form(monkeypatch):
+    """buckling column, restarted block eigensolver with converged pairs beyond N (deflated by both forms), 24 modes of
+    which one has a zero right-hand side; more than 32 modes in a second run (one block of 40 columns)"""
+    import eigd_amd as eg
+    from eigd_amd.device import default_context
+    from eigd_amd.problems import BucklingColumn
+
+    ctx = default_context()
+    col = BucklingColumn(90, 90, seed=2)
+    K = col.stiffness()
+    u = col.full_vector(eg.SpLuOperator(K, ctx=ctx, check_symmetry=False)(col.f[col.reduced]))
+    A, B, sigma = col.geometric_stiffness(u), K, 1.0
+    fac = eg.SpLuOperator((B + sigma * A).tocsr(), ctx=ctx, check_symmetry=False)
+    monkeypatch.setattr(eg.tuning, "iram_block", 4)
+    for N in (24, 40):
+        s = eg.IRAM(N=N, m=2 * N + 1, mode="buckling", ctx=ctx)
+        s.solve(A, B, fac, sigma)
+        Phib = np.random.default_rng(7).uniform(-1, 1, size=(B.shape[0], N))
+        Phib[:, 3] = 0.0
+
+        def solve():
+            hist = []
+            psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, callback=hist.append)
+            return psi, data, list(s.last_info), hist
+
+        (psi_s, data_s, info_s, hist_s), (psi_a, data_a, info_a, hist_a) = _both_forms(monkeypatch, solve)
+        assert relerr(psi_s, psi_a) < 1e-9
+        assert index_sets(data_s) == index_sets(data_a)
+        assert info_s[3] == 0 == info_a[3]
+        assert sum(info_s) <= 1.1 * sum(info_a) + N and max(info_s) <= 1.15 * max(info_a) + 1, (info_s, info_a)
+        res, _ = s.eval_adjoint_residual_norm(Phib, psi_s, b_ortho=True)
+        assert res.max() < 1e-9 * np.sqrt(np.max(np.sum(Phib * Phib, axis=0)))
+        # a step limit inside the solve: the best iterate so far comes back, the unfinished modes are not in ``info``
+        monkeypatch.setattr(eg.tuning, "recurrence", "auto")
+        psi_c, _ = s.solve_adjoint(Phib, method="sibk", rtol=1e-10, update_guess=False, bs_target=1, maxiter=4, nrestart=0)
+        assert len(s.last_info) < N and np.all(np.isfinite(psi_c))
+        assert relerr(psi_c, psi_s) < 0.5
+
+
+def test_short_recurrence_steps_aside_where_it_does_not_apply(monkeypatch):
+    """an interior shift (indefinite factor) and an incomplete deflation set (eigenvalues below lam_i left in: the
+    operator is indefinite in the deflated space, the breakdown is flagged on the device) both end in the Arnoldi form"""
+    import eigd_amd as eg
+    from eigd_amd import adjoint as adj
+    from oracle import eigd_oracle as orc
+
+    g = load_golden("g4_laplace900_basiclanczos")
+    K, M = csr_from(g, "K"), csr_from(g, "M")
+    lam, Phi, Phib = g["normal_lam"], g["normal_Phi"], g["Phib"]
+    monkeypatch.setattr(eg.tuning, "recurrence", "auto")
+    # (1) eigenvectors 2..5 only: modes 0 and 1 lie below and are not deflated
+    sel = np.arange(2, 6)
+    sigma = -0.1
+    fac_d = eg.SpLuOperator((K - sigma * M).tocsc())
+    fac_o = orc.SpLuOperator((K - sigma * M).tocsc())
+    psi_d, data_d, info_d = eg.sibk(Phib[:, sel], K, M, lam[sel], Phi[:, sel], factor=fac_d, sigma=sigma, rtol=1e-12)
+    assert adj.LAST_ROUND["recurrence"].startswith("arnoldi (")
+    psi_o, data_o, info_o = orc.sibk(Phib[:, sel], K, M, lam[sel], Phi[:, sel], factor=fac_o, sigma=sigma, rtol=1e-12)
+    assert relerr(psi_d, psi_o) < RTOL
+    # (2) a shift between lam_1 and lam_2
+    sig2 = 0.5 * (lam[1] + lam[2])
+    fac2 = eg.SpLuOperator((K - sig2 * M).tocsc())
+    assert fac2.negative_pivots == 2
+    fac2_o = orc.SpLuOperator((K - sig2 * M).tocsc())
+    psi_d, _, _ = eg.sibk(Phib, K, M, lam, Phi, factor=fac2, sigma=sig2, rtol=1e-12)
+    assert adj.LAST_ROUND["recurrence"] == "arnoldi"
+    psi_o, _, _ = orc.sibk(Phib, K, M, lam, Phi, factor=fac2_o, sigma=sig2, rtol=1e-12)
+    assert relerr(psi_d, psi_o) < RTOL
