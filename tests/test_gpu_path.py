@@ -902,9 +902,12 @@ def test_iram_reports_non_convergence():
         eg.IRAM(N=6, m=2000).solve(K, M, fac, -0.1)   # ncv must not exceed n
 
 
-def test_concurrent_mode_groups_on_streams_match_single_stream():
-    """streams=3: the modes are split into three groups on three HIP streams / host threads; same psi, data, counts"""
+def test_concurrent_mode_groups_on_streams_match_single_stream(monkeypatch):
+    """streams=3: the modes are split into three groups on three HIP streams / host threads; same psi, data, counts
+    (the mode groups run the Arnoldi form: the single-stream run is held to it here)"""
     import eigd_amd as eg
+
+    monkeypatch.setattr(eg.tuning, "recurrence", "arnoldi")
 
     g = load_golden("g4_laplace900_basiclanczos")
     K, M = csr_from(g, "K"), csr_from(g, "M")
