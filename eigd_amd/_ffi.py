@@ -101,12 +101,13 @@ _SIGNATURES = {
     "eigd_elem_linear_matrices": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp],
     "eigd_colnorm2_dev": [c_vp, c_int, c_int, c_vp, c_int, c_vp],
     "eigd_colnorm2_fetch": [c_vp, c_vp, c_int],
+    "eigd_colnorm2_publish": [c_vp, c_vp, c_int],
     "eigd_scale_inv_norm": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp],
     "eigd_copy_block": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_cg_state_rows": [],
     "eigd_cg_coefficients": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int],
     "eigd_cg_update": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp,
-                       c_int],
+                       c_int, c_vp],
     "eigd_gather_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
     "eigd_scatter_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],
     "eigd_elem_bilinear": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_dbl,

@@ -1050,9 +1050,27 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     # what the measured projection lets pass: a component along B Phi_D of relative size 1e-11 grows by |1 - alpha theta_j|
     # per step until it is taken out again; psi carries it at that relative size at most, and is projected once at the end
     proj_tol = 1e-11
+    # How often the residual is projected at all (1257).  A component of r along a deflated direction B phi_j is
+    # multiplied by the eigenvalue of C_i there, 1 - (lam_i - sigma) / (lam_j - sigma), in every step while the
+    # residual itself shrinks: with the largest such factor g over the deflated pairs, rounding (1e-16) left alone for p
+    # steps stands at 1e-16 (4 g)^p relative to the residual (a residual reduction of 4 per step assumed).  p is the
+    # largest period that keeps this below 1e-12; the steps in between take their residual norms from the update kernel.
+    lam_all = np.asarray(lam_c, dtype=float)
+    lam_defl = lam_all if not (prob.use_extra and prob.lam_x is not None) else np.concatenate([lam_all, prob.lam_x])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        g = np.nanmax(np.abs(1.0 - (lam_all[:, None] - sigma) / (lam_defl[None, :] - sigma)))
+    proj_every = 1
+    if np.isfinite(g):
+        proj_every = int(max(1, min(4, np.floor(np.log(1e4) / np.log(max(4.0 * g, 1.0 + 1e-12))))))
+    LAST_ROUND["cg_projection_period"] = proj_every
 
     def sptr(lo):
         return state.cols(lo, 64).ptr
+
+    norms_of = {}                                          # step -> device block of its residual norms (unprojected steps)
+
+    def project_in(j):
+        return j % proj_every == 0 or j >= maxsteps
 
     def first_part(j, lo, hi, n2, n2_lo):
         """sweep of the residual of step j - 1, product, coefficients, the two recurrences (no synchronisation)"""
@@ -1065,8 +1083,10 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
         call("eigd_cg_coefficients", ctx.h, n, kk, zv.ptr, zv.ld, rv.ptr, rv.ld, yv.ptr, yv.ld, n2p, sptr(lo), int(j),
              1 if j == 1 else 0)
         rov, psv, pov = r_old.cols(lo, hi), psi.cols(lo, hi), psi_old.cols(lo, hi)
+        own = None if project_in(j) else ctx.empty(1, kk)  # (a step that is not projected forms its own residual norms)
         call("eigd_cg_update", ctx.h, n, kk, rv.ptr, rv.ld, rov.ptr, rov.ld, psv.ptr, psv.ld, pov.ptr, pov.ld, zv.ptr, zv.ld,
-             yv.ptr, yv.ld, sptr(lo), 1 if j == 1 else 0)
+             yv.ptr, yv.ld, sptr(lo), 1 if j == 1 else 0, own.ptr if own is not None else None)
+        norms_of[j] = own
         r, r_old = r_old, r                                # (all columns of a block share the parity: the ranges lag one
         psi, psi_old = psi_old, psi                        # step behind the flags, see below)
 
@@ -1086,7 +1106,12 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     j = 1
     while True:
         lo, hi = rng_j
-        n2 = prob.project_r_norm2(r.cols(lo, hi), tol=proj_tol)   # ref 1257 + the residual norm of 1275; measured update
+        if project_in(j):
+            n2 = prob.project_r_norm2(r.cols(lo, hi), tol=proj_tol)   # ref 1257 + the residual norm of 1275; measured update
+        else:
+            n2 = norms_of[j]                               # (formed by the update kernel of this step)
+            call("eigd_colnorm2_publish", ctx.h, n2.ptr, hi - lo)
+        norms_of.pop(j - 1, None)
         nsteps = j
         live = np.flatnonzero(~done)
         expect_all = tuning.predict_finish and j > 1 and all(

@@ -72,3 +72,8 @@ struct eigd_ctx {
   int ensure_scratch(size_t bytes);
   int ensure_coef(size_t bytes);
 };
+
+namespace eigd {
+// small device results for the host: copy in stream order behind their kernel, collected by eigd_colnorm2_fetch (dense.hip)
+int publish_norm2(eigd_ctx* ctx, const double* dOut, int k);
+}  // namespace eigd

@@ -1073,7 +1073,6 @@ int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu
   return EIGD_OK;
 }
 
-static int publish_norm2(eigd_ctx* ctx, const double* dOut, int k);
 
 int eigd_project_norm2(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv,
                        double* dX, int ldx, double* dOut, double uscale, double tol) {
@@ -1459,7 +1458,9 @@ int eigd_colnorm2_dev(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, do
 }
 
 // copy for the host, in stream order right behind the reduction; eigd_colnorm2_fetch collects it
-static int publish_norm2(eigd_ctx* ctx, const double* dOut, int k) {
+}  // extern "C"
+
+int eigd::publish_norm2(eigd_ctx* ctx, const double* dOut, int k) {
   if (!ctx->pinned) {
     EIGD_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), sizeof(double) * 2 * kMaxK, hipHostMallocDefault));
     EIGD_HIP(hipEventCreateWithFlags(&ctx->ev_pinned, hipEventDisableTiming));
@@ -1468,6 +1469,13 @@ static int publish_norm2(eigd_ctx* ctx, const double* dOut, int k) {
   EIGD_HIP(hipEventRecord(ctx->ev_pinned, ctx->stream));
   ctx->pinned_count = k;
   return EIGD_OK;
+}
+
+extern "C" {
+
+int eigd_colnorm2_publish(eigd_ctx* ctx, const double* dNorm2, int k) {
+  EIGD_REQUIRE(ctx && dNorm2 && k >= 1 && k <= 2 * kMaxK, "bad argument");
+  return publish_norm2(ctx, dNorm2, k);
 }
 
 int eigd_colnorm2_fetch(eigd_ctx* ctx, double* hout, int k) {

@@ -144,10 +144,13 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, int k, const
                                                             double* __restrict__ pso, int ldpso,
                                                             const double* __restrict__ z, int ldz,
                                                             const double* __restrict__ y, int ldy,
-                                                            const double* __restrict__ state, int first) {
+                                                            const double* __restrict__ state, int first,
+                                                            double* __restrict__ normpart) {
   constexpr int RP = kThreads / KP;
+  __shared__ double red[kThreads];
   const int c = threadIdx.x % KP, rr = threadIdx.x / KP;
-  if (c >= k) return;
+  double nrm = 0.0;
+  if (c < k) {
   const double gam = state[kGamNow * kMaxK + c], rho = state[kRhoNow * kMaxK + c];
   const double al = state[kAlpha * kMaxK + c];
   const bool moves = gam != 0.0;
@@ -166,6 +169,26 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, int k, const
     }
     ro[row * ldro + c] = rn;
     pso[row * ldpso + c] = sn;
+    nrm += rn * rn;
+  }
+  }
+  if (normpart == nullptr) return;  // (uniform)
+  red[threadIdx.x] = nrm;
+  __syncthreads();
+  if (rr == 0 && c < k) {
+    double t = 0.0;
+    for (int q = 0; q < RP; ++q) t += red[q * KP + c];
+    normpart[static_cast<int64_t>(blockIdx.x) * k + c] = t;
+  }
+}
+
+// one workgroup: the partial squared norms of the new residual -> out[c]
+__global__ __launch_bounds__(kThreads) void cg_norm_kernel(const double* __restrict__ partial, int nblocks, int k,
+                                                          double* __restrict__ out) {
+  const int wave = threadIdx.x >> 6;
+  for (int o = wave; o < k; o += kThreads / 64) {
+    const double s = wave_sum_partials(partial, nblocks, k, o);
+    if ((threadIdx.x & 63) == 0) out[o] = s;
   }
 }
 
@@ -215,17 +238,27 @@ int eigd_cg_coefficients(eigd_ctx* ctx, int n, int k, const double* dZ, int ldz,
 
 int eigd_cg_update(eigd_ctx* ctx, int n, int k, const double* dR, int ldr, double* dRold, int ldro, const double* dPsi,
                    int ldpsi, double* dPsiOld, int ldpso, const double* dZ, int ldz, const double* dY, int ldy,
-                   const double* dState, int first) {
+                   const double* dState, int first, double* dNorm2) {
   EIGD_REQUIRE(ctx && dR && dRold && dPsi && dPsiOld && dZ && dY && dState, "null argument");
   EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldr >= k && ldro >= k && ldpsi >= k && ldpso >= k && ldz >= k && ldy >= k,
                "bad shape n=%d k=%d", n, k);
   const int kp = next_pow2(k);
   const int nb = cg_grid(n, (kThreads / kp) * 4);
-  int rc = cg_dispatch_kp(k, [&](auto KP) {
+  double* partial = nullptr;
+  int rc = EIGD_OK;
+  if (dNorm2 != nullptr) {
+    rc = ctx->ensure_scratch(sizeof(double) * static_cast<size_t>(nb) * k);
+    if (rc) return rc;
+    partial = ctx->scratch;
+  }
+  rc = cg_dispatch_kp(k, [&](auto KP) {
     hipLaunchKernelGGL(cg_update_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dR, ldr, dRold,
-                       ldro, dPsi, ldpsi, dPsiOld, ldpso, dZ, ldz, dY, ldy, dState, first);
+                       ldro, dPsi, ldpsi, dPsiOld, ldpso, dZ, ldz, dY, ldy, dState, first, partial);
   });
   if (rc) return rc;
+  EIGD_LAUNCH_CHECK();
+  if (dNorm2 == nullptr) return EIGD_OK;
+  hipLaunchKernelGGL(cg_norm_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, partial, nb, k, dNorm2);
   EIGD_LAUNCH_CHECK();
   return EIGD_OK;
 }

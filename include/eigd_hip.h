@@ -231,6 +231,8 @@ int eigd_colnorm2_dev(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, do
 /* the same numbers on the host: their copy was issued in stream order behind eigd_colnorm2_dev, this call waits for
  * that copy only (not for kernels enqueued since) */
 int eigd_colnorm2_fetch(eigd_ctx* ctx, double* hout, int k);
+/* issue that copy for k numbers some other kernel left on the device (eigd_cg_update's residual norms): one copy in flight */
+int eigd_colnorm2_publish(eigd_ctx* ctx, const double* dNorm2, int k);
 int eigd_scale_inv_norm(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, double* dOut, int ldo,
                         const double* dNorm2, const unsigned char* hskip);
 /* ---- sibk in short-recurrence form (csrc/krylov.hip) -------------------------------------------------------------
@@ -247,13 +249,15 @@ int eigd_scale_inv_norm(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, 
  *                         rho = 1 / (1 - (gam/gam')(r.z / r'.z') / rho')  (rho = 1 when first != 0)
  *   eigd_cg_update        r_old <- rho (r - gam (r - alpha y)) + (1 - rho) r_old,
  *                         psi_old <- rho (psi + gam z) + (1 - rho) psi_old  (psi of 1277; finished modes: copies) --
- *                         the caller swaps the roles of the two buffers afterwards */
+ *                         the caller swaps the roles of the two buffers afterwards.  dNorm2 (device, k; may be null):
+ *                         the squared column norms of the new residual, formed in the same pass (for the steps whose
+ *                         residual is not projected; eigd_colnorm2_publish hands them to the host) */
 int eigd_cg_state_rows(void);
 int eigd_cg_coefficients(eigd_ctx* ctx, int n, int k, const double* dZ, int ldz, const double* dR, int ldr, const double* dY,
                          int ldy, const double* dNorm2, double* dState, int step, int first);
 int eigd_cg_update(eigd_ctx* ctx, int n, int k, const double* dR, int ldr, double* dRold, int ldro, const double* dPsi,
                    int ldpsi, double* dPsiOld, int ldpso, const double* dZ, int ldz, const double* dY, int ldy,
-                   const double* dState, int first);
+                   const double* dState, int first, double* dNorm2);
 /* copy an n x k block between buffers with different leading dimensions / column offsets */
 int eigd_copy_block(eigd_ctx* ctx, int n, int k, const double* dSrc, int lds, double* dDst, int ldd);
 /* gather columns: Dst[r, j] = Src[r, cols[j]] (compaction of the active modes) */
