@@ -287,6 +287,7 @@ def main():
     ap.add_argument("--trace", default=None, help="write the per-iteration host timeline of one extra step to this file")
     ap.add_argument("--no-fd-check", action="store_true", help="skip the directional finite-difference check of df/dx")
     ap.add_argument("--no-arnoldi-leg", action="store_true", help="skip the untimed comparison solve in the Arnoldi form")
+    ap.add_argument("--no-scaling-model", action="store_true", help="skip the slowest-rank timings for P = 2, 4, 8")
     ap.add_argument("--dump-dfdx", default=None, help="rank 0 saves the df/dx of the last timed step to this .npy file")
     ap.add_argument("--force-launch", action="store_true",
                     help="start the rank processes through the launcher even for --gpus 1 (test of the launcher)")
@@ -526,6 +527,45 @@ def main():
         ctx.release_workspaces()                         # the Krylov stacks of the Arnoldi form (26 GB at C3) go back
         log(rank, f"Arnoldi form: {arnoldi_form['ms_per_step']} ms/step, iterations {sum(it_arn)} against {sum(it_short)}, "
                   f"psi rel diff {arnoldi_form['psi_rel_diff']:.1e}")
+    # ------------------------------------------------------------------ what mode sharding can give: the slowest rank's share
+    # (one GPU: the block-cyclic share of the LAST rank of P -- it owns the slowest mode -- timed with a stand-in
+    # communicator; no collective: the 4 MB all-reduce of df/dx adds < 0.1 ms.  A prediction for the next multi-GPU run.)
+    scaling_model = None
+    if world == 1 and comm is None and not args.no_scaling_model:
+        class _LastOfMany:
+            def __init__(self, p):
+                self.rank, self.size = p - 1, p
+
+            def allreduce_sum(self, a):
+                return a
+
+            def allreduce_max(self, x):
+                return x
+
+            def barrier(self):
+                pass
+
+        scaling_model = {"note": "slowest rank's share of the same 32-mode step, timed on this one GPU (no collective); "
+                                 "efficiency = ms_per_step / (P * rank_ms)", "ranks": {}}
+        for P_ in (2, 4, 8):
+            cm = _LastOfMany(P_)
+
+            def rank_step():
+                dpsi_r, data_r = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1,
+                                                      comm=cm, streams=args.streams)
+                solver.add_total_derivative(lamb, dPhib, dpsi_r, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data_r,
+                                            deriv_type="tensor", comm=cm)
+
+            rank_step()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                rank_step()
+            ctx.sync()
+            t_r = (time.perf_counter() - t0) / 3
+            scaling_model["ranks"][str(P_)] = {"rank_ms": round(1e3 * t_r, 3), "modes_of_rank": int(len(range(P_ - 1, N, P_))),
+                                                "predicted_efficiency": round(ms_per_step * 1e-3 / (P_ * t_r), 3)}
+        log(rank, f"scaling model (slowest rank of P on one GPU): {scaling_model['ranks']}")
     # ------------------------------------------------------------------ the reference's call surface: numpy in, numpy out
     # (the timed value keeps the operands resident in HBM; callers of the reference hand numpy arrays to solve_adjoint
     # and add_total_derivative, which adds the H2D of Phib and the D2H / H2D of psi: reported next to the value)
@@ -736,6 +776,7 @@ def main():
         "factor_sweeps_per_step": int(adj_count),
         "sibk_iterations": sibk_iterations,
         "arnoldi_form": arnoldi_form,
+        "scaling_model": scaling_model,
         "eigensolve_sweeps": int(eig_count),
         "eigensolver": eig_info,
         "lock_step": {"recurrence": last_round.get("recurrence"),

@@ -59,6 +59,7 @@ class DeviceProblem:
         self.Phix = self.BPhix = self.lam_x = None
         self.PhiD = self.BPhiD = None
         self.use_extra = False
+        self.lam_phi = None   # eigenvalues of the columns of Phi when the caller knows them (all N, also on a rank that solves a share)
         self._uscale = {}     # largest Euclidean column norm of B Phi ("N") / B [Phi | Phix] ("D"), formed on first use
 
     def on(self, ctx):
@@ -1056,7 +1057,9 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     # steps stands at 1e-16 (4 g)^p relative to the residual (a residual reduction of 4 per step assumed).  p is the
     # largest period that keeps this below 1e-12; the steps in between take their residual norms from the update kernel.
     lam_all = np.asarray(lam_c, dtype=float)
-    lam_defl = lam_all if not (prob.use_extra and prob.lam_x is not None) else np.concatenate([lam_all, prob.lam_x])
+    lam_defl = lam_all if prob.lam_phi is None else np.asarray(prob.lam_phi, dtype=float)
+    if prob.use_extra and prob.lam_x is not None:
+        lam_defl = np.concatenate([lam_defl, prob.lam_x])
     with np.errstate(divide="ignore", invalid="ignore"):
         g = np.nanmax(np.abs(1.0 - (lam_all[:, None] - sigma) / (lam_defl[None, :] - sigma)))
     proj_every = 1
@@ -1452,6 +1455,7 @@ def sibk(Phib, A, B, lam, Phi, mode="normal", psi=None, sigma=None, factor=None,
     dpsi = ctx.from_host(_psi)
     dPhib = ctx.from_host(Phib)
     lam = np.asarray(lam, dtype=float)
+    prob.lam_phi = lam
     G = -prob.Phi.tdot(dPhib)                            # ref 1180
     Glo = refine_repeated_entries(G, lam, prob.Phi, dPhib, eig_atol)
     if bs_target == 1 and not update_guess:

@@ -53,7 +53,9 @@ def rendezvous_dir():
         start = "0"
     port = os.environ.get("MASTER_PORT", "0")
     run = "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "") if ch.isalnum())[:32]
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"eigd_comm_{os.getuid()}_{ppid}_{start}_{port}_{run}")
+    # (a worker restart of the same agent keeps pid, start time, port and run id: the restart count tells the rounds apart)
+    rnd = "".join(ch for ch in os.environ.get("TORCHELASTIC_RESTART_COUNT", "0") if ch.isdigit())[:6] or "0"
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"eigd_comm_{os.getuid()}_{ppid}_{start}_{port}_{run}_{rnd}")
 
 
 def _process_start_time():
@@ -101,9 +103,13 @@ def exchange_unique_id(rank, size, make_id, tag="uid", timeout=300.0):
         return uid
     t0 = time.monotonic()
     oldest = _process_start_time() - _STALE_SLACK_S
+    me = os.getuid()
     while True:
         try:
-            if os.stat(path).st_mtime >= oldest:
+            sd, sf = os.stat(d), os.stat(path)
+            # only what this user published in a directory nobody else can write to (rank 0 creates it 0700) counts
+            private = sd.st_uid == me and not (sd.st_mode & 0o077) and sf.st_uid == me and not (sf.st_mode & 0o022)
+            if private and sf.st_mtime >= oldest:
                 with open(path, "rb") as fh:
                     uid = fh.read()
                 if len(uid) > 0:

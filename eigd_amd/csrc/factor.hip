@@ -94,6 +94,21 @@ __global__ void scatter_a_kernel(int64_t nlower, const int64_t* __restrict__ src
     F[dst[e]] = data[src[e]];
 }
 
+// largest |x_i| per workgroup (the threshold of the static pivots is sqrt(eps) times the largest matrix entry)
+__global__ __launch_bounds__(kThreads) void absmax_kernel(int64_t n, const double* __restrict__ x, double* __restrict__ partial) {
+  __shared__ double red[kThreads];
+  double m = 0.0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kThreads)
+    m = fmax(m, fabs(x[i]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // update matrix of each child (its trailing bs x bs block) added into the parent front
 __global__ __launch_bounds__(kThreads) void extend_add_kernel(FrontArrays fa, const int* __restrict__ children,
                                                              double* __restrict__ F) {
@@ -1913,6 +1928,7 @@ struct eigd_factor {
   int nslot = 0, nplanes = 0;        // planes the parents read; planes allocated (+ scratch when there are surplus children)
   int64_t* d_toff = nullptr;
   double *d_T = nullptr, *d_aux = nullptr;  // aux: {0.0, (int) -1}
+  double* d_red = nullptr;                  // 512 partial results of small reductions
   std::vector<int> h_fwd_ptr, h_bwd_ptr;  // per level: first workgroup record
   std::vector<int> h_thin_fwd, h_thin_bwd;  // per level: 4, 8 or 16 K-steps (of 4 own columns) of the wave-per-block kernels, 0: the tile kernels
   std::vector<int> h_fwd_kd, h_bwd_kd;    // per level: LDS tile rows of the single-column-tile launches (multiple of 8)
@@ -2065,11 +2081,15 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false, bool piv
   // Factor again with Bunch-Kaufman pivoting inside the panels -- the positive definite shifts of the reference's
   // examples never come here and keep the plain (bitwise unchanged) Cholesky path.
   if (!pivot && (flag[0] != 0 || flag[1] != 0)) {
-    // the threshold of the static pivots: sqrt(eps) * max |a_ij| (the values are on the device by now)
-    std::vector<double> h(f->data_len);
-    EIGD_HIP(hipMemcpy(h.data(), f->d_data, sizeof(double) * f->data_len, hipMemcpyDeviceToHost));
+    // the threshold of the static pivots: sqrt(eps) * max |a_ij| (the values are on the device: reduced there)
+    constexpr int nbm = 512;
+    hipLaunchKernelGGL(absmax_kernel, dim3(nbm), dim3(kThreads), 0, st, f->data_len, f->d_data, f->d_red);
+    EIGD_LAUNCH_CHECK();
+    double part[nbm];
+    EIGD_HIP(hipMemcpyAsync(part, f->d_red, sizeof(part), hipMemcpyDeviceToHost, st));
+    EIGD_HIP(hipStreamSynchronize(st));
     double amax = 0.0;
-    for (double v : h) amax = std::max(amax, std::fabs(v));
+    for (double v : part) amax = std::max(amax, v);
     f->pivtol = 1.4901161193847656e-08 * amax;
     return numeric(f, nullptr, true, true);
   }
@@ -2398,7 +2418,7 @@ int eigd_factor_free(eigd_factor* f) {
                   f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_ov_dst,   f->d_ov_ptr, f->d_ov_src,
                   f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux,      f->d_bout,  f->d_tickets,
                   f->d_P,         f->d_wave_wg,     f->d_ftoff,      f->d_tr_pref,  f->d_Ft,  f->d_Fb,
-                  f->d_Fm,        f->d_Bm,          f->d_ff,         f->d_mt_pref};
+                  f->d_Fm,        f->d_Bm,          f->d_ff,         f->d_mt_pref,  f->d_red};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;
@@ -2759,6 +2779,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   rc = dmalloc(&f->d_Inv, s.inv_doubles);
   rc = dmalloc(&f->d_T, static_cast<size_t>(f->t_doubles));
   rc = dmalloc(&f->d_aux, 2);
+  rc = dmalloc(&f->d_red, 512);
   rc = dmalloc(&f->d_Ft, static_cast<size_t>(f->ft_doubles));
   rc = dmalloc(&f->d_Fb, static_cast<size_t>(f->ft_doubles));
   rc = dmalloc(&f->d_Fm, static_cast<size_t>(std::max<int64_t>(f->fm_doubles, 1)));

@@ -120,6 +120,7 @@ class Context:
         """give the pooled (released, reusable) device blocks back to the driver"""
         pool = self.__dict__.pop("_pool", {})
         self.__dict__["_pool_bytes"] = 0
+        _pinned.trim()
         if self.h is None:
             return
         for free in pool.values():
@@ -161,26 +162,32 @@ class _PinnedHost:
     """
 
     def __init__(self):
+        import threading
+
         self.free = {}            # nbytes -> [host pointers]
         self.held = 0
-        self.seen = {}            # (address, nbytes) -> sightings of a caller-owned buffer
+        self.seen = {}            # id(array) -> [weak reference, sightings] of a caller-owned array
         self.registered = {}      # address -> nbytes
         self.asked = {}           # nbytes -> results of that size asked for so far
+        self._lock = threading.RLock()   # (mode groups on several streams upload and download from their own host threads)
 
     def empty(self, shape):
         import weakref
 
         nbytes = int(np.prod(shape)) * 8
-        lst = self.free.get(nbytes)
-        if lst:
-            ptr = lst.pop()
-            self.held -= nbytes
-        else:
+        with self._lock:
+            lst = self.free.get(nbytes)
+            ptr = lst.pop() if lst else None
+            if ptr is not None:
+                self.held -= nbytes
+            else:
+                self.asked[nbytes] = self.asked.get(nbytes, 0) + 1
+                first = self.asked[nbytes] < 2
+        if ptr is None:
             # page-locking costs about what the staged copy of the same bytes costs twice over (62 ms for 255 MB): it
             # pays from the second result of a size on -- a one-off download (the eigenvectors after a solve) goes to an
             # ordinary array
-            self.asked[nbytes] = self.asked.get(nbytes, 0) + 1
-            if self.asked[nbytes] < 2 and nbytes >= _PIN_FIRST_USE_MAX_BYTES:
+            if first and nbytes >= _PIN_FIRST_USE_MAX_BYTES:
                 return np.empty(shape)
             h = c_vp()
             try:
@@ -194,11 +201,25 @@ class _PinnedHost:
         return np.frombuffer(buf, dtype=np.float64).reshape(shape)
 
     def _release(self, ptr, nbytes):
-        lst = self.free.setdefault(nbytes, [])
-        if len(lst) < _PIN_KEEP_PER_SIZE and self.held + nbytes <= _PIN_POOL_MAX_BYTES:
-            lst.append(ptr)
-            self.held += nbytes
-        else:
+        with self._lock:
+            lst = self.free.setdefault(nbytes, [])
+            keep = len(lst) < _PIN_KEEP_PER_SIZE and self.held + nbytes <= _PIN_POOL_MAX_BYTES
+            if keep:
+                lst.append(ptr)
+                self.held += nbytes
+        if not keep:
+            try:
+                _ffi.lib().eigd_host_free(c_vp(ptr))
+            except Exception:
+                pass
+
+    def trim(self):
+        """give the pooled page-locked buffers back (Context.trim_pool does this together with the device pool)"""
+        with self._lock:
+            ptrs = [p for lst in self.free.values() for p in lst]
+            self.free.clear()
+            self.held = 0
+        for ptr in ptrs:
             try:
                 _ffi.lib().eigd_host_free(c_vp(ptr))
             except Exception:
@@ -210,26 +231,34 @@ class _PinnedHost:
 
         if a.nbytes < _PIN_MIN_BYTES or not a.flags.owndata:
             return
-        addr = a.ctypes.data
-        if addr in self.registered:
-            return
-        key = (addr, a.nbytes)
-        self.seen[key] = self.seen.get(key, 0) + 1
-        if self.seen[key] < 2:
-            if len(self.seen) > 64:
-                self.seen.clear()
-            return
-        try:
-            call("eigd_host_register", c_vp(addr), a.nbytes)
-        except (_ffi.EigdHipError, ValueError):
-            self.seen[key] = -(1 << 30)                    # (cannot be locked: do not try again)
-            return
-        self.registered[addr] = a.nbytes
-        self.seen.pop(key, None)
-        weakref.finalize(a, self._unregister, addr).atexit = False
+        with self._lock:
+            addr = a.ctypes.data
+            if self.registered.get(addr) == a.nbytes:
+                return
+            # sightings are counted per array OBJECT (a fresh array that happens to land on a freed one's address is a
+            # first sighting: a loop that allocates its right-hand sides anew every step never pays for page-locking)
+            ent = self.seen.get(id(a))
+            if ent is None or ent[0]() is not a:
+                if len(self.seen) > 64:
+                    self.seen.clear()
+                self.seen[id(a)] = [weakref.ref(a), 1]
+                return
+            ent[1] += 1
+            if ent[1] != 2:                                # (second sighting locks; a failed attempt is not repeated)
+                return
+            if addr in self.registered:                    # an array resized in place left a stale registration here
+                self._unregister(addr)
+            try:
+                call("eigd_host_register", c_vp(addr), a.nbytes)
+            except (_ffi.EigdHipError, ValueError):
+                return
+            self.registered[addr] = a.nbytes
+            weakref.finalize(a, self._unregister, addr).atexit = False
 
     def _unregister(self, addr):
-        if self.registered.pop(addr, None) is not None:
+        with self._lock:
+            had = self.registered.pop(addr, None) is not None
+        if had:
             try:
                 _ffi.lib().eigd_host_unregister(c_vp(addr))
             except Exception:

@@ -249,7 +249,8 @@ def arpack_converged(bounds, theta, tol, beta_scale, basis_size=0):
     return bounds <= np.maximum(tol * np.maximum(eps ** (2.0 / 3.0), np.abs(theta)), floor)
 
 
-def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=None, k_strict=None, tol_extra=None):
+def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=None, k_strict=None, tol_extra=None,
+                                report=None):
     """
     Thick-restart Lanczos with blocks of p vectors on the operator the backend ``be`` applies (shift-invert, B inner
     product), full reorthogonalisation.  p = 1 is the single-vector thick-restart Lanczos (= ARPACK's implicitly
@@ -269,6 +270,9 @@ def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=N
     further ones -- kept for the adjoint stage's deflation, which needs them to ~1e-10 -- to ``tol_extra``.  (A Ritz
     vector next to unconverged neighbours in a cluster carries eps |T| / gap of THEIR residuals: asking machine
     precision of the last pairs of a wanted set inside a cluster never ends.)
+    ``report`` (a dict, optional) receives what the run achieved for the wanted pairs, largest |theta| first:
+    ``theta``, ``bound`` (residual bounds |C s_last|) and ``by_noise_rule`` (accepted by one of the noise-level rules
+    below rather than by ARPACK's test at the requested tolerance).
     """
     tols = np.full(k_want, tol)
     if k_strict is not None and tol_extra is not None:
@@ -303,6 +307,7 @@ def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=N
         order = np.argsort(-np.abs(theta))              # which = "LM"
         wanted = order[:k_want]
         conv = arpack_converged(bounds[wanted], theta[wanted], tols, np.linalg.norm(C, 2), c)
+        by_test = conv.copy()
         if locked.size:
             # A pair that passed its test in an earlier restart has been in the basis ever since (the thick restart keeps
             # the wanted Ritz vectors) and its true residual can only have shrunk; its computed bound sits at the noise
@@ -333,7 +338,10 @@ def thick_restart_block_lanczos(be, k_want, m_int, p, tol, max_restarts, trace=N
             stalled += 1
         if nconv < k_want and worst <= 1e-11 and stalled >= 8:
             nconv = k_want
+            conv[:] = True
         if nconv >= k_want or n_restarts >= max_restarts:
+            if report is not None:
+                report.update(theta=theta[wanted].copy(), bound=bounds[wanted].copy(), by_noise_rule=conv & ~by_test)
             return T[:c, :c].copy(), C, c, nconv, n_restarts
         # thick restart: the wanted pairs plus part of the unwanted ones as ARPACK's dsaup2 does (more of them as more
         # have converged); a whole number of blocks has to fit behind the kept vectors
@@ -688,6 +696,7 @@ class _AdjointAPI:
             # below, as 385-389 does for j <= N.  psi is unique, the Krylov solve just no longer has to resolve the
             # eigenvalues closest above lam_N, which are what makes the high modes slow.
             prob.use_extra = prob.PhiD is not None
+            prob.lam_phi = lam
             try:
                 if prob.use_extra:
                     psi_c.project(prob.Phix, prob.BPhix)      # the guess gives up its share along Phix
@@ -1092,8 +1101,9 @@ class IRAM(_AdjointAPI):
                 print(f"[iram] restart {r}: {nconv}/{kw} converged (block {p}, basis {m_int}), worst bound / |theta| "
                       f"{worst:.2e}", flush=True)
 
+        run = {}
         T, C, c, nconv, self.n_restarts = thick_restart_block_lanczos(dev, k_want, m_int, p, tol, max_restarts, trace,
-                                                                      k_strict=k, tol_extra=tol_x)
+                                                                      k_strict=k, tol_extra=tol_x, report=run)
         if nconv < k_want:
             # the extra pairs are an internal acceleration of the adjoint stage: only the N requested ones decide
             theta_c, S_c = np.linalg.eigh(T)
@@ -1135,6 +1145,33 @@ class IRAM(_AdjointAPI):
         self._phi_token = self.Phi
         bounds = np.abs(beta_m * self.Y[m - 1, :])
         self.eig_res = bounds[sel]
+        # What the restarted run itself achieved for these pairs (the m-vector contract basis is rebuilt around the kept
+        # Ritz vectors with their couplings set to zero: its own bounds say nothing about them), and the TRUE residuals
+        # |OP phi - theta phi|_B of the returned pairs, from one N-column application of the operator -- the acceptance
+        # rules of the block run are checked against the real thing before anybody builds on these pairs.
+        th_sel = self.theta[sel]
+        hit = np.zeros(self.N, dtype=bool)
+        if run:
+            jm = np.argmin(np.abs(th_sel[:, None] - run["theta"][None, :]), axis=1)
+            hit = np.abs(run["theta"][jm] - th_sel) <= 1e-9 * np.abs(th_sel)
+            self.eig_res = np.where(hit, np.maximum(self.eig_res, run["bound"][jm]), self.eig_res)
+            self.eig_accepted_at_noise_level = int(np.count_nonzero(run["by_noise_rule"][jm] & hit))
+        Wr = ctx.empty(n, self.N)
+        prob.fac.apply_to(prob.BPhi, Wr, count=0)          # OP Phi = factor(B Phi)   (not counted: a check, not a solve)
+        Wr.assign_lincomb([(1.0, Wr), (-th_sel, dPhi)])
+        self.eig_res_true = np.sqrt(np.maximum(Wr.coldot(prob.opB.apply(Wr)), 0.0))
+        del Wr
+        self.eig_res = np.maximum(self.eig_res, self.eig_res_true)
+        rel = self.eig_res_true / np.maximum(np.abs(th_sel), np.finfo(float).tiny)
+        if np.any(hit & (rel > self.eig_atol)):            # (pairs the run declared converged; a selection of other
+            from scipy.sparse.linalg import ArpackNoConvergence   # pairs -- shift on the wrong side -- is warned about below)
+
+            raise ArpackNoConvergence(f"IRAM: the returned Ritz pairs are not eigenpairs (largest true residual "
+                                      f"|OP phi - theta phi|_B / |theta| = {rel.max():.1e})", self.lam, self.Phi)
+        tol_user = self.tol if self.tol > 0 else 0.0
+        if tol_user > 0.0 and np.any(rel > 10.0 * max(tol_user, 64.0 * eps)):
+            warnings.warn(f"IRAM: residual of the returned pairs {rel.max():.1e} |theta| above the requested tol = {tol_user:.1e} "
+                          "(pairs are accepted at the noise level of the projected problem, 1e-11 |theta| at worst)")
         if np.any(self.eig_res > 1e-6 * np.maximum(np.abs(self.theta[sel]), 1.0)):
             # the restarts converge the Ritz values of largest magnitude; the reference then selects by eigenvalue order
             # (1960-1965): with a shift on the wrong side of the wanted eigenvalues these are different pairs

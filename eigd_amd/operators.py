@@ -95,6 +95,10 @@ class SpLuOperator(LinearOperator):
         st = self.factor.stats()
         self.negative_pivots = st["negative_pivots"]
         self.static_pivots = st["static_pivots"]   # pivots singular inside their panel block, replaced by +-sqrt(eps)|A|
+        # a static pivot takes its sign from a diagonal entry at rounding level: the inertia is then known only up to
+        # their number -- negative_pivots_bounds brackets the count of eigenvalues below the shift
+        self.negative_pivots_bounds = (max(0, self.negative_pivots - self.static_pivots),
+                                       self.negative_pivots + self.static_pivots)
         self._refine_steps = self.factor.STATIC_PIVOT_REFINEMENTS if self.static_pivots > 0 else 1
 
     def _refine(self, B, X, alpha):

@@ -443,6 +443,12 @@ class ShellBoxOnDevice:
         self._shifted.update_values_device(vS)
         self.factor.refactor_device(vS, indefinite_matrix=self._shifted)
         self.sigma = float(sigma)
+        if self.factor.static_pivots > 0:
+            import warnings
+
+            lo, hi = self.factor.negative_pivots_bounds
+            warnings.warn(f"refactor: {self.factor.static_pivots} static pivots -- the number of eigenvalues below the shift is "
+                          f"only known to lie in [{lo}, {hi}]")
         return self.factor.negative_pivots
 
     def callbacks(self, t=None):

@@ -14,6 +14,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     from conftest import corr_from, exact_pair_coefficients, load_golden, pair_rounding_in_dfdx, relerr
     from eigd_amd import design
     from eigd_amd.device import ElementBilinear, default_context
+    from eigd_amd import tuning
+
+    tuning.iram_seed = int(os.environ.get("SEED", "12345"))
 
     name = sys.argv[2]
     g = load_golden(name)
@@ -32,14 +35,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     exact = exact_pair_coefficients(g["lam"], g["Phi"], g["Qb"], ref_data)
     d_rhoEb = pair_rounding_in_dfdx(ref_data, exact, g["Phi"], dAdx, dBdx)
     np.save(sys.argv[3], out["rhoEb"])
-    print(f"seed {os.environ.get('EIGD_IRAM_SEED')}: vs corrected reference {relerr(out['rhoEb'], g['rhoEb'] + d_rhoEb):.3e}, raw "
+    print(f"seed {os.environ.get('SEED')}: vs corrected reference {relerr(out['rhoEb'], g['rhoEb'] + d_rhoEb):.3e}, raw "
           f"{relerr(out['rhoEb'], g['rhoEb']):.3e}", flush=True)
     sys.exit(0)
 name = sys.argv[1] if len(sys.argv) > 1 else "g3_thermal32_eps1e-8_iram"
 res = []
 for seed in (12345, 1, 2, 3, 4, 5, 6, 7):
     f = f"/tmp/g3_{seed}.npy"
-    subprocess.run([sys.executable, __file__, "one", name, f], env=dict(os.environ, EIGD_IRAM_SEED=str(seed)), check=True)
+    subprocess.run([sys.executable, __file__, "one", name, f], env=dict(os.environ, SEED=str(seed)), check=True)
     res.append(np.load(f))
 res = np.array(res)
 mean = res.mean(axis=0)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""wall time of k-column sweeps on the C3 factor (development aid); split policy from the EIGD_SPLIT_* environment"""
+"""wall time of k-column sweeps on the C3 factor (development aid); DIGEST=1 adds a hash of each result, EIGD_LIB picks the build"""
 import os
 import sys
 import time
@@ -16,7 +16,7 @@ K = col.stiffness()
 F = Factor(ctx, K, coords=col.dof_coords(), leaf_size=int(os.environ.get("LEAF", "0")))
 rng = np.random.default_rng(0)
 out = []
-for k in (1, 4, 8, 16, 32):
+for k in tuple(int(v) for v in os.environ.get("WIDTHS", "1,4,8,16,32").split(",")):
     B = ctx.from_host(rng.normal(size=(K.shape[0], k)))
     X = ctx.empty(K.shape[0], k)
     for _ in range(3):
@@ -33,4 +33,4 @@ for k in (1, 4, 8, 16, 32):
         out.append("[" + hashlib.sha1(X.get().tobytes()).hexdigest()[:10] + "]")
 x = X.get()
 r = np.linalg.norm(K @ x - B.get()) / np.linalg.norm(B.get())
-print({k: os.environ[k] for k in os.environ if k.startswith("EIGD_SPLIT")}, " ".join(out), f"resid {r:.1e}")
+print(" ".join(out), f"resid {r:.1e}")
