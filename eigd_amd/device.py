@@ -87,6 +87,35 @@ class Context:
     def stack(self, ns, n, k=1):
         return DeviceStack(self, ns, n, k)
 
+    # -- device twins of host arrays (the reference's two-call surface hands the same arrays in twice) ---------------
+    def twin_upload(self, a):
+        """
+        Device block holding the host array ``a`` for READ-ONLY use.  The reference's surface passes Phib to solve_adjoint
+        and again to add_total_derivative, and psi back in as it came out: with ``tuning.host_twins`` the device copy of
+        such an array is kept (as long as the array object lives; four arrays at most) and handed out again instead of a
+        second PCIe transfer.  It is validated on every reuse against the host array itself -- same object, same shape,
+        and a sample of its content kept from the time of the copy: 1024 rows spread over the array plus its first and
+        last page.  A change of the array that touches none of those rows goes unnoticed: callers that edit single
+        entries between the two calls set ``tuning.host_twins = False`` (every call then transfers what it is given).
+        """
+        from . import tuning
+
+        big = isinstance(a, np.ndarray) and a.dtype == np.float64 and a.ndim == 2 and a.flags.c_contiguous and a.nbytes >= _PIN_MIN_BYTES
+        if not (tuning.host_twins and big):
+            return self.from_host(a)
+        blk = _twins.lookup(self, a)
+        if blk is None:
+            blk = self.from_host(a)
+            _twins.remember(self, a, blk)
+        return blk
+
+    def twin_adopt(self, a, block):
+        """``a`` has just been downloaded from ``block`` (which nobody modifies any more): keep the pair (see twin_upload)"""
+        from . import tuning
+
+        if tuning.host_twins and isinstance(a, np.ndarray) and a.ndim == 2 and a.nbytes >= _PIN_MIN_BYTES and block.ld == block.k:
+            _twins.remember(self, a, block)
+
     def project_stats(self):
         """(projections measured, updates applied) by project_norm2 since the last call; resets the counters"""
         out = np.zeros(2, dtype=np.int32)
@@ -121,6 +150,7 @@ class Context:
         pool = self.__dict__.pop("_pool", {})
         self.__dict__["_pool_bytes"] = 0
         _pinned.trim()
+        _twins.clear()
         if self.h is None:
             return
         for free in pool.values():
@@ -268,12 +298,59 @@ class _PinnedHost:
 _pinned = _PinnedHost()
 
 
+class _HostTwins:
+    """the (host array, device block) pairs of Context.twin_upload: weak on the host side, at most four"""
+
+    KEEP = 4
+
+    def __init__(self):
+        import threading
+
+        self.items = []           # [weakref to the array, context, block, sampled row indices, their content], newest last
+        self._lock = threading.RLock()
+
+    @staticmethod
+    def _rows(a):
+        n = a.shape[0]
+        per_page = max(1, 4096 // max(a.strides[0], 1))
+        idx = np.unique(np.concatenate([np.arange(min(per_page, n)), np.linspace(0, n - 1, min(n, 1024)).astype(np.int64),
+                                        np.arange(max(0, n - per_page), n)]))
+        return idx
+
+    def remember(self, ctx, a, block):
+        import weakref
+
+        idx = self._rows(a)
+        with self._lock:
+            self.items = [it for it in self.items if it[0]() is not None and it[0]() is not a]
+            self.items.append([weakref.ref(a), ctx, block, idx, a[idx].copy()])
+            del self.items[: max(0, len(self.items) - self.KEEP)]
+
+    def lookup(self, ctx, a):
+        with self._lock:
+            for it in self.items:
+                if it[0]() is a and it[1] is ctx:
+                    blk = it[2]
+                    if (blk.n, blk.k) == a.shape and np.array_equal(a[it[3]], it[4]):
+                        return blk
+                    self.items.remove(it)               # the array was changed (or reshaped) since: forget the copy
+                    return None
+        return None
+
+    def clear(self):
+        with self._lock:
+            self.items = []
+
+
+_twins = _HostTwins()
+
+
 def pinned_empty(shape):
     """numpy float64 array in page-locked memory (uploads and downloads of it run at the direct-DMA rate)"""
     return _pinned.empty(tuple(int(v) for v in np.atleast_1d(shape)))
 
 
-_POOL_KEEP_PER_SIZE = 6           # blocks of one size kept for reuse
+_POOL_KEEP_PER_SIZE = 16          # blocks of one size kept for reuse (a short-recurrence step holds ten n x k blocks at once, the numpy surface two more)
 _POOL_MAX_BYTES = 24 * 1024**3     # and in total (the Krylov workspaces have their own cache)
 
 

@@ -641,7 +641,7 @@ class _AdjointAPI:
             lanczos_guess = False
         prob, ctx = self._prob, self._prob.ctx
         self._sync_phi()
-        dPhib = Phib if on_device else ctx.from_host(Phib)
+        dPhib = Phib if on_device else ctx.twin_upload(Phib)     # (read only from here on)
         seq_sibk = method == "sibk" and (kwargs.get("bs_target", 1) != 1 or kwargs.get("update_guess", False))
         cols = None if (method == "dl" or seq_sibk) else self._mode_columns(N, comm)
         sel = np.arange(N) if cols is None else cols
@@ -745,7 +745,9 @@ class _AdjointAPI:
             psi_c.scatter_cols_into(dpsi, cols)
         if on_device:
             return dpsi, data
-        return dpsi.get(), data
+        psi_host = dpsi.get()
+        ctx.twin_adopt(psi_host, dpsi)                           # (handed back to add_total_derivative as it is: no upload then)
+        return psi_host, data
 
     @staticmethod
     def _assemble_G(Gc, sel, N, comm, optional=False):
@@ -762,8 +764,8 @@ class _AdjointAPI:
     def eval_adjoint_residual_norm(self, Phib, psi, b_ortho=False):
         self._sync_phi()
         ctx = self._prob.ctx
-        dPhib = Phib if isinstance(Phib, DeviceBlock) else ctx.from_host(Phib)
-        dpsi = psi if isinstance(psi, DeviceBlock) else ctx.from_host(psi)
+        dPhib = Phib if isinstance(Phib, DeviceBlock) else ctx.twin_upload(Phib)
+        dpsi = psi if isinstance(psi, DeviceBlock) else ctx.twin_upload(psi)
         return adj._residual_norm_device(self._prob, np.asarray(self._lamN(), dtype=float), dPhib, dpsi, b_ortho)
 
     def add_total_derivative(self, lamb, Phib, psi, dAdx, dBdx, dfdx, adj_corr_data={}, deriv_type="vector",
@@ -778,8 +780,8 @@ class _AdjointAPI:
             return dfdx
         self._sync_phi()
         ctx = self._prob.ctx
-        dPhib = Phib if isinstance(Phib, DeviceBlock) else ctx.from_host(Phib)
-        dpsi = psi if isinstance(psi, DeviceBlock) else ctx.from_host(psi)
+        dPhib = Phib if isinstance(Phib, DeviceBlock) else ctx.twin_upload(Phib)   # (both read only below)
+        dpsi = psi if isinstance(psi, DeviceBlock) else ctx.twin_upload(psi)
         cols = self._mode_columns(N, comm)
         return adj._total_derivative_device(self._prob.Phi, dPhib, dpsi, lam, lamb, dAdx, dBdx, dfdx, adj_corr_data,
                                             self.mode, deriv_type, cols, Phi_host=self.Phi, comm=comm)

@@ -19,6 +19,10 @@ pair_defect_tol = 1e-10    # Arnoldi form: w_{j+1}.w_{j+2} above which a two-ste
 predict_finish = True      # enqueue the next cycle only for the modes not expected to finish in the current one
 reorth_tol = 1e-13         # measured second Gram-Schmidt pass: applied where |h2| > reorth_tol |h1|
 
+# ---- the numpy-in / numpy-out surface (device.py: Context.twin_upload)
+host_twins = True          # keep the device copies of Phib and of a returned psi for the next call that is handed the same
+                           # array object (validated against a content sample of 1024 rows + first and last page)
+
 # ---- restarted block Lanczos (lanczos.py)
 iram_block = 0             # block size (0: 8 for n >= 200 000, 4 for n >= 50 000, else the single-vector solver)
 iram_extra = None          # converged pairs beyond N kept for the adjoint stage's deflation (None: min(N, 32) with blocks)

@@ -165,3 +165,57 @@ def test_short_recurrence_steps_aside_where_it_does_not_apply(monkeypatch):
     assert adj.LAST_ROUND["recurrence"] == "arnoldi"
     psi_o, _, _ = orc.sibk(Phib, K, M, lam, Phi, factor=fac2_o, sigma=sig2, rtol=1e-12)
     assert relerr(psi_d, psi_o) < RTOL
+
+
+def test_device_twins_of_host_arrays_follow_the_host_content(monkeypatch):
+    """
+    The numpy surface keeps the device copies of Phib and of the psi it returned for the next call that is handed the
+    same array objects (Context.twin_upload): add_total_derivative then needs no transfer.  A change of either array in
+    between -- scaling, a column, one sampled row -- is seen (the copy is dropped, the array uploaded again); the result
+    always equals the one computed with the copies switched off.
+    """
+    import eigd_amd as eg
+    from eigd_amd import device as dev
+    from eigd_amd.problems import FreePlate
+
+    pl = FreePlate(120, 120, seed=1)                    # 29 282 dof x 8 modes: 1.9 MB per array, above the twin threshold
+    K, M = pl.stiffness(), pl.mass()
+    sigma, N = -10.0, 8
+    fac = eg.SpLuOperator((K - sigma * M).tocsr(), check_symmetry=False)
+    s = eg.BasicLanczos(N=N, m=60)
+    s.solve(K, M, fac, sigma)
+    rng = np.random.default_rng(0)
+    Phib, lamb = rng.uniform(size=(K.shape[0], N)), rng.uniform(size=N)
+    Cm = rng.normal(size=(K.shape[0], 3))
+    cb = lambda w, v: Cm.T @ (np.sum(w * v, axis=1) if w.ndim == 2 else w * v)   # noqa: E731
+
+    def run():
+        psi, data = s.solve_adjoint(Phib, method="sibk", rtol=1e-11)
+        return psi, data
+
+    def derivative(psi, data):
+        return s.add_total_derivative(lamb, Phib, psi, cb, cb, np.zeros(3), adj_corr_data=data, deriv_type="tensor")
+
+    uploads = []
+    orig = dev.Context.from_host
+    monkeypatch.setattr(dev.Context, "from_host", lambda self, a: (uploads.append(np.shape(a)), orig(self, a))[1])
+    monkeypatch.setattr(eg.tuning, "host_twins", True)
+    psi, data = run()
+    big = lambda: [u for u in uploads if len(u) == 2 and u[0] == K.shape[0]]   # noqa: E731
+    n0 = len(big())
+    d1 = derivative(psi, data)
+    assert len(big()) == n0                             # neither Phib nor psi went over the bus again
+    monkeypatch.setattr(eg.tuning, "host_twins", False)
+    d0 = derivative(psi, data)
+    assert len(big()) == n0 + 2 and relerr(d1, d0) < 1e-13
+    monkeypatch.setattr(eg.tuning, "host_twins", True)
+    psi, data = run()
+    # the caller edits psi (a column) and Phib (everything) before the derivative: both copies are stale
+    psi2 = psi
+    psi2[:, 2] *= -1.0
+    np.multiply(Phib, 1.5, out=Phib)
+    n1 = len(big())
+    d2 = derivative(psi2, data)
+    assert len(big()) == n1 + 2
+    monkeypatch.setattr(eg.tuning, "host_twins", False)
+    assert relerr(d2, derivative(psi2, data)) < 1e-13
