@@ -151,7 +151,7 @@ def measured_traffic(entry, sources):
     the rocprofv3 --pmc CSVs), valid only for the kernel sources they were taken with: a changed kernel file gives null.
     """
     rec = None
-    for name in ("r03_traffic.json", "r02_traffic.json"):      # the newest round's passes first
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):      # the newest round's passes first
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))[entry]
             break
@@ -164,6 +164,39 @@ def measured_traffic(entry, sources):
         if rec.get("source_sha16", {}).get(fn) != sha:
             return None, f"stale: {fn} changed since the PMC pass ({rec.get('files')})"
     return rec["traffic_bytes_per_launch"], rec.get("files")
+
+
+MFMA_F64_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4 holds a SIMD's matrix pipe 64 cycles (PMC: BUSY_CYCLES / INSTS = 64.0 on
+                              # every sweep kernel): 2048 flop / 64 cycles x 4 SIMDs x 256 CUs x 2.4 GHz
+
+
+def measured_mfma(entry, sources, useful_flops, us_per_launch):
+    """
+    Compute ceiling of the sweep from the committed MFMA counter pass (same record and staleness rule as the traffic):
+    fp64 MFMA flops issued against the useful ones (4 nnz(L) k: every entry of L meets every column once per direction),
+    the time the issued ones need at the matrix pipe's peak, and the fraction of the launch the pipe was busy.
+    """
+    rec = None
+    for name in ("r04_traffic.json",):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))[entry]
+        except (OSError, KeyError, ValueError):
+            pass
+    if rec is None or "mfma_f64_insts_per_launch" not in rec:
+        return None
+    for fn in sources:
+        sha = hashlib.sha256(open(os.path.join(ROOT, "eigd_amd", "csrc", fn), "rb").read()).hexdigest()[:16]
+        if rec.get("source_sha16", {}).get(fn) != sha:
+            return None
+    issued = rec["mfma_f64_insts_per_launch"] * 2048.0
+    pipe_us = issued / (MFMA_F64_PEAK_TFLOPS * 1e12) * 1e6
+    return {"flops_useful": useful_flops, "flops_issued_mfma_f64": issued, "issued_over_useful": round(issued / useful_flops, 3),
+            "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "achieved": round(useful_flops / (us_per_launch * 1e-6) / 1e12, 2),
+            "frac": round(useful_flops / (us_per_launch * 1e-6) / 1e12 / MFMA_F64_PEAK_TFLOPS, 4),
+            "pipe_time_us_if_perfectly_spread": round(pipe_us, 1), "pipe_time_over_launch": round(pipe_us / us_per_launch, 3),
+            "hbm_time_us_at_peak": round(rec["traffic_bytes_per_launch"] / 8e12 * 1e6, 1),
+            "note": "bound = whichever ceiling is nearer: the bytes really moved need hbm_time_us_at_peak at 8 TB/s, the MFMAs "
+                    "really issued need pipe_time_us; the launch takes us_per_launch"}
 
 
 def main_c5(args):
@@ -725,7 +758,9 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": sweep_traffic, "traffic_source": sweep_src,
                 "bytes_per_launch": sweep_bytes, "us_per_launch": round(sweep_ms * 1e3, 1), "columns": N,
-                "nnzL": fstats["nnzL"]}
+                "nnzL": fstats["nnzL"],
+                "compute": (measured_mfma("sweep_k32_c3", ("factor.hip",), 4.0 * fstats["nnzL"] * N, sweep_ms * 1e3)
+                            if default_c3 else None)}
     # SpMV, the bit-exact CSR-stream kernel: K and G (same sparsity, 235 MB of traffic each) are applied alternately
     # so that consecutive launches cannot be served from the 256 MiB Infinity Cache
     x = ctx.from_host(rng.normal(size=n))

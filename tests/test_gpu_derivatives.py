@@ -376,7 +376,7 @@ def test_g2_natural_frequency_from_the_design_variables(solver):
 
 
 @pytest.mark.parametrize("name,tol", [("g3_thermal32_eps1e-1_basiclanczos", 1e-8), ("g3_thermal32_eps1e-8_basiclanczos", 1e-8),
-                                      ("g3_thermal32_eps1e-8_iram", 3e-8)])
+                                      ("g3_thermal32_eps1e-8_iram", 2e-8)])
 def test_g3_thermal_from_the_design_variables(name, tol):
     """examples/thermal.py end to end on the device (1 dof / node, K and M both design dependent): compliance value and
     df/dx against the reference, nothing of the reference's eigen data adopted.  epsilon = 1e-8: xi / eta of the repeated
@@ -386,7 +386,8 @@ def test_g3_thermal_from_the_design_variables(name, tol):
     repeated-pair formulas carry into df/dx with a factor of ~20: the restarted solver's df/dx moves by 1e-9 ... 1.6e-8
     from one start vector to the next (tools/g3_noise_probe.py, eight start vectors: profiles/r03_g3_chain_noise.txt;
     2e-9 ... 1.9e-8 against the reference, whose ARPACK vectors are one more such draw).  The gate for that case is
-    therefore 3e-8, twice the measured spread; the 1e-8 parity of the branch itself is the other test's."""
+    therefore 2e-8, the edge of the measured spread and the ONLY exception to the 1e-8 of north_star; the 1e-8 parity of
+    the branch itself is the other test's."""
     from eigd_amd import design
     from eigd_amd.device import default_context
 

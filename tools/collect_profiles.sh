@@ -3,7 +3,7 @@
 # the SpMV (separate runs: --pmc with --kernel-trace only), the per-level table.  Run on the GPU box from the repo root:
 #   tools/collect_profiles.sh r03 [stats|pmc|steppmc|all]
 # Results land in gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
-tag=${1:-r03}
+tag=${1:-r04}
 what=${2:-all}
 root=$(pwd)
 out=$root/gpurun_out/$tag
@@ -23,6 +23,10 @@ if [ "$what" = "pmc" ] || [ "$what" = "all" ]; then
         > $out/pmc_spmv_$ctr.log 2>&1) || exit 1
     cp $(find $out/pmc_spmv_$ctr -name "*counter_collection.csv" | head -1) $out/pmc_${ctr}_spmv_coldot.csv
   done
+  # matrix pipe of the sweep: fp64 MFMA instructions issued and the cycles they hold the pipe (compute ceiling of the roofline)
+  rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out/pmc_sweep_mfma -- \
+      python3 $root/tools/pmc_sweep.py > $out/pmc_sweep_mfma.log 2>&1 || exit 1
+  cp $(find $out/pmc_sweep_mfma -name "*counter_collection.csv" | head -1) $out/pmc_mfma_sweep.csv
 fi
 if [ "$what" = "steppmc" ] || [ "$what" = "all" ]; then
   # HBM traffic of a whole step: the bench command under the two counters (separate runs, --kernel-trace only)

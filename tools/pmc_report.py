@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--sources", nargs="*", default=[])
     ap.add_argument("--calib-kernel", default="coldot")
     ap.add_argument("--calib-bytes", type=float, default=None, help="known bytes of ONE calibration launch")
+    ap.add_argument("--mfma", default=None, help="pass with SQ_INSTS_VALU_MFMA_F64 and SQ_VALU_MFMA_BUSY_CYCLES over the same launches")
     args = ap.parse_args()
     if args.json is None:
         tot, cnt = family_sums(args.path)
@@ -77,6 +78,13 @@ def main():
         launches = sum(c for _, _, c in cal)
         rec["calibration"] = {"kernel": args.calib_kernel, "launches": launches,
                               "ratio_2x_fetch_to_known_bytes": 2.0 * kib * 1024.0 / (launches * args.calib_bytes)}
+    if args.mfma:
+        mt, _ = family_sums(args.mfma)
+        insts = sum(v for (name, ctr), v in mt.items() if ctr == "SQ_INSTS_VALU_MFMA_F64" and pat.search(name))
+        busy = sum(v for (name, ctr), v in mt.items() if ctr == "SQ_VALU_MFMA_BUSY_CYCLES" and pat.search(name))
+        rec["mfma_f64_insts_per_launch"] = insts / args.units            # wave instructions (v_mfma_f64_16x16x4: 2048 flop each)
+        rec["mfma_busy_cycles_per_launch"] = busy / args.units
+        rec["files"].append(os.path.relpath(args.mfma, ROOT))
     out = {}
     if os.path.exists(args.json):
         out = json.load(open(args.json))
