@@ -581,6 +581,8 @@ def main():
         scaling_model = {"note": "slowest rank's share of the same 32-mode step, timed on this one GPU (no collective); "
                                  "efficiency = ms_per_step / (P * rank_ms)", "ranks": {}}
         for P_ in (2, 4, 8):
+            if P_ > N:
+                continue
             cm = _LastOfMany(P_)
 
             def rank_step():
