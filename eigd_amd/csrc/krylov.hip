@@ -89,19 +89,21 @@ __global__ __launch_bounds__(kThreads) void cg_dots_kernel(int n, int k, const d
   }
 }
 
-// one workgroup: |r_k|^2 against the tolerance -> done, step; the partial sums -> gam, rho of this step
-__global__ __launch_bounds__(kThreads) void cg_coef_kernel(const double* __restrict__ partial, int nblocks, int k,
-                                                          const double* __restrict__ norm2, double* __restrict__ state,
-                                                          int step, int first) {
+// one workgroup of two waves per column: |r_k|^2 against the tolerance -> done, step; the partial sums -> gam, rho of
+// this step (a single workgroup walking all 2 k sums one after the other took 32 us per step at 32 columns)
+__global__ __launch_bounds__(128) void cg_coef_kernel(const double* __restrict__ partial, int nblocks, int k,
+                                                     const double* __restrict__ norm2, double* __restrict__ state,
+                                                     int step, int first) {
   __shared__ double sums[2 * kMaxK];
+  const int c = blockIdx.x;
   const int wave = threadIdx.x >> 6;
-  for (int o = wave; o < 2 * k; o += kThreads / 64) {
+  {
+    const int o = wave * k + c;   // wave 0: r.z of this column, wave 1: z.y
     const double s = wave_sum_partials(partial, nblocks, 2 * k, o);
     if ((threadIdx.x & 63) == 0) sums[o] = s;
   }
   __syncthreads();
-  const int c = threadIdx.x;
-  if (c >= k) return;
+  if (threadIdx.x != 0) return;
   bool done = state[kDone * kMaxK + c] != 0.0;
   if (!done && norm2 != nullptr && norm2[c] < state[kTol2 * kMaxK + c]) {  // reference 1275: the residual this step started from
     done = true;
@@ -182,14 +184,11 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, int k, const
   }
 }
 
-// one workgroup: the partial squared norms of the new residual -> out[c]
-__global__ __launch_bounds__(kThreads) void cg_norm_kernel(const double* __restrict__ partial, int nblocks, int k,
-                                                          double* __restrict__ out) {
-  const int wave = threadIdx.x >> 6;
-  for (int o = wave; o < k; o += kThreads / 64) {
-    const double s = wave_sum_partials(partial, nblocks, k, o);
-    if ((threadIdx.x & 63) == 0) out[o] = s;
-  }
+// one wave per column: the partial squared norms of the new residual -> out[c]
+__global__ __launch_bounds__(64) void cg_norm_kernel(const double* __restrict__ partial, int nblocks, int k,
+                                                    double* __restrict__ out) {
+  const double s = wave_sum_partials(partial, nblocks, k, blockIdx.x);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 template <typename F>
@@ -231,7 +230,7 @@ int eigd_cg_coefficients(eigd_ctx* ctx, int n, int k, const double* dZ, int ldz,
   });
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cg_coef_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, partial, nb, k, dNorm2, dState, step, first);
+  hipLaunchKernelGGL(cg_coef_kernel, dim3(k), dim3(128), 0, ctx->stream, partial, nb, k, dNorm2, dState, step, first);
   EIGD_LAUNCH_CHECK();
   return EIGD_OK;
 }
@@ -258,7 +257,7 @@ int eigd_cg_update(eigd_ctx* ctx, int n, int k, const double* dR, int ldr, doubl
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();
   if (dNorm2 == nullptr) return EIGD_OK;
-  hipLaunchKernelGGL(cg_norm_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, partial, nb, k, dNorm2);
+  hipLaunchKernelGGL(cg_norm_kernel, dim3(k), dim3(64), 0, ctx->stream, partial, nb, k, dNorm2);
   EIGD_LAUNCH_CHECK();
   return EIGD_OK;
 }

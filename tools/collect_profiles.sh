@@ -11,8 +11,11 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 if [ "$what" = "stats" ] || [ "$what" = "all" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --steps 3 --warmup 1 \
-      --cpu-sample none --no-fd-check --numpy-steps 0 > $out/profiled_run.json 2> $out/profiled_run.log || exit 1
+      --cpu-sample none --no-fd-check --numpy-steps 0 --no-arnoldi-leg --no-scaling-model > $out/profiled_run.json \
+      2> $out/profiled_run.log || exit 1
   cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/bench_c3_kernel_stats.csv
+  python3 $root/tools/step_breakdown.py $out/stats > $out/step_breakdown.txt   # (the trace itself is too big to travel back)
+  find $out/stats -name "*kernel_trace.csv" -delete
 fi
 if [ "$what" = "pmc" ] || [ "$what" = "all" ]; then
   for ctr in FETCH_SIZE WRITE_SIZE; do
@@ -32,7 +35,8 @@ if [ "$what" = "steppmc" ] || [ "$what" = "all" ]; then
   # HBM traffic of a whole step: the bench command under the two counters (separate runs, --kernel-trace only)
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_step_$ctr -- python3 $root/bench.py --steps 2 \
-        --warmup 1 --cpu-sample none --no-fd-check --numpy-steps 0 --spmv-reps 4 > $out/pmc_step_$ctr.json \
+        --warmup 1 --cpu-sample none --no-fd-check --numpy-steps 0 --spmv-reps 4 --no-arnoldi-leg --no-scaling-model \
+        > $out/pmc_step_$ctr.json \
         2> $out/pmc_step_$ctr.log || exit 1
     cp $(find $out/pmc_step_$ctr -name "*counter_collection.csv" | head -1) $out/pmc_${ctr}_step.csv
   done

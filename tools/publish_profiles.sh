@@ -7,7 +7,7 @@ src=gpurun_out/$tag
 if [ "$what" = "stats" ] || [ "$what" = "all" ]; then
   cp $src/bench_c3_kernel_stats.csv profiles/${tag}_bench_c3_kernel_stats.csv
   cp $src/profiled_run.json profiles/${tag}_bench_c3_profiled_run.json
-  python3 tools/step_breakdown.py $src/stats > profiles/${tag}_step_breakdown.txt
+  cp $src/step_breakdown.txt profiles/${tag}_step_breakdown.txt
 fi
 if [ "$what" = "steppmc" ] || [ "$what" = "all" ]; then
   cp $src/step_traffic.txt profiles/${tag}_step_traffic.txt
