@@ -1145,6 +1145,12 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
         j += 1
     st = state.get()
     ok = not np.any(st[_CG_ROWS["flag"], :k] != 0.0) and bool(np.all(np.isfinite(st[_CG_ROWS["rr"], :k])))
+    # an unfinished mode whose residual has not halved over its last ten steps: the recurrence is not converging (the
+    # caller's Phi is not invariant enough for the deflated operator to stay positive definite in finite precision, or
+    # lam is not the eigenvalue of its column): the Arnoldi form, which minimises the true residual step by step, decides
+    for c in range(k):
+        if not converged[c] and len(hist[c]) > 12 and not hist[c][-1] < 0.5 * hist[c][-11]:
+            ok = False
     prob.project_s(psi)                                    # what the measured projections let pass (see proj_tol)
     if prob.fac.native and ok:                            # one factor application per step and mode (ref 1248)
         with prob.fac.factor._count_lock:
@@ -1318,7 +1324,7 @@ def _sibk_device(prob, dPhib, dpsi, lam_c, sigma, rtol, atol, maxiter, nrestart,
             dpsi.assign_lincomb([(1.0, dpsi), (1.0, upd)])
             _emit(callback, hist, range(k))
             return [i for i in inf if i is not None]
-        LAST_ROUND["recurrence"] = "arnoldi (the short recurrence broke down)"
+        LAST_ROUND["recurrence"] = "arnoldi (the short recurrence broke down or stalled)"
         hist = [[] for _ in range(k)]
     pending = np.arange(k)
     for attempt in range(nrestart + 1):                  # ref 1312-1321: restarts reuse the same residual
