@@ -475,8 +475,15 @@ int eigd_spmm_on(eigd_ctx* ctx, eigd_mat* A, const double* dX, int ldx, double* 
     EIGD_LAUNCH_CHECK();
     return EIGD_OK;
   }
-  for (int c0 = 0; c0 < k; c0 += kMaxK) {
-    const int kb = std::min(kMaxK, k - c0);
+  // widest block per launch: 64 columns, or 32 where the tile's rows of X fit the LDS at 32 columns but not at 64 (the
+  // direct-gather kernel that would take a 64-column block is four times slower than two tiled launches of 32)
+  auto tile_fits = [&](int kpv) {
+    const int cplv = (kpv >= 8) ? kpv / 8 : 1;
+    return A->ntiles > 0 && sizeof(double) * static_cast<size_t>(A->umax) * (cplv >= 2 ? kpv + 4 : kpv + 1) <= static_cast<size_t>(kTileLds);
+  };
+  const int chunk = (k > 32 && !tile_fits(64) && tile_fits(32)) ? 32 : kMaxK;
+  for (int c0 = 0; c0 < k; c0 += chunk) {
+    const int kb = std::min(chunk, k - c0);
     const int kp = std::max(2, next_pow2(kb));
     const int rp = kThreads / kp;
     const dim3 grid((A->n + rp - 1) / rp);
