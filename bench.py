@@ -606,17 +606,18 @@ def main():
     # and add_total_derivative, which adds the H2D of Phib and the D2H / H2D of psi: reported next to the value)
     numpy_api = None
     if world == 1 and comm is None and args.numpy_steps > 0:
+        Phib_np = Phib.copy()                          # (the leg's own array: its content is changed from step to step)
         t_each = []
         for _ in range(args.numpy_steps + 2):          # two untimed: page-locked result buffers and Phib's registration
             # a design loop brings new right-hand sides every step: the content of the caller's array changes (outside
             # the timed region), so the device copy kept from the last step is found stale and Phib is uploaded again --
             # once per step; what the kept copies save is the SECOND upload of Phib and the upload of psi (tuning.host_twins)
-            np.multiply(Phib, 1.0 + 1e-9, out=Phib)
+            np.multiply(Phib_np, 1.0 + 1e-9, out=Phib_np)
             ctx.sync()
             t0 = time.perf_counter()
-            psi_np, data_np = solver.solve_adjoint(Phib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1)
+            psi_np, data_np = solver.solve_adjoint(Phib_np, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1)
             t_mid = time.perf_counter()
-            solver.add_total_derivative(lamb, Phib, psi_np, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data_np,
+            solver.add_total_derivative(lamb, Phib_np, psi_np, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data_np,
                                         deriv_type="tensor")
             ctx.sync()
             t_each.append(time.perf_counter() - t0)
@@ -640,10 +641,10 @@ def main():
             if hasattr(mod, "call"):
                 setattr(mod, "call", timed_call)
         try:
-            np.multiply(Phib, 1.0 + 1e-9, out=Phib)
+            np.multiply(Phib_np, 1.0 + 1e-9, out=Phib_np)
             ctx.sync()
-            psi_np, data_np = solver.solve_adjoint(Phib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1)
-            solver.add_total_derivative(lamb, Phib, psi_np, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data_np,
+            psi_np, data_np = solver.solve_adjoint(Phib_np, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1)
+            solver.add_total_derivative(lamb, Phib_np, psi_np, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data_np,
                                         deriv_type="tensor")
             ctx.sync()
         finally:
@@ -654,7 +655,7 @@ def main():
         # the two transfers by themselves (idle GPU): H2D of the caller's (page-locked) Phib, D2H of a block of psi's size
         ctx.sync()
         tq = time.perf_counter()
-        blk_t = ctx.from_host(Phib)
+        blk_t = ctx.from_host(Phib_np)
         ctx.sync()
         t_h2d = time.perf_counter() - tq
         tq = time.perf_counter()
