@@ -107,9 +107,10 @@ class DeviceProblem:
         U, V = self._projector()
         return X.project(U, V)
 
-    def project_r_norm2(self, X, tol=0.0):
-        """project_r followed by the squared column norms of the result (device block; see DeviceBlock.project_norm2)"""
-        U, V = self._projector()
+    def project_r_norm2(self, X, tol=0.0, requested_only=False):
+        """project_r followed by the squared column norms of the result (device block; see DeviceBlock.project_norm2);
+        ``requested_only``: against the N requested pairs even while the extra ones are deflated"""
+        U, V = (self.BPhi, self.Phi) if requested_only else self._projector()
         # the measured update compares |u_a| |c_ab| with |x_b|: the largest column norm of U, once per projector
         which = "D" if U is self.BPhiD else "N"
         if self._uscale.get(which) is None:
@@ -1058,8 +1059,6 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     # largest period that keeps this below 1e-12; the steps in between take their residual norms from the update kernel.
     lam_all = np.asarray(lam_c, dtype=float)
     lam_defl = lam_all if prob.lam_phi is None else np.asarray(prob.lam_phi, dtype=float)
-    if prob.use_extra and prob.lam_x is not None:
-        lam_defl = np.concatenate([lam_defl, prob.lam_x])
     with np.errstate(divide="ignore", invalid="ignore"):
         g = np.nanmax(np.abs(1.0 - (lam_all[:, None] - sigma) / (lam_defl[None, :] - sigma)))
     proj_every = 1
@@ -1110,7 +1109,10 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     while True:
         lo, hi = rng_j
         if project_in(j):
-            n2 = prob.project_r_norm2(r.cols(lo, hi), tol=proj_tol)   # ref 1257 + the residual norm of 1275; measured update
+            # ref 1257 + the residual norm of 1275; measured update.  Against the N requested pairs only: along an extra
+            # pair (lam_j above every lam_i) the eigenvalue of C_i lies in (0, 1) -- rounding there shrinks from step
+            # to step like any other part of the residual, it is the pairs BELOW a mode that amplify
+            n2 = prob.project_r_norm2(r.cols(lo, hi), tol=proj_tol, requested_only=True)
         else:
             n2 = norms_of[j]                               # (formed by the update kernel of this step)
             call("eigd_colnorm2_publish", ctx.h, n2.ptr, hi - lo)
