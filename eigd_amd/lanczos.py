@@ -407,6 +407,7 @@ class _BlockLanczosDevice:
         self.scratch = None
         self.sweeps = 0
         self.reorth_passes = 0
+        self._arrow = True                                 # the next step's block couples to the whole basis
 
     def basis_to_host(self, m):
         return self.V.to_host(m)
@@ -478,17 +479,31 @@ class _BlockLanczosDevice:
         # panel); then what that pass left along the basis is MEASURED panel by panel and removed where it matters:
         # |coefficient| > 1e-13 |x_b|_B, the B-norm of the column as the first pass left it (x_b^T B x_b formed on the
         # device) -- the relative B-orthogonality of the new vectors, whatever the scale of B; decided on the device.
+        # The first pass takes the last two blocks only, except in the step behind a restart: the three-term
+        # recurrence leaves OP v_j components of rounding size along everything older (the arrow of a thick restart is
+        # in its first block column alone), so the pass over the whole basis is the measured one below -- and what it
+        # finds is small against the block, which is the case in which one Gram-Schmidt pass is enough.
         nc, npan = self.V.ncols, self.V.npanels
+        lo = max(0, c - 2 * p) if (tuning.lanczos_local_first_pass and not self._arrow) else 0
+        self._arrow = False
         pieces = list(zip(self.V.pieces(0, c), self.BV.pieces(0, c)))
-        for (Vb, a, b), (BVb, _, _) in pieces:
-            X.project_to(Vb, BVb, Hd.rows(a, b))
+        if lo > 0:
+            Hd.rows(0, lo).zero()
+        for (Vb, a, b), (BVb, _, _) in zip(self.V.pieces(lo, c), self.BV.pieces(lo, c)):
+            X.project_to(Vb, BVb, Hd.rows(lo + a, lo + b))
         r0 = 2 * nc + npan
-        nb2 = Hd.rows(r0 + p + 1, r0 + p + 2)
-        self.prob.opB.apply(X, BX)
-        X.coldot_dev(BX, nb2)
-        for q, ((Vb, a, b), (BVb, _, _)) in enumerate(pieces):
-            X.project_to(Vb, BVb, Hd.rows(nc + a, nc + b), tol=1e-13, flag=Hd.rows(2 * nc + q, 2 * nc + q + 1).cols(0, 1),
-                         norm2=nb2)
+        if lo > 0:
+            # (what the local pass left along the older vectors is never below the 1e-13 of the rule underneath: applied
+            # without the measurement, which would cost a product with B for the norms)
+            for (Vb, a, b), (BVb, _, _) in pieces:
+                X.project_to(Vb, BVb, Hd.rows(nc + a, nc + b))
+        else:
+            nb2 = Hd.rows(r0 + p + 1, r0 + p + 2)
+            self.prob.opB.apply(X, BX)
+            X.coldot_dev(BX, nb2)
+            for q, ((Vb, a, b), (BVb, _, _)) in enumerate(pieces):
+                X.project_to(Vb, BVb, Hd.rows(nc + a, nc + b), tol=1e-13, flag=Hd.rows(2 * nc + q, 2 * nc + q + 1).cols(0, 1),
+                             norm2=nb2)
         # B-orthonormalisation of the block (SVQB, twice) on the device
         Cd, flag = Hd.rows(r0, r0 + p), Hd.rows(r0 + p, r0 + p + 1).cols(0, 1)
         if p <= 32:
@@ -501,17 +516,17 @@ class _BlockLanczosDevice:
             Chost = self._orthonormalise(X, BX, tmp)
         self.V.set_block(c, X)
         self.BV.set_block(c, BX)
-        return (Hd, c, p, len(pieces), Chost)
+        return (Hd, c, p, lo > 0, Chost)
 
     def expand_end(self, token):
         """(H (c x p), C (p x p)) of a step enqueued by expand_begin; one synchronisation fetches its coefficient slot"""
-        Hd, c, p, npieces, Chost = token
+        Hd, c, p, unconditional, Chost = token
         nc, npan = self.V.ncols, self.V.npanels
         Hall = Hd.get()
         H = Hall[:c].copy()
         again = False
         for q, (_, a, b) in enumerate(self.V.pieces(0, c)):
-            if Hall[2 * nc + q, 0] != 0.0:
+            if unconditional or Hall[2 * nc + q, 0] != 0.0:
                 H[a:b] += Hall[nc + a: nc + b]
                 again = True
         self.reorth_passes += int(again)
@@ -545,6 +560,7 @@ class _BlockLanczosDevice:
                 src.times_into(dst.view(a, b), S[:, a:b], ns=c)
             dst.set_block(keep, src.get_block(c, p, out=self._work(p)[2]))   # the residual block follows the kept vectors
             src.swap(dst)
+        self._arrow = True
 
 
 class _AdjointAPI:

@@ -29,6 +29,8 @@ iram_extra = None          # converged pairs beyond N kept for the adjoint stage
 iram_basis = 0             # internal basis size (0: max(m, 2 (N + extra) + block))
 iram_extra_tol = 1e-11     # convergence tolerance of the extra pairs (relative to |theta|)
 iram_seed = 12345          # seed of the start block
+lanczos_local_first_pass = True   # Gram-Schmidt of a Lanczos step: first pass against the last two blocks only (the
+                           # recurrence), then ONE measured pass over the whole basis; False: both passes over all of it
 deflate_extra = True       # the adjoint stage deflates the extra pairs and adds their share of psi in closed form
 laa_internal = True        # the block run's own basis serves the first guess of solve_adjoint
 laa_relation = True        # ... formed through the Lanczos relation of that basis (no factor application)
