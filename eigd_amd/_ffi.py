@@ -105,7 +105,7 @@ _SIGNATURES = {
     "eigd_scale_inv_norm": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp],
     "eigd_copy_block": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_cg_state_rows": [],
-    "eigd_cg_coefficients": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int],
+    "eigd_cg_coefficients": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp],
     "eigd_cg_update": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp,
                        c_int, c_vp],
     "eigd_gather_cols": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int],

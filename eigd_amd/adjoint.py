@@ -1007,15 +1007,43 @@ def _short_recurrence_applies(prob):
 
 
 _CG_ROWS = {"rr": 0, "gam": 1, "rho": 2, "done": 3, "tol2": 4, "alpha": 5, "steps": 6, "flag": 7}
+_CG_CHUNK = 16             # slabs per allocation of the z history
+
+
+def _cg_solution_coefficients(log, k):
+    """
+    ``log`` (2 steps x 64): rows 2 (j - 1), 2 (j - 1) + 1 = gam_j, rho_j of step j per column (gam = 0: the column did not
+    move).  The three-term recurrence psi_j = rho_j (psi_{j-1} + gam_j z_j) + (1 - rho_j) psi_{j-2} is the two-term form
+    psi_j = psi_{j-1} + alpha_j p_j, p_j = z_j + beta_{j-1} p_{j-1} with alpha_j = rho_j gam_j and
+    beta_{j-1} = (rho_j - 1) alpha_{j-1} / alpha_j, so psi_m = sum_j s_j z_j with s_m = alpha_m, s_j = alpha_j + beta_j s_{j+1}
+    -- all positive for a positive definite operator: no cancellation in the sum.  Returns S (steps x k).
+    """
+    nst = log.shape[0] // 2
+    gam, rho = log[0::2, :k], log[1::2, :k]
+    S = np.zeros((nst, k))
+    for c in range(k):
+        mv = np.flatnonzero(gam[:, c] != 0.0)              # the steps in which the column moved, in order
+        if mv.size == 0:
+            continue
+        alpha = rho[mv, c] * gam[mv, c]
+        s = alpha[-1]
+        S[mv[-1], c] = s
+        for i in range(mv.size - 2, -1, -1):
+            beta = (rho[mv[i + 1], c] - 1.0) * alpha[i] / alpha[i + 1]
+            s = alpha[i] + beta * s
+            S[mv[i], c] = s
+    return S
 
 
 def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     """
     All columns of R0 (at most 64) by conjugate gradients in the factor inner product, in lock step.  Same Krylov spaces
     as the Arnoldi form (reference 1246-1277), same stopping rule on the true Euclidean residual (1275), no Krylov
-    history: per step ONE multi-column sweep, one SpMM, one measured projection and three streaming kernels over the
-    work blocks (three-term recurrences for residual and solution, csrc/krylov.hip); every per-mode scalar stays on the
-    device, the host reads the residual norms of a step behind the next step already in flight.  Returns (update block,
+    history: per step ONE multi-column sweep, one SpMM, one measured projection and two streaming kernels over the
+    work blocks (three-term recurrence for the residual, csrc/krylov.hip); every per-mode scalar stays on the device, the
+    host reads the residual norms of a step behind the next step already in flight.  The solution is formed once, at the
+    end: psi = sum_k s_k z_k over the z = factor(r) of the steps, which the sweeps leave in the slabs of a history stack
+    (tuning.cg_solution_from_history; the coefficients s_k > 0 from the (gam, rho) log of the device).  Returns (update block,
     converged flags, info list, ok); ok False = a breakdown was flagged (the operator was not positive definite in the
     deflated space): the caller redoes the solve in the Arnoldi form.
     """
@@ -1048,7 +1076,16 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     st_h[_CG_ROWS["alpha"], :k] = sgn * (np.asarray(lam_c, dtype=float) - sigma)   # ref 1264-1269
     state = ctx.from_host(st_h)
     r = ctx.empty(n, k).copy_from(R0)
-    r_old, psi_old, z, y = ctx.empty(n, k), ctx.zeros(n, k), ctx.empty(n, k), ctx.empty(n, k)
+    r_old, y = ctx.empty(n, k), ctx.empty(n, k)
+    deferred = bool(tuning.cg_solution_from_history)
+    if deferred:
+        psi_old = z = None
+        zchunks = []                                       # stacks of _CG_CHUNK slabs each, kept between calls
+        log = ctx.zeros(2 * (maxsteps + 2), 64)            # (gam, rho) of every step, written by eigd_cg_coefficients
+    else:
+        psi_old, z = ctx.zeros(n, k), ctx.empty(n, k)
+        log = None
+    failed = []                                            # (no memory for another chunk of the history)
     # what the measured projection lets pass: a component along B Phi_D of relative size 1e-11 grows by |1 - alpha theta_j|
     # per step until it is taken out again; psi carries it at that relative size at most, and is projected once at the end
     proj_tol = 1e-11
@@ -1065,9 +1102,19 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     if np.isfinite(g):
         proj_every = int(max(1, min(4, np.floor(np.log(1e4) / np.log(max(4.0 * g, 1.0 + 1e-12))))))
     LAST_ROUND["cg_projection_period"] = proj_every
+    LAST_ROUND["cg_solution"] = "from the z history" if deferred else "recurrence"
 
     def sptr(lo):
         return state.cols(lo, 64).ptr
+
+    def zslab(j):
+        """the block step j's sweep writes: a slab of the history (deferred solution) or the one work block"""
+        if not deferred:
+            return z
+        q, i = divmod(j - 1, _CG_CHUNK)
+        while len(zchunks) <= q:
+            zchunks.append(ctx.workspace_stack(("cg_z", len(zchunks), k), _CG_CHUNK, n, k))
+        return zchunks[q][i]
 
     norms_of = {}                                          # step -> device block of its residual norms (unprojected steps)
 
@@ -1078,19 +1125,29 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
         """sweep of the residual of step j - 1, product, coefficients, the two recurrences (no synchronisation)"""
         nonlocal r, r_old, psi, psi_old
         kk = hi - lo
-        rv, zv, yv = r.cols(lo, hi), z.cols(lo, hi), y.cols(lo, hi)
+        try:
+            zj = zslab(j)
+        except _ffi.EigdHipError:
+            failed.append(j)
+            return
+        rv, zv, yv = r.cols(lo, hi), zj.cols(lo, hi), y.cols(lo, hi)
         prob.fac.apply_to(rv, zv, count=0)                # ref 1248
         Kop.apply(zv, yv)                                 # ref 1250 / 1252
         n2p = None if n2 is None else n2.cols(lo - n2_lo, hi - n2_lo).ptr
         call("eigd_cg_coefficients", ctx.h, n, kk, zv.ptr, zv.ld, rv.ptr, rv.ld, yv.ptr, yv.ld, n2p, sptr(lo), int(j),
-             1 if j == 1 else 0)
-        rov, psv, pov = r_old.cols(lo, hi), psi.cols(lo, hi), psi_old.cols(lo, hi)
+             1 if j == 1 else 0, log.cols(lo, 64).ptr if deferred else None)
+        rov = r_old.cols(lo, hi)
         own = None if project_in(j) else ctx.empty(1, kk)  # (a step that is not projected forms its own residual norms)
-        call("eigd_cg_update", ctx.h, n, kk, rv.ptr, rv.ld, rov.ptr, rov.ld, psv.ptr, psv.ld, pov.ptr, pov.ld, zv.ptr, zv.ld,
-             yv.ptr, yv.ld, sptr(lo), 1 if j == 1 else 0, own.ptr if own is not None else None)
-        norms_of[j] = own
-        r, r_old = r_old, r                                # (all columns of a block share the parity: the ranges lag one
-        psi, psi_old = psi_old, psi                        # step behind the flags, see below)
+        if deferred:
+            call("eigd_cg_update", ctx.h, n, kk, rv.ptr, rv.ld, rov.ptr, rov.ld, None, 0, None, 0, None, 0,
+                 yv.ptr, yv.ld, sptr(lo), 1 if j == 1 else 0, own.ptr if own is not None else None)
+        else:
+            psv, pov = psi.cols(lo, hi), psi_old.cols(lo, hi)
+            call("eigd_cg_update", ctx.h, n, kk, rv.ptr, rv.ld, rov.ptr, rov.ld, psv.ptr, psv.ld, pov.ptr, pov.ld, zv.ptr,
+                 zv.ld, yv.ptr, yv.ld, sptr(lo), 1 if j == 1 else 0, own.ptr if own is not None else None)
+            psi, psi_old = psi_old, psi                    # (all columns of a block share the parity: the ranges lag one
+        norms_of[j] = own                                  # step behind the flags, see below)
+        r, r_old = r_old, r
 
     lo, hi = _active_range(done)
     prob.project_r_norm2(r.cols(lo, hi))                  # ref 1232 (the caller projected already, 1193: measured)
@@ -1136,6 +1193,8 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
             if norms2[c - lo] < tol2:                     # ref 1275 (the comparison the device makes in eigd_cg_coefficients)
                 info[c] = j
                 done[c] = converged[c] = True
+        if failed:
+            break
         if done.all() or j == maxsteps:
             # (a step in flight behind the last one only copies: every column is frozen by then, both buffers hold psi)
             LAST_ROUND["cg_sweeps_for_nothing"] = LAST_ROUND.get("cg_sweeps_for_nothing", 0) + int(in_flight)
@@ -1146,13 +1205,20 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
         rng_j = nxt
         j += 1
     st = state.get()
-    ok = not np.any(st[_CG_ROWS["flag"], :k] != 0.0) and bool(np.all(np.isfinite(st[_CG_ROWS["rr"], :k])))
+    ok = not failed and not np.any(st[_CG_ROWS["flag"], :k] != 0.0) and bool(np.all(np.isfinite(st[_CG_ROWS["rr"], :k])))
     # an unfinished mode whose residual has not halved over its last ten steps: the recurrence is not converging (the
     # caller's Phi is not invariant enough for the deflated operator to stay positive definite in finite precision, or
     # lam is not the eigenvalue of its column): the Arnoldi form, which minimises the true residual step by step, decides
     for c in range(k):
         if not converged[c] and len(hist[c]) > 12 and not hist[c][-1] < 0.5 * hist[c][-11]:
             ok = False
+    if deferred and ok:
+        S = _cg_solution_coefficients(log.get(), k)
+        ok = bool(np.all(np.isfinite(S)))
+        for q, chunk in enumerate(zchunks):
+            Sq = S[q * _CG_CHUNK:(q + 1) * _CG_CHUNK]
+            if ok and Sq.size and np.any(Sq != 0.0):
+                chunk.axpy_into(psi, Sq)
     prob.project_s(psi)                                    # what the measured projections let pass (see proj_tol)
     if prob.fac.native and ok:                            # one factor application per step and mode (ref 1248)
         with prob.fac.factor._count_lock:

@@ -172,6 +172,11 @@ __global__ __launch_bounds__(kThreads) void stack_dot_kernel(int n, int k, int n
   }
 }
 
+// masked lanes load this word (address select) instead of branching around the load: loads in divergent branches
+// make the compiler wait for ALL outstanding memory operations (vmcnt(0)) at every later use -- including every
+// store, which then run one at a time
+__device__ const double g_zero_word = 0.0;
+
 // T[r][c] += alpha * sum_j S_j[r][c] * H[j][c]   (H on the device, ns x k)
 template <int KP>
 __global__ __launch_bounds__(kThreads) void stack_axpy_kernel(int n, int k, int ns, const double* __restrict__ S,
@@ -188,14 +193,14 @@ __global__ __launch_bounds__(kThreads) void stack_axpy_kernel(int n, int k, int 
     double s = 0.0;
     int j = 0;
     for (; j + 8 <= ns; j += 8) {
-      double sv[8];
+      double sv[8], h[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) sv[q] = sp[(j + q) * slab];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {  // a zero coefficient skips its slab entry, whatever bits it holds (never-written columns)
-        const double h = Hs[(j + q) * k + c];
-        s += (h != 0.0) ? sv[q] * h : 0.0;
+      for (int q = 0; q < 8; ++q) {  // a zero coefficient skips its slab entry: never-written columns are not read at all
+        h[q] = Hs[(j + q) * k + c];
+        sv[q] = *((h[q] != 0.0) ? sp + (j + q) * slab : &g_zero_word);
       }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += sv[q] * h[q];
     }
     for (; j < ns; ++j) {
       const double h = Hs[j * k + c];
@@ -440,11 +445,6 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(int n, int ku, int kx
     }
   }
 }
-
-// masked lanes load this word (address select) instead of branching around the load: loads in divergent branches
-// make the compiler wait for ALL outstanding memory operations (vmcnt(0)) at every later use -- including every
-// store, which then run one at a time
-__device__ const double g_zero_word = 0.0;
 
 // The same product for WIDE results (more than four 16 x 16 tiles: the projection coefficients Phi_D^T [T1 | T2], 63 x 64)
 // with row-major U: in the direct form above every wave reads the fragments of its own tiles from global memory, so

@@ -16,6 +16,12 @@
 //     r_{k+1}   = rho (r_k - gam (r_k - alpha y)) + (1 - rho) r_{k-1};   r_{k+1} <- P r_{k+1}   (1257)
 //     psi_{k+1} = rho (psi_k + gam z)             + (1 - rho) psi_{k-1}
 //
+// The solution recurrence need not run at all: with alpha_k = rho_k gam_k and beta_k = (rho_{k+1} - 1) alpha_k / alpha_{k+1}
+// it is the two-term form psi_{k+1} = psi_k + alpha_k p_k, p_k = z_k + beta_{k-1} p_{k-1}, so the final psi is a combination
+// of the z_k with POSITIVE coefficients s_k = alpha_k + beta_k s_{k+1}.  The caller keeps every step's z (the sweep writes
+// it into a slab of a history stack instead of a work block: no extra traffic), passes no psi blocks to eigd_cg_update
+// (four streaming passes per step instead of eight) and forms psi once at the end from the (gam, rho) log below.
+//
 // |r_{k+1}| is the true Euclidean residual norm of 1275.  All modes advance in lock step as columns of n x k row-major
 // blocks; every scalar above is a per-column number that never leaves the device: state[row][column], rows below.  A
 // column is frozen from the step on in which its residual norm meets the tolerance, so its psi does not depend on how
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void cg_dots_kernel(int n, int k, const d
 // this step (a single workgroup walking all 2 k sums one after the other took 32 us per step at 32 columns)
 __global__ __launch_bounds__(128) void cg_coef_kernel(const double* __restrict__ partial, int nblocks, int k,
                                                      const double* __restrict__ norm2, double* __restrict__ state,
-                                                     int step, int first) {
+                                                     int step, int first, double* __restrict__ log) {
   __shared__ double sums[2 * kMaxK];
   const int c = blockIdx.x;
   const int wave = threadIdx.x >> 6;
@@ -135,11 +141,15 @@ __global__ __launch_bounds__(128) void cg_coef_kernel(const double* __restrict__
   }
   state[kGamNow * kMaxK + c] = gam;  // gam == 0: the column does not move in this step
   state[kRhoNow * kMaxK + c] = rho;
+  if (log != nullptr) {              // (gam, rho) of every step, for the caller that forms psi from the z history
+    log[(static_cast<int64_t>(step) - 1) * 2 * kMaxK + c] = gam;
+    log[(static_cast<int64_t>(step) - 1) * 2 * kMaxK + kMaxK + c] = rho;
+  }
 }
 
 // r_{k+1} = rho (r - gam (r - alpha y)) + (1 - rho) r_old  and  psi_{k+1} = rho (psi + gam z) + (1 - rho) psi_old, written
 // over r_old / psi_old (the caller swaps the roles of the buffers); columns that do not move are copied
-template <int KP>
+template <int KP, bool PSI>
 __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, int k, const double* __restrict__ r, int ldr,
                                                             double* __restrict__ ro, int ldro,
                                                             const double* __restrict__ psi, int ldpsi,
@@ -158,19 +168,21 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, int k, const
   const bool moves = gam != 0.0;
   const bool three = moves && !first && rho != 1.0;
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * RP + rr; row < n; row += static_cast<int64_t>(gridDim.x) * RP) {
-    const double rv = r[row * ldr + c], sv = psi[row * ldpsi + c];
+    const double rv = r[row * ldr + c];
+    double sv = 0.0;
+    if constexpr (PSI) sv = psi[row * ldpsi + c];
     double rn = rv, sn = sv;
     if (moves) {
-      const double zv = z[row * ldz + c], yv = y[row * ldy + c];
+      const double yv = y[row * ldy + c];
       rn = rv - gam * (rv - al * yv);
-      sn = sv + gam * zv;
+      if constexpr (PSI) sn = sv + gam * z[row * ldz + c];
       if (three) {
         rn = rho * rn + (1.0 - rho) * ro[row * ldro + c];
-        sn = rho * sn + (1.0 - rho) * pso[row * ldpso + c];
+        if constexpr (PSI) sn = rho * sn + (1.0 - rho) * pso[row * ldpso + c];
       }
     }
     ro[row * ldro + c] = rn;
-    pso[row * ldpso + c] = sn;
+    if constexpr (PSI) pso[row * ldpso + c] = sn;
     nrm += rn * rn;
   }
   }
@@ -216,7 +228,7 @@ extern "C" {
 int eigd_cg_state_rows(void) { return kCgRows; }
 
 int eigd_cg_coefficients(eigd_ctx* ctx, int n, int k, const double* dZ, int ldz, const double* dR, int ldr, const double* dY,
-                         int ldy, const double* dNorm2, double* dState, int step, int first) {
+                         int ldy, const double* dNorm2, double* dState, int step, int first, double* dLog) {
   EIGD_REQUIRE(ctx && dZ && dR && dY && dState, "null argument");
   EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldz >= k && ldr >= k && ldy >= k, "bad shape n=%d k=%d", n, k);
   const int kp = next_pow2(k);
@@ -230,7 +242,8 @@ int eigd_cg_coefficients(eigd_ctx* ctx, int n, int k, const double* dZ, int ldz,
   });
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cg_coef_kernel, dim3(k), dim3(128), 0, ctx->stream, partial, nb, k, dNorm2, dState, step, first);
+  hipLaunchKernelGGL(cg_coef_kernel, dim3(k), dim3(128), 0, ctx->stream, partial, nb, k, dNorm2, dState, step, first,
+                     dLog);
   EIGD_LAUNCH_CHECK();
   return EIGD_OK;
 }
@@ -238,8 +251,11 @@ int eigd_cg_coefficients(eigd_ctx* ctx, int n, int k, const double* dZ, int ldz,
 int eigd_cg_update(eigd_ctx* ctx, int n, int k, const double* dR, int ldr, double* dRold, int ldro, const double* dPsi,
                    int ldpsi, double* dPsiOld, int ldpso, const double* dZ, int ldz, const double* dY, int ldy,
                    const double* dState, int first, double* dNorm2) {
-  EIGD_REQUIRE(ctx && dR && dRold && dPsi && dPsiOld && dZ && dY && dState, "null argument");
-  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldr >= k && ldro >= k && ldpsi >= k && ldpso >= k && ldz >= k && ldy >= k,
+  EIGD_REQUIRE(ctx && dR && dRold && dY && dState, "null argument");
+  const bool with_psi = dPsi != nullptr;   // without: the residual recurrence alone (psi from the z history, see the header)
+  EIGD_REQUIRE(!with_psi || (dPsiOld && dZ), "the solution recurrence needs psi, psi_old and z");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ldr >= k && ldro >= k && ldy >= k &&
+                   (!with_psi || (ldpsi >= k && ldpso >= k && ldz >= k)),
                "bad shape n=%d k=%d", n, k);
   const int kp = next_pow2(k);
   const int nb = cg_grid(n, (kThreads / kp) * 4);
@@ -251,8 +267,12 @@ int eigd_cg_update(eigd_ctx* ctx, int n, int k, const double* dR, int ldr, doubl
     partial = ctx->scratch;
   }
   rc = cg_dispatch_kp(k, [&](auto KP) {
-    hipLaunchKernelGGL(cg_update_kernel<decltype(KP)::value>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dR, ldr, dRold,
-                       ldro, dPsi, ldpsi, dPsiOld, ldpso, dZ, ldz, dY, ldy, dState, first, partial);
+    if (with_psi)
+      hipLaunchKernelGGL((cg_update_kernel<decltype(KP)::value, true>), dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dR, ldr,
+                         dRold, ldro, dPsi, ldpsi, dPsiOld, ldpso, dZ, ldz, dY, ldy, dState, first, partial);
+    else
+      hipLaunchKernelGGL((cg_update_kernel<decltype(KP)::value, false>), dim3(nb), dim3(kThreads), 0, ctx->stream, n, k, dR, ldr,
+                         dRold, ldro, dPsi, ldpsi, dPsiOld, ldpso, dZ, ldz, dY, ldy, dState, first, partial);
   });
   if (rc) return rc;
   EIGD_LAUNCH_CHECK();

@@ -13,6 +13,8 @@ bench.py adds EIGD_LAUNCH_TIMEOUT.
 recurrence = "auto"        # "auto": conjugate gradients in the factor inner product when the shift is positive definite
                            # (short recurrence, no Krylov history), else the Arnoldi form; "arnoldi": always the
                            # reference's form (full Gram-Schmidt against the history, Hessenberg least squares)
+cg_solution_from_history = True   # short recurrence: psi = sum_k s_k z_k once at the end from the kept z of every step
+                           # (four streaming passes per step); False: the three-term recurrence for psi runs along (eight)
 steps_per_pass = 2         # Arnoldi form: Krylov steps per Gram-Schmidt pass (1 = orthogonalise every step)
 inner_projections = False  # Arnoldi form: True keeps the projections behind both operator applications (ref 1250-1252)
 pair_defect_tol = 1e-10    # Arnoldi form: w_{j+1}.w_{j+2} above which a two-step solve is redone in the one-step form

@@ -246,15 +246,20 @@ int eigd_scale_inv_norm(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, 
  * dState + first column of the block it works on.
  *   eigd_cg_coefficients  dNorm2 (device, |r_k|^2 per column from eigd_project_norm2, or null) < tol^2 -> done;
  *                         with z = factor(r_k) (1248) and y = K z (1250-1252): gam = r.z / (r.z - alpha z.y) and
- *                         rho = 1 / (1 - (gam/gam')(r.z / r'.z') / rho')  (rho = 1 when first != 0)
+ *                         rho = 1 / (1 - (gam/gam')(r.z / r'.z') / rho')  (rho = 1 when first != 0); dLog (device, may
+ *                         be null; like dState offset by the block's first column): row 2 (step - 1) receives gam,
+ *                         row 2 (step - 1) + 1 rho of this step (rows of 64 doubles; gam = 0: the column did not move)
  *   eigd_cg_update        r_old <- rho (r - gam (r - alpha y)) + (1 - rho) r_old,
  *                         psi_old <- rho (psi + gam z) + (1 - rho) psi_old  (psi of 1277; finished modes: copies) --
- *                         the caller swaps the roles of the two buffers afterwards.  dNorm2 (device, k; may be null):
+ *                         the caller swaps the roles of the two buffers afterwards.  dPsi null: the residual alone --
+ *                         psi_m = sum_k s_k z_k with s_m = alpha_m, s_k = alpha_k + beta_k s_{k+1}, alpha_k = rho_k gam_k,
+ *                         beta_k = (rho_{k+1} - 1) alpha_k / alpha_{k+1} is then the caller's to form from the z it kept
+ *                         and the log (eigd_stack_axpy).  dNorm2 (device, k; may be null):
  *                         the squared column norms of the new residual, formed in the same pass (for the steps whose
  *                         residual is not projected; eigd_colnorm2_publish hands them to the host) */
 int eigd_cg_state_rows(void);
 int eigd_cg_coefficients(eigd_ctx* ctx, int n, int k, const double* dZ, int ldz, const double* dR, int ldr, const double* dY,
-                         int ldy, const double* dNorm2, double* dState, int step, int first);
+                         int ldy, const double* dNorm2, double* dState, int step, int first, double* dLog);
 int eigd_cg_update(eigd_ctx* ctx, int n, int k, const double* dR, int ldr, double* dRold, int ldro, const double* dPsi,
                    int ldpsi, double* dPsiOld, int ldpso, const double* dZ, int ldz, const double* dY, int ldy,
                    const double* dState, int first, double* dNorm2);

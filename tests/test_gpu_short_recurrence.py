@@ -38,6 +38,14 @@ def _both_forms(monkeypatch, solve):
         monkeypatch.setattr(eg.tuning, "recurrence", form)
         out[form] = solve()
         assert adj.LAST_ROUND["recurrence"] == ("short" if form == "auto" else "arnoldi"), adj.LAST_ROUND["recurrence"]
+    # the short form once more with the solution's own three-term recurrence running along instead of psi formed at the end
+    # from the z history: same iterates (result [0] = psi, [2] = steps per mode)
+    monkeypatch.setattr(eg.tuning, "recurrence", "auto")
+    monkeypatch.setattr(eg.tuning, "cg_solution_from_history", False)
+    alt = solve()
+    assert adj.LAST_ROUND["recurrence"] == "short" and adj.LAST_ROUND["cg_solution"] == "recurrence"
+    monkeypatch.setattr(eg.tuning, "cg_solution_from_history", True)
+    assert relerr(alt[0], out["auto"][0]) < 1e-11 and list(alt[2]) == list(out["auto"][2])
     return out["auto"], out["arnoldi"]
 
 
