@@ -1081,7 +1081,7 @@ class IRAM(_AdjointAPI):
         if p == 1:
             return 1, extra, m
         k_want = N + extra
-        m_int = int(tuning.iram_basis) or max(m, 2 * k_want + p)
+        m_int = int(tuning.iram_basis) or max(m, int(np.ceil(tuning.iram_basis_factor * k_want)) + p)
         m_int = p * (-(-m_int // p))
         if m_int + p > n:
             return 1, min(extra, max(0, m - 1 - N)), m

@@ -28,7 +28,8 @@ host_twins = True          # keep the device copies of Phib and of a returned ps
 # ---- restarted block Lanczos (lanczos.py)
 iram_block = 0             # block size (0: 8 for n >= 200 000, 4 for n >= 50 000, else the single-vector solver)
 iram_extra = None          # converged pairs beyond N kept for the adjoint stage's deflation (None: min(N, 32) with blocks)
-iram_basis = 0             # internal basis size (0: max(m, 2 (N + extra) + block))
+iram_basis = 0             # internal basis size (0: max(m, iram_basis_factor (N + extra) + block))
+iram_basis_factor = 2.5    # (2 -> 2.5: C3 -5 %, C4 -7 %, C2 unchanged; beyond 2.5 nothing more)
 iram_extra_tol = 1e-11     # convergence tolerance of the extra pairs (relative to |theta|)
 iram_seed = 12345          # seed of the start block
 lanczos_local_first_pass = True   # Gram-Schmidt of a Lanczos step: first pass against the last two blocks only (the
