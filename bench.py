@@ -447,8 +447,6 @@ def main():
         _adj.LAST_ROUND["gs_cycles"] = _adj.LAST_ROUND["gs_correcting_passes"] = 0
         _adj.LAST_ROUND["post_gs_projections"] = _adj.LAST_ROUND["post_gs_updates_applied"] = 0
         _adj.LAST_ROUND["cycles_enqueued_for_nothing"] = _adj.LAST_ROUND["cycles_waited_for"] = 0
-        for key in ("cg_steps", "cg_projections", "cg_projection_updates", "cg_sweeps_for_nothing", "cg_waited_for"):
-            _adj.LAST_ROUND[key] = 0
         dpsi, data = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1,
                                           comm=comm, streams=args.streams)
         dfdx = solver.add_total_derivative(lamb, dPhib, dpsi, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data,
@@ -877,7 +875,8 @@ def main():
         "eigensolver": eig_info,
         "lock_step": {"recurrence": last_round.get("recurrence"),
                       "cg": {key[3:]: last_round.get(key) for key in ("cg_steps", "cg_projections", "cg_projection_updates",
-                                                                      "cg_sweeps_for_nothing", "cg_waited_for")},
+                                                                      "cg_sweeps_for_nothing", "cg_waited_for",
+                                                                      "cg_restarted_modes", "cg_solution")},
                       "steps_per_gram_schmidt_pass": last_round.get("steps_per_pass"),
                       "inner_projections": last_round.get("inner_projections"),
                       "cycles": last_round.get("gs_cycles"),

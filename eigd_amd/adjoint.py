@@ -1008,6 +1008,7 @@ def _short_recurrence_applies(prob):
 
 _CG_ROWS = {"rr": 0, "gam": 1, "rho": 2, "done": 3, "tol2": 4, "alpha": 5, "steps": 6, "flag": 7}
 _CG_CHUNK = 16             # slabs per allocation of the z history
+_CG_TRACE_HOOK = None      # probes: function(prob, step, residual block, lo, hi, projected) called before a step's projection
 
 
 def _cg_solution_coefficients(log, k):
@@ -1088,19 +1089,25 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     failed = []                                            # (no memory for another chunk of the history)
     # what the measured projection lets pass: a component along B Phi_D of relative size 1e-11 grows by |1 - alpha theta_j|
     # per step until it is taken out again; psi carries it at that relative size at most, and is projected once at the end
-    proj_tol = 1e-11
-    # How often the residual is projected at all (1257).  A component of r along a deflated direction B phi_j is
-    # multiplied by the eigenvalue of C_i there, 1 - (lam_i - sigma) / (lam_j - sigma), in every step while the
-    # residual itself shrinks: with the largest such factor g over the deflated pairs, rounding (1e-16) left alone for p
-    # steps stands at 1e-16 (4 g)^p relative to the residual (a residual reduction of 4 per step assumed).  p is the
-    # largest period that keeps this below 1e-12; the steps in between take their residual norms from the update kernel.
+    proj_tol = tuning.cg_projection_tol
+    # How often the residual is projected at all (1257).  What the sweep's rounding (1e-13 of the residual) leaves along
+    # a deflated direction B phi_j with lam_j below lam_i -- where C_i is NEGATIVE, 1 - (lam_i - sigma) / (lam_j - sigma) --
+    # is multiplied by rho (1 - gam mu) per step while the residual shrinks: measured on the 1 M-dof column
+    # (tools/contamination_probe.py) a factor of 30 per step relative to the residual, 4 g with g the largest |mu| is the
+    # model.  Left alone it takes the recurrence apart (<r, C r>_F turns negative: step 24 on that column).  Every p-th
+    # step therefore projects the residual AND the previous one, which the three-term recurrence brings back in the next
+    # step (projecting r alone only divided the component by |1 - rho|: it kept growing from period to period);
+    # p = the largest period with 1e-13 (4 g)^p < 1e-8, four at most.  The steps in between take their residual norms
+    # from the update kernel.
     lam_all = np.asarray(lam_c, dtype=float)
     lam_defl = lam_all if prob.lam_phi is None else np.asarray(prob.lam_phi, dtype=float)
     with np.errstate(divide="ignore", invalid="ignore"):
         g = np.nanmax(np.abs(1.0 - (lam_all[:, None] - sigma) / (lam_defl[None, :] - sigma)))
     proj_every = 1
     if np.isfinite(g):
-        proj_every = int(max(1, min(4, np.floor(np.log(1e4) / np.log(max(4.0 * g, 1.0 + 1e-12))))))
+        proj_every = int(max(1, min(4, np.floor(np.log(1e5) / np.log(max(4.0 * g, 1.0 + 1e-12))))))
+    if tuning.cg_projection_period:
+        proj_every = int(tuning.cg_projection_period)
     LAST_ROUND["cg_projection_period"] = proj_every
     LAST_ROUND["cg_solution"] = "from the z history" if deferred else "recurrence"
 
@@ -1165,11 +1172,17 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     j = 1
     while True:
         lo, hi = rng_j
+        if _CG_TRACE_HOOK is not None:                     # (probes: the residual of step j before its projection)
+            _CG_TRACE_HOOK(prob, j, r.cols(lo, hi), lo, hi, project_in(j))
         if project_in(j):
             # ref 1257 + the residual norm of 1275; measured update.  Against the N requested pairs only: along an extra
             # pair (lam_j above every lam_i) the eigenvalue of C_i lies in (0, 1) -- rounding there shrinks from step
             # to step like any other part of the residual, it is the pairs BELOW a mode that amplify
-            n2 = prob.project_r_norm2(r.cols(lo, hi), tol=proj_tol, requested_only=True)
+            if j > 1 and proj_every > 1 and tuning.cg_project_previous:
+                # the previous residual takes part in the next step's recurrence: what it carries along the deflated
+                # pairs would come back with it
+                prob.project_r_norm2(r_old.cols(lo, hi), tol=proj_tol, requested_only=not tuning.cg_project_extra_pairs)
+            n2 = prob.project_r_norm2(r.cols(lo, hi), tol=proj_tol, requested_only=not tuning.cg_project_extra_pairs)
         else:
             n2 = norms_of[j]                               # (formed by the update kernel of this step)
             call("eigd_colnorm2_publish", ctx.h, n2.ptr, hi - lo)
@@ -1205,13 +1218,22 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
         rng_j = nxt
         j += 1
     st = state.get()
-    ok = not failed and not np.any(st[_CG_ROWS["flag"], :k] != 0.0) and bool(np.all(np.isfinite(st[_CG_ROWS["rr"], :k])))
+    # flag 2: r^T F r or <r, C r>_F not positive (the column stopped moving); flag 1: a step taken with rho = 1 because the
+    # recurrence's denominator was not positive in finite precision -- a restart from the current iterate, counted only
+    ok = not failed and not np.any(st[_CG_ROWS["flag"], :k] == 2.0) and bool(np.all(np.isfinite(st[_CG_ROWS["rr"], :k])))
+    LAST_ROUND["cg_restarted_modes"] = LAST_ROUND.get("cg_restarted_modes", 0) + int(np.count_nonzero(st[_CG_ROWS["flag"], :k] == 1.0))
     # an unfinished mode whose residual has not halved over its last ten steps: the recurrence is not converging (the
     # caller's Phi is not invariant enough for the deflated operator to stay positive definite in finite precision, or
     # lam is not the eigenvalue of its column): the Arnoldi form, which minimises the true residual step by step, decides
-    for c in range(k):
-        if not converged[c] and len(hist[c]) > 12 and not hist[c][-1] < 0.5 * hist[c][-11]:
-            ok = False
+    stalled = [c for c in range(k) if not converged[c] and len(hist[c]) > 12 and not hist[c][-1] < 0.5 * hist[c][-11]]
+    if stalled:
+        ok = False
+    if not ok:                                             # (why the Arnoldi form takes over: for the caller's log)
+        LAST_ROUND["cg_exit"] = {"steps": nsteps, "broke_down": [int(c) for c in np.flatnonzero(st[_CG_ROWS["flag"], :k] == 2.0)],
+                                 "stalled": stalled, "no_memory_at_step": failed[:1],
+                                 "breakdown_saw": {int(c): (float(st[10, c]), float(st[11, c]), int(st[12, c]))
+                                                   for c in np.flatnonzero(st[_CG_ROWS["flag"], :k] == 2.0)} if nrows > 12 else {},
+                                 "residual_over_tolerance": {int(c): float(hist[c][-1] / tol) for c in range(k) if not converged[c]}}
     if deferred and ok:
         S = _cg_solution_coefficients(log.get(), k)
         ok = bool(np.all(np.isfinite(S)))
@@ -1383,6 +1405,8 @@ def _sibk_device(prob, dPhib, dpsi, lam_c, sigma, rtol, atol, maxiter, nrestart,
     hist = [[] for _ in range(k)]
     info = [None] * k
     LAST_ROUND["recurrence"] = "arnoldi"
+    for key in [key for key in LAST_ROUND if key.startswith("cg_")]:
+        del LAST_ROUND[key]                                # (the cg_* entries describe this call)
     if streams == 1 and _short_recurrence_applies(prob):
         # positive definite shift: conjugate gradients in the factor inner product (same spaces, no history); as many
         # steps as the reference's restarted loop may take in all (1312-1321)

@@ -38,7 +38,8 @@ namespace eigd {
 
 // rows of the per-column state block (leading dimension kMaxK)
 enum CgRow { kRr = 0, kGam = 1, kRho = 2, kDone = 3, kTol2 = 4, kAlpha = 5, kSteps = 6, kFlag = 7, kGamNow = 8, kRhoNow = 9,
-             kCgRows = 10 };
+             kBadRr = 10, kBadDen = 11, kBadStep = 12,   // what a breakdown (flag 2) saw: r.z, r.z - alpha z.y, the step
+             kCgRows = 13 };
 
 constexpr int kCgMaxBlocks = 1024;
 
@@ -121,22 +122,32 @@ __global__ __launch_bounds__(128) void cg_coef_kernel(const double* __restrict__
     const double rr = sums[c];
     const double den = rr - state[kAlpha * kMaxK + c] * sums[k + c];  // <r, C r>_F
     // rr = r^T F r and <r, C r>_F must be positive: F is positive definite and so is C in the deflated space.  Anything
-    // else (an eigenvalue below lam_i that is not deflated, an indefinite factor) is reported; the caller falls back
-    // to the Arnoldi form.  rr == 0: the residual vanished exactly, nothing left to do for this column.
+    // else (an eigenvalue below lam_i that is not deflated, an indefinite factor) is a breakdown (flag 2): the column
+    // stops moving and the caller falls back to the Arnoldi form.  rr == 0: the residual vanished exactly, nothing left to
+    // do for this column.
     if (rr > 0.0 && den > 0.0) {
       gam = rr / den;
       if (!first) {
+        // q <= 0 happens in finite precision when C_i is nearly singular in the deflated space (a pair just above lam_i
+        // that is not deflated) and r^T F r has grown by orders between two steps: the step is then taken with rho = 1 -- a
+        // restart of the recurrence from the current iterate; r and psi stay consistent for any (gam, rho), so the
+        // residual test decides as before.  Counted (flag 1), not an error.
         const double q = 1.0 - (gam / state[kGam * kMaxK + c]) * (rr / state[kRr * kMaxK + c]) / state[kRho * kMaxK + c];
         if (q > 0.0)
           rho = 1.0 / q;
-        else
+        else if (state[kFlag * kMaxK + c] == 0.0)
           state[kFlag * kMaxK + c] = 1.0;
       }
       state[kRr * kMaxK + c] = rr;
       state[kGam * kMaxK + c] = gam;
       state[kRho * kMaxK + c] = rho;
     } else if (rr != 0.0) {
-      state[kFlag * kMaxK + c] = 1.0;
+      if (state[kFlag * kMaxK + c] != 2.0) {
+        state[kBadRr * kMaxK + c] = rr;
+        state[kBadDen * kMaxK + c] = den;
+        state[kBadStep * kMaxK + c] = static_cast<double>(step);
+      }
+      state[kFlag * kMaxK + c] = 2.0;
     }
   }
   state[kGamNow * kMaxK + c] = gam;  // gam == 0: the column does not move in this step

@@ -15,6 +15,11 @@ recurrence = "auto"        # "auto": conjugate gradients in the factor inner pro
                            # reference's form (full Gram-Schmidt against the history, Hessenberg least squares)
 cg_solution_from_history = True   # short recurrence: psi = sum_k s_k z_k once at the end from the kept z of every step
                            # (four streaming passes per step); False: the three-term recurrence for psi runs along (eight)
+cg_projection_period = 0   # short recurrence: steps between projections of the residual (0: from the spectrum, at most 4)
+cg_projection_tol = 1e-11  # ... applied where a coefficient exceeds this times the residual norm of its column
+cg_project_previous = True # ... and the previous residual with it (False: the residual alone -- the deflated components
+                           # come back through the three-term recurrence and grow from period to period)
+cg_project_extra_pairs = False   # ... against the extra pairs as well (False: the N requested pairs only)
 steps_per_pass = 2         # Arnoldi form: Krylov steps per Gram-Schmidt pass (1 = orthogonalise every step)
 inner_projections = False  # Arnoldi form: True keeps the projections behind both operator applications (ref 1250-1252)
 pair_defect_tol = 1e-10    # Arnoldi form: w_{j+1}.w_{j+2} above which a two-step solve is redone in the one-step form

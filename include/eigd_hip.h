@@ -242,7 +242,9 @@ int eigd_scale_inv_norm(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, 
  * conjugate gradients in that inner product (three-term form: residual and solution directly), one multi-column step
  * per factor application, no Krylov history.  All per-mode scalars live in dState (device, eigd_cg_state_rows() rows of
  * 64 doubles, one column per mode: r.z, gam, rho of the previous step, done, tol^2, alpha_i = +-(lam_i - sigma) of
- * 1264-1269, steps taken when the mode met 1275, breakdown flag, gam and rho of the current step); the caller passes
+ * 1264-1269, steps taken when the mode met 1275, flag (1: some step was taken with rho = 1 because the recurrence's denominator
+ * was not positive in finite precision -- a restart from the current iterate; 2: r.z or r.z - alpha z.y not positive, the
+ * column stopped moving: not positive definite), gam and rho of the current step); the caller passes
  * dState + first column of the block it works on.
  *   eigd_cg_coefficients  dNorm2 (device, |r_k|^2 per column from eigd_project_norm2, or null) < tol^2 -> done;
  *                         with z = factor(r_k) (1248) and y = K z (1250-1252): gam = r.z / (r.z - alpha z.y) and
