@@ -529,77 +529,10 @@ def main():
         pr.disable()
         with open(args.pyprofile, "w") as fh:
             pstats.Stats(pr, stream=fh).sort_stats("cumulative").print_stats(45)
-    # ------------------------------------------------------------------ the Arnoldi form of the same solve, for comparison
-    # (outside the timed region: the reference's recurrence with full Gram-Schmidt, two steps per pass -- round 3's solver)
-    arnoldi_form = None
-    if world == 1 and comm is None and last_round.get("recurrence") == "short" and not args.emulate_rank \
-            and not args.no_arnoldi_leg:
-        import eigd_amd as _eg
-
-        it_short = [int(i) for i in solver.last_info]
-        keep = _eg.tuning.recurrence
-        _eg.tuning.recurrence = "arnoldi"
-        try:
-            step()                                       # (allocates the Krylov stacks)
-            ctx.sync()
-            t0 = time.perf_counter()
-            dpsi_a, _, dfdx_a = step()
-            ctx.sync()
-            t_a = time.perf_counter() - t0
-            it_arn = [int(i) for i in solver.last_info]
-        finally:
-            _eg.tuning.recurrence = keep
-        da, ds = dpsi_a.get(), dpsi.get()
-        arnoldi_form = {"ms_per_step": round(1e3 * t_a, 3), "sibk_iterations": it_arn,
-                        "total_iterations": int(sum(it_arn)), "total_iterations_short_recurrence": int(sum(it_short)),
-                        "psi_rel_diff": float(np.linalg.norm(da - ds) / np.linalg.norm(da)),
-                        "dfdx_rel_diff": float(np.linalg.norm(dfdx_a - dfdx) / np.linalg.norm(dfdx_a))}
-        del da, ds, dpsi_a
-        ctx.release_workspaces()                         # the Krylov stacks of the Arnoldi form (26 GB at C3) go back
-        log(rank, f"Arnoldi form: {arnoldi_form['ms_per_step']} ms/step, iterations {sum(it_arn)} against {sum(it_short)}, "
-                  f"psi rel diff {arnoldi_form['psi_rel_diff']:.1e}")
-    # ------------------------------------------------------------------ what mode sharding can give: the slowest rank's share
-    # (one GPU: the block-cyclic share of the LAST rank of P -- it owns the slowest mode -- timed with a stand-in
-    # communicator; no collective: the 4 MB all-reduce of df/dx adds < 0.1 ms.  A prediction for the next multi-GPU run.)
-    scaling_model = None
-    if world == 1 and comm is None and not args.no_scaling_model:
-        class _LastOfMany:
-            def __init__(self, p):
-                self.rank, self.size = p - 1, p
-
-            def allreduce_sum(self, a):
-                return a
-
-            def allreduce_max(self, x):
-                return x
-
-            def barrier(self):
-                pass
-
-        scaling_model = {"note": "slowest rank's share of the same 32-mode step, timed on this one GPU (no collective); "
-                                 "efficiency = ms_per_step / (P * rank_ms)", "ranks": {}}
-        for P_ in (2, 4, 8):
-            if P_ > N:
-                continue
-            cm = _LastOfMany(P_)
-
-            def rank_step():
-                dpsi_r, data_r = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1,
-                                                      comm=cm, streams=args.streams)
-                solver.add_total_derivative(lamb, dPhib, dpsi_r, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data_r,
-                                            deriv_type="tensor", comm=cm)
-
-            rank_step()
-            ctx.sync()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                rank_step()
-            ctx.sync()
-            t_r = (time.perf_counter() - t0) / 3
-            scaling_model["ranks"][str(P_)] = {"rank_ms": round(1e3 * t_r, 3), "modes_of_rank": int(len(range(P_ - 1, N, P_))),
-                                                "predicted_efficiency": round(ms_per_step * 1e-3 / (P_ * t_r), 3)}
-        log(rank, f"scaling model (slowest rank of P on one GPU): {scaling_model['ranks']}")
     # ------------------------------------------------------------------ the reference's call surface: numpy in, numpy out
+    # (this leg runs BEFORE the Arnoldi and scaling-model legs: behind the Arnoldi leg's downloads and release_workspaces()
+    # both transfers of the numpy step ran at half their rate on the same box -- 9.6 + 8.8 ms against 4.7 + 4.7 -- although
+    # the caller's array was page-locked and the result came from the page-locked pool: tools/pin_probe.py, docs/LOG.md)
     # (the timed value keeps the operands resident in HBM; callers of the reference hand numpy arrays to solve_adjoint
     # and add_total_derivative, which adds the H2D of Phib and the D2H / H2D of psi: reported next to the value)
     numpy_api = None
@@ -693,6 +626,76 @@ def main():
         del psi_np
         log(rank, f"numpy-in / numpy-out step: {1e3 * t_np:.1f} ms ({N / t_np:.1f} modes/s)")
 
+    # ------------------------------------------------------------------ the Arnoldi form of the same solve, for comparison
+    # (outside the timed region: the reference's recurrence with full Gram-Schmidt, two steps per pass -- round 3's solver)
+    arnoldi_form = None
+    if world == 1 and comm is None and last_round.get("recurrence") == "short" and not args.emulate_rank \
+            and not args.no_arnoldi_leg:
+        import eigd_amd as _eg
+
+        it_short = list(sibk_iterations)              # (of the last timed step)
+        keep = _eg.tuning.recurrence
+        _eg.tuning.recurrence = "arnoldi"
+        try:
+            step()                                       # (allocates the Krylov stacks)
+            ctx.sync()
+            t0 = time.perf_counter()
+            dpsi_a, _, dfdx_a = step()
+            ctx.sync()
+            t_a = time.perf_counter() - t0
+            it_arn = [int(i) for i in solver.last_info]
+        finally:
+            _eg.tuning.recurrence = keep
+        da, ds = dpsi_a.get(), dpsi.get()
+        arnoldi_form = {"ms_per_step": round(1e3 * t_a, 3), "sibk_iterations": it_arn,
+                        "total_iterations": int(sum(it_arn)), "total_iterations_short_recurrence": int(sum(it_short)),
+                        "psi_rel_diff": float(np.linalg.norm(da - ds) / np.linalg.norm(da)),
+                        "dfdx_rel_diff": float(np.linalg.norm(dfdx_a - dfdx) / np.linalg.norm(dfdx_a))}
+        del da, ds, dpsi_a
+        ctx.release_workspaces()                         # the Krylov stacks of the Arnoldi form (26 GB at C3) go back
+        log(rank, f"Arnoldi form: {arnoldi_form['ms_per_step']} ms/step, iterations {sum(it_arn)} against {sum(it_short)}, "
+                  f"psi rel diff {arnoldi_form['psi_rel_diff']:.1e}")
+    # ------------------------------------------------------------------ what mode sharding can give: the slowest rank's share
+    # (one GPU: the block-cyclic share of the LAST rank of P -- it owns the slowest mode -- timed with a stand-in
+    # communicator; no collective: the 4 MB all-reduce of df/dx adds < 0.1 ms.  A prediction for the next multi-GPU run.)
+    scaling_model = None
+    if world == 1 and comm is None and not args.no_scaling_model:
+        class _LastOfMany:
+            def __init__(self, p):
+                self.rank, self.size = p - 1, p
+
+            def allreduce_sum(self, a):
+                return a
+
+            def allreduce_max(self, x):
+                return x
+
+            def barrier(self):
+                pass
+
+        scaling_model = {"note": "slowest rank's share of the same 32-mode step, timed on this one GPU (no collective); "
+                                 "efficiency = ms_per_step / (P * rank_ms)", "ranks": {}}
+        for P_ in (2, 4, 8):
+            if P_ > N:
+                continue
+            cm = _LastOfMany(P_)
+
+            def rank_step():
+                dpsi_r, data_r = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1,
+                                                      comm=cm, streams=args.streams)
+                solver.add_total_derivative(lamb, dPhib, dpsi_r, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data_r,
+                                            deriv_type="tensor", comm=cm)
+
+            rank_step()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                rank_step()
+            ctx.sync()
+            t_r = (time.perf_counter() - t0) / 3
+            scaling_model["ranks"][str(P_)] = {"rank_ms": round(1e3 * t_r, 3), "modes_of_rank": int(len(range(P_ - 1, N, P_))),
+                                                "predicted_efficiency": round(ms_per_step * 1e-3 / (P_ * t_r), 3)}
+        log(rank, f"scaling model (slowest rank of P on one GPU): {scaling_model['ranks']}")
     # ------------------------------------------------------------------ accuracy of the timed result
     res, ortho = solver.eval_adjoint_residual_norm(dPhib, dpsi, b_ortho=False) if world == 1 else (None, None)
     accuracy = {}
