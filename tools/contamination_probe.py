@@ -35,6 +35,8 @@ def hook(prob, j, rv, lo, hi, projected):
 
 
 adj._CG_TRACE_HOOK = hook
+eg.tuning.cg_project_previous = os.environ.get("PREVIOUS", "1") != "0"   # 0: the residual alone (the scheme before the fix)
+print("projection of the previous residual:", eg.tuning.cg_project_previous)
 for extra in [int(v) for v in (sys.argv[1:] or ["16", "32"])]:
     eg.tuning.iram_extra = extra
     s = eg.IRAM(N=N, m=65, mode="buckling")
