@@ -192,6 +192,33 @@ def test_short_recurrence_keeps_the_residual_out_of_the_deflated_directions(monk
     assert max(v for _, v in seen) > 1e-5, seen
 
 
+def test_short_recurrence_without_memory_for_its_history_hands_over(monkeypatch):
+    """no room for another 16 slabs of the z history (here: from the second allocation on): the Arnoldi form redoes the solve"""
+    import eigd_amd as eg
+    from eigd_amd import _ffi, adjoint as adj, device as dev
+
+    g = load_golden("g4_laplace900_basiclanczos")
+    K, M = csr_from(g, "K"), csr_from(g, "M")
+    lam, Phi, Phib = g["normal_lam"], g["normal_Phi"], g["Phib"]
+    sigma = -0.1
+    fac = eg.SpLuOperator((K - sigma * M).tocsc())
+    monkeypatch.setattr(eg.tuning, "recurrence", "auto")
+    psi_ok, _, info_ok = eg.sibk(Phib, K, M, lam, Phi, factor=fac, sigma=sigma, rtol=1e-12)
+    assert adj.LAST_ROUND["recurrence"] == "short" and max(info_ok) > 2
+    monkeypatch.setattr(adj, "_CG_CHUNK", 2)
+    orig = dev.Context.workspace_stack
+
+    def stingy(self, tag, ns, n, k=1):
+        if isinstance(tag, tuple) and tag[0] == "cg_z" and tag[1] >= 1:
+            raise _ffi.EigdHipError("out of memory (test)")
+        return orig(self, tag, ns, n, k)
+
+    monkeypatch.setattr(dev.Context, "workspace_stack", stingy)
+    psi, _, info = eg.sibk(Phib, K, M, lam, Phi, factor=fac, sigma=sigma, rtol=1e-12)
+    assert adj.LAST_ROUND["recurrence"].startswith("arnoldi (") and adj.LAST_ROUND["cg_exit"]["no_memory_at_step"] == [3]
+    assert relerr(psi, psi_ok) < 1e-9
+
+
 def test_short_recurrence_steps_aside_where_it_does_not_apply(monkeypatch):
     """an interior shift (indefinite factor) and an incomplete deflation set (eigenvalues below lam_i left in: the
     operator is indefinite in the deflated space, the breakdown is flagged on the device) both end in the Arnoldi form"""
