@@ -1139,10 +1139,16 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
             return
         rv, zv, yv = r.cols(lo, hi), zj.cols(lo, hi), y.cols(lo, hi)
         prob.fac.apply_to(rv, zv, count=0)                # ref 1248
-        Kop.apply(zv, yv)                                 # ref 1250 / 1252
         n2p = None if n2 is None else n2.cols(lo - n2_lo, hi - n2_lo).ptr
-        call("eigd_cg_coefficients", ctx.h, n, kk, zv.ptr, zv.ld, rv.ptr, rv.ld, yv.ptr, yv.ld, n2p, sptr(lo), int(j),
-             1 if j == 1 else 0, log.cols(lo, 64).ptr if deferred else None)
+        logp = log.cols(lo, 64).ptr if deferred else None
+        if tuning.cg_dots_in_spmm:
+            # ref 1250 / 1252 with the two inner products of the step formed in the product's own pass
+            call("eigd_spmm_cg", ctx.h, Kop.csr.h, kk, zv.ptr, zv.ld, yv.ptr, yv.ld, rv.ptr, rv.ld, n2p, sptr(lo), int(j),
+                 1 if j == 1 else 0, logp)
+        else:
+            Kop.apply(zv, yv)                             # ref 1250 / 1252
+            call("eigd_cg_coefficients", ctx.h, n, kk, zv.ptr, zv.ld, rv.ptr, rv.ld, yv.ptr, yv.ld, n2p, sptr(lo), int(j),
+                 1 if j == 1 else 0, logp)
         rov = r_old.cols(lo, hi)
         own = None if project_in(j) else ctx.empty(1, kk)  # (a step that is not projected forms its own residual norms)
         if deferred:

@@ -76,4 +76,7 @@ struct eigd_ctx {
 namespace eigd {
 // small device results for the host: copy in stream order behind their kernel, collected by eigd_colnorm2_fetch (dense.hip)
 int publish_norm2(eigd_ctx* ctx, const double* dOut, int k);
+// krylov.hip: the coefficient kernel of the short-recurrence sibk over partial sums [nblocks][2 k] left by another kernel
+int cg_coefficients_from_partials(eigd_ctx* ctx, const double* partial, int nblocks, int k, const double* dNorm2,
+                                  double* dState, int step, int first, double* dLog);
 }  // namespace eigd

@@ -232,6 +232,15 @@ static int cg_dispatch_kp(int k, F&& f) {
 
 }  // namespace eigd
 
+// the coefficient kernel over partial sums some other kernel left ([nblocks][2 k]: r.z then z.y per column)
+int eigd::cg_coefficients_from_partials(eigd_ctx* ctx, const double* partial, int nblocks, int k, const double* dNorm2,
+                                        double* dState, int step, int first, double* dLog) {
+  hipLaunchKernelGGL(cg_coef_kernel, dim3(k), dim3(128), 0, ctx->stream, partial, nblocks, k, dNorm2, dState, step, first,
+                     dLog);
+  EIGD_LAUNCH_CHECK();
+  return EIGD_OK;
+}
+
 using namespace eigd;
 
 extern "C" {

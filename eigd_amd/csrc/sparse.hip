@@ -172,7 +172,11 @@ struct SpmmTile {
   static constexpr int LD = (CPL >= 2) ? KP + 4 : KP + 1;      // Xs row stride in doubles (CPL >= 2: rows 16-byte aligned)
 };
 
-template <int KP, int LANES>
+// DOTS (KP = 8, 16, 32; the short-recurrence sibk): the tile also leaves its share of the column sums x.r and x.y --
+// x = X, y = the result, r = a third block -- in dots[tile][2 k] (fixed order: the rows of a wave by shuffles, the four waves
+// in order), so that conjugate gradients need no pass of its own over z, r and y for its two inner products.  The
+// products of Y are untouched: the result stays bit-identical to the kernel without DOTS.
+template <int KP, int LANES, bool DOTS = false>
 __global__ __launch_bounds__(kThreads) void spmm_tiled_kernel(int n, int k, int ntiles, int tiles_per_xcd,
                                                              const int32_t* __restrict__ tile_ptr,
                                                              const int32_t* __restrict__ ucols,
@@ -181,7 +185,9 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled_kernel(int n, int k, int 
                                                              const double* __restrict__ vals,
                                                              const double* __restrict__ X, int ldx,
                                                              double* __restrict__ Y, int ldy, double alpha, double beta,
-                                                             int umax, int tnz_cap) {
+                                                             int umax, int tnz_cap,
+                                                             const double* __restrict__ R = nullptr, int ldr = 0,
+                                                             double* __restrict__ dots = nullptr) {
   extern __shared__ __align__(16) double Xs[];
   constexpr int RP = kThreads / KP;  // staging: rows of X per trip, lane (rr, c) moves one double
   constexpr int CPL = SpmmTile<KP, LANES>::CPL, LPR = SpmmTile<KP, LANES>::LPR, LD = SpmmTile<KP, LANES>::LD;
@@ -218,6 +224,17 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled_kernel(int n, int k, int 
     sv[q] = ok ? vals[e0 + e] : 0.0;
     sl[q] = ok ? lidx[e0 + e] : uint16_t(0);
   }
+  // DOTS: the lane's own entries of x and r (its row, its columns) are requested with everything else
+  [[maybe_unused]] double xo[CPL], ro[CPL];
+  if constexpr (DOTS) {
+    const int r = tile * kTileRows + prow;
+#pragma unroll
+    for (int t = 0; t < CPL; ++t) {
+      const bool ok = r < rend && CPL * pl + t < k;
+      xo[t] = ok ? X[static_cast<int64_t>(r) * ldx + CPL * pl + t] : 0.0;
+      ro[t] = ok ? R[static_cast<int64_t>(r) * ldr + CPL * pl + t] : 0.0;
+    }
+  }
   constexpr int SU = 16;  // staged rows per lane and trip: all their loads are in flight together
   for (int j0 = 0; j0 < nu; j0 += SU * RP) {
     int col[SU];
@@ -247,14 +264,57 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled_kernel(int n, int k, int 
   }
   __syncthreads();
   const int cb = CPL * pl;  // the lane's first column
-  if (cb >= k) return;
+  if (!DOTS && cb >= k) return;
+  [[maybe_unused]] double dzr[CPL], dzy[CPL];
+  [[maybe_unused]] __shared__ double dred[DOTS ? (kThreads / 64) * 2 * KP : 1];
+  if constexpr (DOTS) {
+#pragma unroll
+    for (int t = 0; t < CPL; ++t) dzr[t] = dzy[t] = 0.0;
+  }
+  auto finish_dots = [&]() {  // every lane of the workgroup comes here exactly once (DOTS)
+    if constexpr (DOTS) {
+      static_assert(KP >= LANES && NR == 1, "one pass over the tile's rows, eight lanes per row");
+#pragma unroll
+      for (int t = 0; t < CPL; ++t) {  // the eight rows of a wave: lanes 8 q + pl
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+          dzr[t] += __shfl_xor(dzr[t], off, 64);
+          dzy[t] += __shfl_xor(dzy[t], off, 64);
+        }
+      }
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      if (lane < LPR) {
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+          dred[(wave * 2 + 0) * KP + cb + t] = dzr[t];
+          dred[(wave * 2 + 1) * KP + cb + t] = dzy[t];
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < 2 * k) {
+        const int q = threadIdx.x / k, c2 = threadIdx.x % k;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) v += dred[(w * 2 + q) * KP + c2];
+        dots[static_cast<int64_t>(tile) * 2 * k + threadIdx.x] = v;
+      }
+    }
+  };
   auto store_row = [&](int r, const double (&s)[CPL]) {
     double* yp = Y + static_cast<int64_t>(r) * ldy + cb;
 #pragma unroll
     for (int t = 0; t < CPL; ++t)
-      if (cb + t < k) yp[t] = (beta == 0.0) ? alpha * s[t] : alpha * s[t] + beta * yp[t];
+      if (cb + t < k) {
+        const double yv = (beta == 0.0) ? alpha * s[t] : alpha * s[t] + beta * yp[t];
+        yp[t] = yv;
+        if constexpr (DOTS) {  // (NR == 1: the row is the one whose entries were loaded at the start)
+          dzr[t] += xo[t] * ro[t];
+          dzy[t] += xo[t] * yv;
+        }
+      }
   };
-  if (staged) {
+  const bool active = cb < k;  // (DOTS: the lanes past the block's columns come along to the one barrier of finish_dots)
+  if (active && staged) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int r = tile * kTileRows + prow + i * RPP;
@@ -300,8 +360,7 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled_kernel(int n, int k, int 
       }
       store_row(r, s);
     }
-    return;
-  }
+  } else if (active) {
   for (int r = tile * kTileRows + prow; r < rend; r += RPP) {
     const int a = indptr[r], z = indptr[r + 1];
     double s[CPL];
@@ -314,6 +373,27 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled_kernel(int n, int k, int 
       for (int t = 0; t < CPL; ++t) s[t] = __dadd_rn(s[t], __dmul_rn(v, xp[t]));
     }
     store_row(r, s);
+  }
+  }
+  finish_dots();
+}
+
+// first level of the sum over the tiles' shares (spmm_tiled_kernel, DOTS): workgroup g adds tiles g, g + G, ... for all
+// nout = 2 k sums; the coefficient kernel of krylov.hip adds the G rows
+__global__ __launch_bounds__(kThreads) void tile_dots_reduce_kernel(const double* __restrict__ dots, int ntiles, int nout,
+                                                                   double* __restrict__ out) {
+  __shared__ double red[kThreads];
+  const int per = kThreads / nout;                 // tiles in flight per trip (nout <= 64: at least four)
+  const int o = threadIdx.x % nout, sub = threadIdx.x / nout;
+  double v = 0.0;
+  if (sub < per)
+    for (int t = blockIdx.x * per + sub; t < ntiles; t += gridDim.x * per) v += dots[static_cast<int64_t>(t) * nout + o];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  if (threadIdx.x < nout) {
+    double t = 0.0;
+    for (int q = 0; q < per; ++q) t += red[q * nout + threadIdx.x];
+    out[static_cast<int64_t>(blockIdx.x) * nout + threadIdx.x] = t;
   }
 }
 
@@ -535,6 +615,53 @@ int eigd_spmm_on(eigd_ctx* ctx, eigd_mat* A, const double* dX, int ldx, double* 
     EIGD_LAUNCH_CHECK();
   }
   return EIGD_OK;
+}
+
+// y = A z together with the coefficients of a conjugate-gradient step (krylov.hip): the inner products z.r and z.y come
+// out of the product's own pass (5 <= k <= 32 on a tiled matrix; other shapes: the product, then eigd_cg_coefficients)
+int eigd_spmm_cg(eigd_ctx* ctx, eigd_mat* A, int k, const double* dZ, int ldz, double* dY, int ldy, const double* dR, int ldr,
+                 const double* dNorm2, double* dState, int step, int first, double* dLog) {
+  EIGD_REQUIRE(ctx && A && dZ && dY && dR && dState, "null argument");
+  EIGD_REQUIRE(ctx->device == A->ctx->device, "context and matrix live on different devices");
+  EIGD_REQUIRE(k >= 1 && k <= kMaxK && ldz >= k && ldy >= k && ldr >= k && A->n == A->ncols, "bad block shape k=%d", k);
+  EIGD_REQUIRE(dZ != dY, "spmm cannot run in place");
+  const int kp = std::max(2, next_pow2(k));
+  const int cpl = (kp >= 8) ? kp / 8 : 1;
+  const size_t tile_lds = sizeof(double) * static_cast<size_t>(A->umax) * (cpl >= 2 ? kp + 4 : kp + 1);
+  const bool fused = kp >= 8 && kp <= 32 && A->ntiles > 0 && tile_lds <= static_cast<size_t>(kTileLds);
+  if (!fused) {
+    int rc = eigd_spmm_on(ctx, A, dZ, ldz, dY, ldy, k, 1.0, 0.0);
+    if (rc) return rc;
+    return eigd_cg_coefficients(ctx, A->n, k, dZ, ldz, dR, ldr, dY, ldy, dNorm2, dState, step, first, dLog);
+  }
+  const int groups = std::min(A->ntiles, 256);
+  int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(A->ntiles) + groups) * 2 * k);
+  if (rc) return rc;
+  double* gsum = ctx->scratch;                                    // groups x 2k
+  double* dots = ctx->scratch + static_cast<size_t>(groups) * 2 * k;  // ntiles x 2k
+  const size_t tile_lds_all = tile_lds + static_cast<size_t>(A->tnz_cap) * (sizeof(double) + sizeof(uint16_t));
+  const int per_xcd = (A->ntiles + 7) / 8;
+  const dim3 tgrid(per_xcd * 8);
+  hipStream_t st = ctx->stream;
+#define EIGD_SPMM_DOTS(KP)                                                                                             \
+  case KP:                                                                                                             \
+    hipLaunchKernelGGL((spmm_tiled_kernel<KP, 8, true>), tgrid, dim3(kThreads), tile_lds_all, st, A->n, k, A->ntiles,  \
+                       per_xcd, A->tile_ptr, A->ucols, A->indptr, A->lidx, A->data, dZ, ldz, dY, ldy, 1.0, 0.0,        \
+                       A->umax, A->tnz_cap, dR, ldr, dots);                                                            \
+    break;
+  switch (kp) {
+    EIGD_SPMM_DOTS(8)
+    EIGD_SPMM_DOTS(16)
+    EIGD_SPMM_DOTS(32)
+    default:
+      set_error("internal: unexpected kp=%d", kp);
+      return EIGD_E_INTERNAL;
+  }
+#undef EIGD_SPMM_DOTS
+  EIGD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tile_dots_reduce_kernel, dim3(groups), dim3(kThreads), 0, st, dots, A->ntiles, 2 * k, gsum);
+  EIGD_LAUNCH_CHECK();
+  return cg_coefficients_from_partials(ctx, gsum, groups, k, dNorm2, dState, step, first, dLog);
 }
 
 }  // extern "C"

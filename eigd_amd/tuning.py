@@ -15,6 +15,7 @@ recurrence = "auto"        # "auto": conjugate gradients in the factor inner pro
                            # reference's form (full Gram-Schmidt against the history, Hessenberg least squares)
 cg_solution_from_history = True   # short recurrence: psi = sum_k s_k z_k once at the end from the kept z of every step
                            # (four streaming passes per step); False: the three-term recurrence for psi runs along (eight)
+cg_dots_in_spmm = True     # short recurrence: r.z and z.y from the SpMM's own pass (False: a dot kernel over z, r, y)
 cg_projection_period = 0   # short recurrence: steps between projections of the residual (0: from the spectrum, at most 4)
 cg_projection_tol = 1e-11  # ... applied where a coefficient exceeds this times the residual norm of its column
 cg_project_previous = True # ... and the previous residual with it (False: the residual alone -- the deflated components

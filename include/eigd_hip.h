@@ -262,6 +262,10 @@ int eigd_scale_inv_norm(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, 
 int eigd_cg_state_rows(void);
 int eigd_cg_coefficients(eigd_ctx* ctx, int n, int k, const double* dZ, int ldz, const double* dR, int ldr, const double* dY,
                          int ldy, const double* dNorm2, double* dState, int step, int first, double* dLog);
+/* y = A z (the SpMM of 1250-1252) and eigd_cg_coefficients in one call: on a tiled matrix with 5 <= k <= 32 the two inner
+ * products come out of the product's own pass (the tiles' shares in a fixed order), y bit-identical to eigd_spmm */
+int eigd_spmm_cg(eigd_ctx* ctx, eigd_mat* A, int k, const double* dZ, int ldz, double* dY, int ldy, const double* dR, int ldr,
+                 const double* dNorm2, double* dState, int step, int first, double* dLog);
 int eigd_cg_update(eigd_ctx* ctx, int n, int k, const double* dR, int ldr, double* dRold, int ldro, const double* dPsi,
                    int ldpsi, double* dPsiOld, int ldpso, const double* dZ, int ldz, const double* dY, int ldy,
                    const double* dState, int first, double* dNorm2);

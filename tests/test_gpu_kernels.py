@@ -71,6 +71,45 @@ def test_spmm_matches_scipy(ctx, k):
     assert np.array_equal(Y, A @ X)
 
 
+@pytest.mark.parametrize("k", [3, 5, 8, 13, 24, 32, 40])
+def test_spmm_with_the_inner_products_of_a_cg_step_in_the_same_pass(ctx, k):
+    """eigd_spmm_cg: y bit-identical to the plain product, gam / rho / log as the dot kernel's coefficients (csrc/krylov.hip)"""
+    from eigd_amd import _ffi
+    from eigd_amd._ffi import call
+    from eigd_amd.device import CSRMatrix
+
+    A = grid_matrix(61, 47, 2, seed=k)
+    A = (A + A.T).tocsr()
+    n = A.shape[0]
+    rng = np.random.default_rng(k)
+    Z, R = rng.normal(size=(n, k)), rng.normal(size=(n, k))
+    dA = CSRMatrix(ctx, A)
+    dZ, dR = ctx.from_host(Z), ctx.from_host(R)
+    nrows = int(_ffi.lib().eigd_cg_state_rows())
+    st = np.zeros((nrows, 64))
+    st[4, :k] = 1e-30                                   # tol^2
+    st[5, :k] = -rng.uniform(0.1, 0.5, size=k)          # alpha_i < 0: rr - alpha z.y > 0 for a positive z.y ... any sign is reported
+    out = {}
+    for name in ("fused", "separate"):
+        state, log, Y = ctx.from_host(st), ctx.zeros(4, 64), ctx.zeros(n, k)
+        if name == "fused":
+            call("eigd_spmm_cg", ctx.h, dA.h, k, dZ.ptr, dZ.ld, Y.ptr, Y.ld, dR.ptr, dR.ld, None, state.ptr, 1, 1, log.ptr)
+        else:
+            dA.apply(dZ, Y)
+            call("eigd_cg_coefficients", ctx.h, n, k, dZ.ptr, dZ.ld, dR.ptr, dR.ld, Y.ptr, Y.ld, None, state.ptr, 1, 1, log.ptr)
+        out[name] = (Y.get(), state.get(), log.get())
+    assert np.array_equal(out["fused"][0], A @ Z) and np.array_equal(out["separate"][0], A @ Z)
+    rr, zy = np.sum(Z * R, axis=0), np.sum(Z * (A @ Z), axis=0)
+    for name in out:
+        stt, lg = out[name][1], out[name][2]
+        ok = (rr > 0) & (rr - st[5, :k] * zy > 0)
+        gam = np.where(ok, rr / (rr - st[5, :k] * zy), 0.0)
+        assert np.allclose(stt[8, :k], gam, rtol=1e-12, atol=0) and np.allclose(lg[0, :k], gam, rtol=1e-12, atol=0), name
+        assert np.allclose(stt[0, :k][ok], rr[ok], rtol=1e-12)
+        assert np.array_equal(stt[7, :k] == 2.0, ~ok & (rr != 0))
+    assert np.allclose(out["fused"][1], out["separate"][1], rtol=1e-12, atol=1e-300)
+
+
 @pytest.mark.parametrize("k", [5, 32])
 def test_spmm_tiles_with_many_nonzeros_and_mixed_rows(ctx, k):
     """banded rows (41 non-zeros each: a 32-row tile holds more than the 1024 non-zeros staged through LDS), a few
