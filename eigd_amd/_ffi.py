@@ -106,6 +106,8 @@ _SIGNATURES = {
     "eigd_copy_block": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_cg_state_rows": [],
     "eigd_cg_coefficients": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp],
+    "eigd_cg_solution_coefficients": [c_vp, c_int, c_vp, c_int, c_vp],
+    "eigd_stack_axpy_dev": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_dbl],
     "eigd_spmm_cg": [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp],
     "eigd_cg_update": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp,
                        c_int, c_vp],

@@ -1223,6 +1223,16 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
             first_part(j + 1, nxt[0], nxt[1], n2, lo)
         rng_j = nxt
         j += 1
+    if deferred and not failed:
+        # psi = sum_j s_j z_j, coefficients and sum on the device, enqueued before the host looks at the flags (a solve
+        # that ends in the Arnoldi form throws the block away)
+        nlog = nsteps + 1
+        Sd = ctx.empty(nlog, k)
+        call("eigd_cg_solution_coefficients", ctx.h, k, log.ptr, nlog, Sd.ptr)
+        for q, chunk in enumerate(zchunks):
+            a, b = q * _CG_CHUNK, min(nlog, (q + 1) * _CG_CHUNK)
+            if a < b:
+                call("eigd_stack_axpy_dev", ctx.h, n, k, b - a, chunk.ptr, chunk.slab, chunk.k, Sd.rows(a, b).ptr, psi.ptr, psi.ld, 1.0)
     st = state.get()
     # flag 2: r^T F r or <r, C r>_F not positive (the column stopped moving); flag 1: a step taken with rho = 1 because the
     # recurrence's denominator was not positive in finite precision -- a restart from the current iterate, counted only
@@ -1240,13 +1250,6 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
                                  "breakdown_saw": {int(c): (float(st[10, c]), float(st[11, c]), int(st[12, c]))
                                                    for c in np.flatnonzero(st[_CG_ROWS["flag"], :k] == 2.0)} if nrows > 12 else {},
                                  "residual_over_tolerance": {int(c): float(hist[c][-1] / tol) for c in range(k) if not converged[c]}}
-    if deferred and ok:
-        S = _cg_solution_coefficients(log.get(), k)
-        ok = bool(np.all(np.isfinite(S)))
-        for q, chunk in enumerate(zchunks):
-            Sq = S[q * _CG_CHUNK:(q + 1) * _CG_CHUNK]
-            if ok and Sq.size and np.any(Sq != 0.0):
-                chunk.axpy_into(psi, Sq)
     prob.project_s(psi)                                    # what the measured projections let pass (see proj_tol)
     if prob.fac.native and ok:                            # one factor application per step and mode (ref 1248)
         with prob.fac.factor._count_lock:

@@ -1560,6 +1560,17 @@ int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64
   return EIGD_OK;
 }
 
+// the same with the coefficients on the device (ns x k, contiguous): no host round trip
+int eigd_stack_axpy_dev(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* dH,
+                        double* dT, int ldt, double alpha) {
+  EIGD_REQUIRE(ctx && dS && dT && dH, "null argument");
+  EIGD_REQUIRE(n > 0 && k >= 1 && k <= kMaxK && ns >= 1 && ldt >= k && lds >= k &&
+                   slab >= static_cast<int64_t>(n - 1) * lds + k && static_cast<int64_t>(n) * lds < (int64_t(1) << 31),
+               "bad shape n=%d k=%d ns=%d (a slab must hold fewer than 2^31 doubles)", n, k, ns);
+  EIGD_REQUIRE(static_cast<size_t>(ns) * k * sizeof(double) <= 60 * 1024, "stack too deep for one pass: ns*k=%d", ns * k);
+  return stack_axpy_device(ctx, n, k, ns, dS, slab, lds, dH, dT, ldt, alpha, k);
+}
+
 int eigd_stack_axpy_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* hH1,
                         double* dT, int ldt, double alpha, double* hH2) {
   EIGD_REQUIRE(ctx && dS && dT && hH1 && hH2, "null argument");

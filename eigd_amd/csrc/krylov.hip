@@ -232,6 +232,32 @@ static int cg_dispatch_kp(int k, F&& f) {
 
 }  // namespace eigd
 
+namespace eigd {
+// coefficients of psi = sum_j s_j z_j from the (gam, rho) log (see the file header): one lane per column walks its steps
+// backwards, s_last = alpha_last, s_j = alpha_j + beta_j s_{j+1} over the steps in which the column moved (gam != 0);
+// S[j][c], zero for the other steps.  The host twin is adjoint._cg_solution_coefficients (tests).
+__global__ __launch_bounds__(kMaxK) void cg_solution_coef_kernel(const double* __restrict__ log, int nsteps, int k,
+                                                                double* __restrict__ S) {
+  const int c = threadIdx.x;
+  if (c >= k) return;
+  double s = 0.0, alpha_next = 0.0, rho_next = 1.0;
+  bool have = false;
+  for (int j = nsteps - 1; j >= 0; --j) {
+    const double gam = log[static_cast<int64_t>(2 * j) * kMaxK + c], rho = log[static_cast<int64_t>(2 * j + 1) * kMaxK + c];
+    double out = 0.0;
+    if (gam != 0.0) {
+      const double alpha = rho * gam;
+      s = have ? alpha + ((rho_next - 1.0) * alpha / alpha_next) * s : alpha;
+      have = true;
+      alpha_next = alpha;
+      rho_next = rho;
+      out = s;
+    }
+    S[static_cast<int64_t>(j) * k + c] = out;
+  }
+}
+}  // namespace eigd
+
 // the coefficient kernel over partial sums some other kernel left ([nblocks][2 k]: r.z then z.y per column)
 int eigd::cg_coefficients_from_partials(eigd_ctx* ctx, const double* partial, int nblocks, int k, const double* dNorm2,
                                         double* dState, int step, int first, double* dLog) {
@@ -264,6 +290,13 @@ int eigd_cg_coefficients(eigd_ctx* ctx, int n, int k, const double* dZ, int ldz,
   EIGD_LAUNCH_CHECK();
   hipLaunchKernelGGL(cg_coef_kernel, dim3(k), dim3(128), 0, ctx->stream, partial, nb, k, dNorm2, dState, step, first,
                      dLog);
+  EIGD_LAUNCH_CHECK();
+  return EIGD_OK;
+}
+
+int eigd_cg_solution_coefficients(eigd_ctx* ctx, int k, const double* dLog, int nsteps, double* dS) {
+  EIGD_REQUIRE(ctx && dLog && dS && k >= 1 && k <= kMaxK && nsteps >= 1, "bad argument");
+  hipLaunchKernelGGL(cg_solution_coef_kernel, dim3(1), dim3(kMaxK), 0, ctx->stream, dLog, nsteps, k, dS);
   EIGD_LAUNCH_CHECK();
   return EIGD_OK;
 }

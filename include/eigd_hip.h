@@ -207,6 +207,8 @@ int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_
 int eigd_stack_axpy(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* hH,
                     double* dT, int ldt, double alpha);
 /* fused middle of the twice-applied Gram-Schmidt: T += alpha * sum_j S_j hH1[j]; then hH2[j] = S_j . T (ns <= 32) */
+int eigd_stack_axpy_dev(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* dH,
+                        double* dT, int ldt, double alpha);   /* eigd_stack_axpy with the coefficients on the device */
 int eigd_stack_axpy_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* hH1,
                         double* dT, int ldt, double alpha, double* hH2);
 /* one Gram-Schmidt step of the lock-step Krylov solvers in a single call (1254-1256, 1012-1014): T -= S (S^T T),
@@ -266,6 +268,9 @@ int eigd_cg_coefficients(eigd_ctx* ctx, int n, int k, const double* dZ, int ldz,
  * products come out of the product's own pass (the tiles' shares in a fixed order), y bit-identical to eigd_spmm */
 int eigd_spmm_cg(eigd_ctx* ctx, eigd_mat* A, int k, const double* dZ, int ldz, double* dY, int ldy, const double* dR, int ldr,
                  const double* dNorm2, double* dState, int step, int first, double* dLog);
+/* dS (device, nsteps x k) = the coefficients s of psi = sum_j s_j z_j from the log eigd_cg_coefficients wrote (see
+ * eigd_cg_update with dPsi null); eigd_stack_axpy_dev forms the sum from the kept z without a host round trip */
+int eigd_cg_solution_coefficients(eigd_ctx* ctx, int k, const double* dLog, int nsteps, double* dS);
 int eigd_cg_update(eigd_ctx* ctx, int n, int k, const double* dR, int ldr, double* dRold, int ldro, const double* dPsi,
                    int ldpsi, double* dPsiOld, int ldpso, const double* dZ, int ldz, const double* dY, int ldy,
                    const double* dState, int first, double* dNorm2);

@@ -192,6 +192,31 @@ def test_short_recurrence_keeps_the_residual_out_of_the_deflated_directions(monk
     assert max(v for _, v in seen) > 1e-5, seen
 
 
+def test_solution_coefficients_on_the_device_match_the_host_twin():
+    """eigd_cg_solution_coefficients against adjoint._cg_solution_coefficients on a made-up log: columns that stop moving
+    at different steps, a restart (rho = 1) in the middle, a column that never moves"""
+    from eigd_amd._ffi import call
+    from eigd_amd.adjoint import _cg_solution_coefficients
+    from eigd_amd.device import default_context
+
+    ctx = default_context()
+    rng = np.random.default_rng(5)
+    nsteps, k = 37, 29
+    log = np.zeros((2 * (nsteps + 2), 64))
+    for c in range(k):
+        m = 0 if c == 4 else int(rng.integers(1, nsteps + 1))
+        log[0:2 * m:2, c] = rng.uniform(0.3, 2.0, size=m)
+        log[1:2 * m:2, c] = np.r_[1.0, rng.uniform(1.0, 2.5, size=max(m - 1, 0))][:m]
+        if m > 6:
+            log[2 * 5 + 1, c] = 1.0
+    want = _cg_solution_coefficients(log, k)[:nsteps]
+    dlog, dS = ctx.from_host(log), ctx.empty(nsteps, k)
+    call("eigd_cg_solution_coefficients", ctx.h, k, dlog.ptr, nsteps, dS.ptr)
+    got = dS.get()
+    assert np.array_equal(got == 0.0, want == 0.0)
+    assert np.allclose(got, want, rtol=1e-14, atol=0.0)
+
+
 def test_short_recurrence_without_memory_for_its_history_hands_over(monkeypatch):
     """no room for another 16 slabs of the z history (here: from the second allocation on): the Arnoldi form redoes the solve"""
     import eigd_amd as eg
