@@ -634,7 +634,7 @@ int eigd_spmm_cg(eigd_ctx* ctx, eigd_mat* A, int k, const double* dZ, int ldz, d
     if (rc) return rc;
     return eigd_cg_coefficients(ctx, A->n, k, dZ, ldz, dR, ldr, dY, ldy, dNorm2, dState, step, first, dLog);
   }
-  const int groups = std::min(A->ntiles, 256);
+  const int groups = std::min(A->ntiles, 1024);
   int rc = ctx->ensure_scratch(sizeof(double) * (static_cast<size_t>(A->ntiles) + groups) * 2 * k);
   if (rc) return rc;
   double* gsum = ctx->scratch;                                    // groups x 2k
