@@ -1129,7 +1129,8 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
         return j % proj_every == 0 or j >= maxsteps
 
     def first_part(j, lo, hi, n2, n2_lo):
-        """sweep of the residual of step j - 1, product, coefficients, the two recurrences (no synchronisation)"""
+        """sweep of the residual of step j - 1 (into the history slab of step j), product with the step's inner products,
+        coefficients, recurrence of the residual (no synchronisation)"""
         nonlocal r, r_old, psi, psi_old
         kk = hi - lo
         try:
@@ -1170,8 +1171,9 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     # (unless every live mode is expected to finish with step j -- its last reduction applied once more, within a factor
     # of four of the tolerance: a wrong 'finishes' costs a pipeline bubble of ~0.1 ms, a wrong 'goes on' a narrow step of ~1.3 ms --),
     # on the column range of the modes that were unfinished after step j - 1 (speculative or not): a mode that finishes in
-    # step j is frozen on the device in step j + 1 (its psi copied into both buffers of the recurrence) and leaves the
-    # range in step j + 2, so every column of a block has seen the same number of buffer swaps when it stops moving.
+    # step j is frozen on the device in step j + 1 (its residual copied into both buffers of the recurrence, its later
+    # coefficients of psi zero) and leaves the range in step j + 2, so every column of a block has seen the same number of
+    # buffer swaps when it stops moving.
     first_part(1, lo, hi, None, lo)
     rng_j = (lo, hi)                                       # range of the step whose projection is next
     nsteps = 0
