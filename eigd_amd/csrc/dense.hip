@@ -451,23 +451,28 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(int n, int ku, int kx
 // with sixteen tiles each operand row is requested four times per workgroup (the rows are the whole traffic here:
 // 1 GB per projection).  Here a chunk of 32 rows of U and of X is staged in LDS once (coalesced, the next chunk in
 // registers while this one multiplies) and the four waves take their fragments from there.
-constexpr int kTsRows = 32;
+constexpr int kTsElems = 32 * kMaxK;  // doubles of one operand per chunk: 32 rows of 64 columns, or 64 rows of 32 columns
 
 // xnorm_part (optional): the squared column norms of X ride along, one partial sum per workgroup and column
-// (xnorm_part[blockIdx.x * kx + b]; fixed order: the lane's chunks, then the four waves)
+// (xnorm_part[blockIdx.x * kx + b]; fixed order: the lane's chunks, then the lanes of a column)
+// KW: columns of the staging layout, 64 or -- for ku, kx <= 32 -- 32: every lane loads (with 64 columns and 32 x 32
+// operands half of them would ask for nothing) and a chunk holds 64 rows, twice the bytes per pair of barriers.
+template <int KW>
 __global__ __launch_bounds__(kThreads) void gemm_tn_staged_kernel(int n, int ku, int kx, const double* __restrict__ U,
                                                                  int64_t rsu, const double* __restrict__ X, int ldx,
                                                                  double* __restrict__ partial,
                                                                  double* __restrict__ xnorm_part) {
-  __shared__ double Us[kTsRows * kMaxK];
-  __shared__ double Xs[kTsRows * kMaxK];
+  constexpr int ROWS = kTsElems / KW;        // rows per chunk
+  constexpr int RPT = kThreads / KW;         // rows per trip of the lanes
+  __shared__ double Us[kTsElems];
+  __shared__ double Xs[kTsElems];
   double xsq = 0.0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int nta = (ku + 15) >> 4, ntb = (kx + 15) >> 4;
   const int ntiles = nta * ntb;  // <= 16
-  constexpr int IT = kTsRows * kMaxK / kThreads;  // 8 elements of each operand per lane and chunk
-  const int col = tid & (kMaxK - 1), row0 = tid >> 6;  // element it of a lane: row row0 + 4 it, column col
+  constexpr int IT = kTsElems / kThreads;  // 8 elements of each operand per lane and chunk
+  const int col = tid % KW, row0 = tid / KW;  // element it of a lane: row row0 + RPT it, column col
   double4_t acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -475,20 +480,20 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_staged_kernel(int n, int ku,
   auto fetch = [&](int64_t base) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      const int64_t r = base + row0 + 4 * it;
+      const int64_t r = base + row0 + RPT * it;
       ru[it] = *((r < n && col < ku) ? U + r * rsu + col : &g_zero_word);
       rx[it] = *((r < n && col < kx) ? X + r * ldx + col : &g_zero_word);
     }
   };
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kTsRows;
-  int64_t base = static_cast<int64_t>(blockIdx.x) * kTsRows;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * ROWS;
+  int64_t base = static_cast<int64_t>(blockIdx.x) * ROWS;
   if (base < n) fetch(base);
   for (; base < n; base += stride) {
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-      Us[(row0 + 4 * it) * kMaxK + col] = ru[it];
-      Xs[(row0 + 4 * it) * kMaxK + col] = rx[it];
+      Us[(row0 + RPT * it) * KW + col] = ru[it];
+      Xs[(row0 + RPT * it) * KW + col] = rx[it];
       xsq += rx[it] * rx[it];
     }
     __syncthreads();
@@ -500,9 +505,9 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_staged_kernel(int n, int ku,
         const int ta = tile / ntb, tb = tile - ta * ntb;
         double4_t c = acc[t];
 #pragma unroll
-        for (int q = 0; q < kTsRows / 4; ++q)
-          c = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[(4 * q + lk) * kMaxK + 16 * ta + li],
-                                                   Xs[(4 * q + lk) * kMaxK + 16 * tb + li], c, 0, 0, 0);
+        for (int q = 0; q < ROWS / 4; ++q)
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[(4 * q + lk) * KW + 16 * ta + li],
+                                                   Xs[(4 * q + lk) * KW + 16 * tb + li], c, 0, 0, 0);
         acc[t] = c;
       }
     }
@@ -521,11 +526,14 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_staged_kernel(int n, int ku,
   }
   if (xnorm_part != nullptr) {
     __syncthreads();
-    Xs[row0 * kMaxK + col] = xsq;  // (row0 = wave: the four lanes of a column sit in the four waves)
+    Xs[row0 * KW + col] = xsq;  // (the RPT lanes of a column, in order)
     __syncthreads();
-    if (tid < kx)
-      xnorm_part[static_cast<int64_t>(blockIdx.x) * kx + tid] =
-          ((Xs[tid] + Xs[kMaxK + tid]) + Xs[2 * kMaxK + tid]) + Xs[3 * kMaxK + tid];
+    if (tid < kx) {
+      double v = 0.0;
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) v += Xs[q * KW + tid];
+      xnorm_part[static_cast<int64_t>(blockIdx.x) * kx + tid] = v;
+    }
   }
 }
 
@@ -951,8 +959,12 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
       set_error("internal: column norms ride along with a row-major U only");
       return EIGD_E_INTERNAL;
     }
-    hipLaunchKernelGGL(gemm_tn_staged_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, dX, ldx,
-                       partial, xpart);
+    if (ku <= 32 && kx <= 32)
+      hipLaunchKernelGGL(gemm_tn_staged_kernel<32>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, dX, ldx,
+                         partial, xpart);
+    else
+      hipLaunchKernelGGL(gemm_tn_staged_kernel<64>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, dX, ldx,
+                         partial, xpart);
     EIGD_LAUNCH_CHECK();
     rc = reduce_to_host(ctx, partial, nb, nout, res, hC);
     if (rc) return rc;
@@ -969,7 +981,7 @@ static int gemm_tn_device(eigd_ctx* ctx, int n, int ku, int kx, const double* dU
     hipLaunchKernelGGL(gemm_tn_kernel<1>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, csu, dX, ldx,
                        partial);
   else if (csu == 1 && staged_tn)
-    hipLaunchKernelGGL(gemm_tn_staged_kernel, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, dX, ldx,
+    hipLaunchKernelGGL(gemm_tn_staged_kernel<64>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, dX, ldx,
                        partial, static_cast<double*>(nullptr));
   else
     hipLaunchKernelGGL(gemm_tn_kernel<4>, dim3(nb), dim3(kThreads), 0, ctx->stream, n, ku, kx, dU, rsu, csu, dX, ldx,
