@@ -1097,7 +1097,8 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     # model.  Left alone it takes the recurrence apart (<r, C r>_F turns negative: step 24 on that column).  Every p-th
     # step therefore projects the residual AND the previous one, which the three-term recurrence brings back in the next
     # step (projecting r alone only divided the component by |1 - rho|: it kept growing from period to period);
-    # p = the largest period with 1e-13 (4 g)^p < 1e-8, four at most.  The steps in between take their residual norms
+    # p = the largest period with 1e-13 (4 g)^p < 1e-7 (measured at the ends of such periods: 3e-6 at most; the
+    # recurrence's scalars feel the square of it), four at most.  The steps in between take their residual norms
     # from the update kernel.
     lam_all = np.asarray(lam_c, dtype=float)
     lam_defl = lam_all if prob.lam_phi is None else np.asarray(prob.lam_phi, dtype=float)
@@ -1105,7 +1106,7 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
         g = np.nanmax(np.abs(1.0 - (lam_all[:, None] - sigma) / (lam_defl[None, :] - sigma)))
     proj_every = 1
     if np.isfinite(g):
-        proj_every = int(max(1, min(4, np.floor(np.log(1e5) / np.log(max(4.0 * g, 1.0 + 1e-12))))))
+        proj_every = int(max(1, min(4, np.floor(np.log(1e6) / np.log(max(4.0 * g, 1.0 + 1e-12))))))
     if tuning.cg_projection_period:
         proj_every = int(tuning.cg_projection_period)
     LAST_ROUND["cg_projection_period"] = proj_every
