@@ -1165,8 +1165,7 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
         r, r_old = r_old, r
 
     lo, hi = _active_range(done)
-    prob.project_r_norm2(r.cols(lo, hi))                  # ref 1232 (the caller projected already, 1193: measured)
-    ctx.fetch_colnorm2(hi - lo)
+    # (ref 1232 projects the start residual once more: the caller has just done that, 1193 -- nothing to take out)
     # Pipeline.  Step j = first_part(j) [sweep .. recurrences] + projection of the new residual, whose norms the host
     # needs to know who has finished.  first_part(j + 1) is put in flight BEFORE the host waits for the norms of step j
     # (unless every live mode is expected to finish with step j -- its last reduction applied once more, within a factor
