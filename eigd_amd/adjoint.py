@@ -122,12 +122,14 @@ class DeviceProblem:
         U, V = self._projector()
         return X.project(V, U)
 
-    def extra_correction_coefficients(self, dPhib, lam):
+    def extra_correction_coefficients(self, dPhib, lam, Gx=None):
         """
         Share of psi along the extra eigenvectors, in closed form as for the pairs j <= N of reference 385-389:
         psi_i += phi_j G0[j, i] / (lam_j - lam_i) with G = -Phix^T Phib (buckling: G0 = diag(lam_x) G).  nx x N.
+        ``Gx``: -Phix^T Phib if the caller has it already.
         """
-        Gx = -self.Phix.tdot(dPhib)
+        if Gx is None:
+            Gx = -self.Phix.tdot(dPhib)
         if self.mode != "normal":
             Gx = self.lam_x[:, None] * Gx
         return Gx / (self.lam_x[:, None] - np.asarray(lam, dtype=float)[None, :])
@@ -1036,7 +1038,7 @@ def _cg_solution_coefficients(log, k):
     return S
 
 
-def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
+def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist, host_work=None):
     """
     All columns of R0 (at most 64) by conjugate gradients in the factor inner product, in lock step.  Same Krylov spaces
     as the Arnoldi form (reference 1246-1277), same stopping rule on the true Euclidean residual (1275), no Krylov
@@ -1076,7 +1078,7 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     st_h[_CG_ROWS["tol2"], :k] = tol2
     st_h[_CG_ROWS["alpha"], :k] = sgn * (np.asarray(lam_c, dtype=float) - sigma)   # ref 1264-1269
     state = ctx.from_host(st_h)
-    r = ctx.empty(n, k).copy_from(R0)
+    r = R0                                                 # (the caller's block is the work block: it is consumed)
     r_old, y = ctx.empty(n, k), ctx.empty(n, k)
     deferred = bool(tuning.cg_solution_from_history)
     if deferred:
@@ -1175,6 +1177,8 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     # coefficients of psi zero) and leaves the range in step j + 2, so every column of a block has seen the same number of
     # buffer swaps when it stops moving.
     first_part(1, lo, hi, None, lo)
+    if host_work is not None:
+        host_work()                                        # (the caller's host-side work, under the first step's kernels)
     rng_j = (lo, hi)                                       # range of the step whose projection is next
     nsteps = 0
     j = 1
@@ -1263,7 +1267,7 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     return psi, converged, info, ok
 
 
-def _sibk_cg(prob, R, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
+def _sibk_cg(prob, R, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist, host_work=None):
     """the short-recurrence solver over all columns of R, 64 at a time; (update, converged, info, ok)"""
     k = R.k
     upd = prob.ctx.zeros(prob.n, k) if k > 64 else None
@@ -1271,7 +1275,7 @@ def _sibk_cg(prob, R, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist):
     for a in range(0, k, 64):
         b = min(k, a + 64)
         ua, ca, ia, oka = _sibk_cg_round(prob, R.cols(a, b) if k > 64 else R, lam_c[a:b], sigma, rnorm0, rtol, atol, maxsteps,
-                                         hist[a:b])
+                                         hist[a:b], host_work=host_work if a == 0 else None)
         if k > 64:
             upd.cols(a, b).copy_from(ua)
         else:
@@ -1400,7 +1404,8 @@ def _run_groups(prob, Rc, lam_p, sigma, rnorm0, rtol, atol, maxiter, sub_hist, s
     return upd, conv, info
 
 
-def _sibk_device(prob, dPhib, dpsi, lam_c, sigma, rtol, atol, maxiter, nrestart, callback, rnorm0=None, streams=None):
+def _sibk_device(prob, dPhib, dpsi, lam_c, sigma, rtol, atol, maxiter, nrestart, callback, rnorm0=None, streams=None,
+                 host_work=None):
     """
     Lock-step sibk (bs_target = 1, update_guess = False) on the columns of dPhib / dpsi.
     dpsi is updated in place; returns the info list.
@@ -1421,7 +1426,8 @@ def _sibk_device(prob, dPhib, dpsi, lam_c, sigma, rtol, atol, maxiter, nrestart,
     if streams == 1 and _short_recurrence_applies(prob):
         # positive definite shift: conjugate gradients in the factor inner product (same spaces, no history); as many
         # steps as the reference's restarted loop may take in all (1312-1321)
-        upd, conv, inf, ok = _sibk_cg(prob, R, lam_c, sigma, rnorm0, rtol, atol, maxiter * (nrestart + 1), hist)
+        upd, conv, inf, ok = _sibk_cg(prob, R, lam_c, sigma, rnorm0, rtol, atol, maxiter * (nrestart + 1), hist,
+                                      host_work=host_work)
         if ok:
             LAST_ROUND["recurrence"] = "short"
             dpsi.assign_lincomb([(1.0, dpsi), (1.0, upd)])
@@ -1429,6 +1435,8 @@ def _sibk_device(prob, dPhib, dpsi, lam_c, sigma, rtol, atol, maxiter, nrestart,
             return [i for i in inf if i is not None]
         LAST_ROUND["recurrence"] = "arnoldi (the short recurrence broke down or stalled)"
         hist = [[] for _ in range(k)]
+        R = prob.residual(dPhib, dpsi, lam_c)            # (the short recurrence worked in the residual block)
+        prob.project_r(R)
     pending = np.arange(k)
     for attempt in range(nrestart + 1):                  # ref 1312-1321: restarts reuse the same residual
         Rc = R if len(pending) == k else R.gather_cols(pending)

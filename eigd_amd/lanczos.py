@@ -705,14 +705,28 @@ class _AdjointAPI:
             kw.pop("eig_atol", None)
             if kw:
                 raise TypeError(f"sibk() got unexpected keyword arguments {sorted(kw)}")
-            G = -prob.Phi.tdot(dPhib)
-            Glo = adj.refine_repeated_entries(G, lam, prob.Phi, dPhib, eig_atol)
             # Converged eigenpairs beyond N (the eigensolver's basis holds some): deflated like the N requested ones --
             # the projectors of 1193 / 1232 / 1250-1257 take [Phi | Phix] -- and their share of psi added in closed form
             # below, as 385-389 does for j <= N.  psi is unique, the Krylov solve just no longer has to resolve the
             # eigenvalues closest above lam_N, which are what makes the high modes slow.
             prob.use_extra = prob.PhiD is not None
             prob.lam_phi = lam
+            Cx = None
+            if prob.use_extra and prob.PhiD.k <= 64:
+                GD = -prob.PhiD.tdot(dPhib)                   # G (2109-2116) and the extra pairs' rows in one product
+                G = np.ascontiguousarray(GD[:N])
+                Cx = prob.extra_correction_coefficients(dPhib, lam, Gx=GD[N:])
+            else:
+                G = -prob.Phi.tdot(dPhib)
+            Glo = adj.refine_repeated_entries(G, lam, prob.Phi, dPhib, eig_atol)
+            early = {}
+
+            def host_work():
+                """what depends on G alone (385-389, 373-383: half a millisecond of host loops), done while the device
+                runs the first Krylov steps"""
+                if "corr" not in early:
+                    early["corr"] = adj.correction_coefficients(lam, G, eig_atol, self.mode, Glo)
+
             try:
                 if prob.use_extra:
                     psi_c.project(prob.Phix, prob.BPhix)      # the guess gives up its share along Phix
@@ -721,10 +735,21 @@ class _AdjointAPI:
                                                           bs_target, update_guess, callback, nrestart)
                 else:
                     self.last_info = adj._sibk_device(prob, dPhib_c, psi_c, lam_c, self.sigma, rtol, atol, maxiter,
-                                                      nrestart, callback, rnorm0=rnorm0, streams=streams)
+                                                      nrestart, callback, rnorm0=rnorm0, streams=streams, host_work=host_work)
+                host_work()
+                Cc, data = early["corr"]
                 if prob.use_extra:
-                    Cx = prob.extra_correction_coefficients(dPhib, lam)
-                    psi_c.add_product(prob.Phix, Cx if cols is None else Cx[:, cols], alpha=1.0, beta=1.0)
+                    if Cx is None:
+                        Cx = prob.extra_correction_coefficients(dPhib, lam)
+                    Cc_sub, Cx_sub = (Cc, Cx) if cols is None else (Cc[:, cols], Cx[:, cols])
+                    if prob.PhiD.k <= 64:                     # both shares in one pass over [Phi | Phix]
+                        psi_c.add_product(prob.PhiD, np.vstack([Cc_sub, Cx_sub]), alpha=1.0, beta=1.0)
+                    else:
+                        psi_c.add_product(prob.Phix, Cx_sub, alpha=1.0, beta=1.0)
+                        adj._apply_correction(psi_c, prob.Phi, Cc, cols=cols)
+                else:
+                    adj._apply_correction(psi_c, prob.Phi, Cc, cols=cols)
+                G = None                                      # (correction applied: nothing left for the common tail)
             finally:
                 prob.use_extra = False
         elif method == "pgmres":
