@@ -210,8 +210,9 @@ def _emit(callback, histories, order):
 # ---------------------------------------------------------------------------
 def repeated_pairs(lam, eig_atol=1e-5):
     """the pairs (i, j), j < i, that the reference treats as numerically repeated (ref 370-372), in its loop order"""
-    N = len(lam)
-    return [(i, j) for i in range(N) for j in range(i) if _is_close(lam[i], lam[j], atol=eig_atol)]
+    lam = np.asarray(lam, dtype=float)
+    close = np.tril(np.fabs(lam[:, None] - lam[None, :]) < eig_atol, -1)   # (_is_close for every pair j < i at once)
+    return [(int(i), int(j)) for i, j in zip(*np.nonzero(close))]            # row-major: i ascending, then j
 
 
 def compensated_entries(dU, dX, rows, cols, sign=1.0):
@@ -263,31 +264,33 @@ def correction_coefficients(lam, G, eig_atol=1e-5, mode="normal", Glo=None):
     ``Glo``: low-order parts of the entries of repeated pairs (refine_repeated_entries); xi and eta are then formed in
     extended precision from hi + lo, so the division by the gap magnifies no rounding of ours.
     """
+    lam = np.asarray(lam, dtype=float)
     N = len(lam)
     G0 = G if mode == "normal" else np.diag(lam) @ G
+    # distinct pairs (385-389): Cc[a, b] = G0[a, b] / (lam_a - lam_b), all of them at once (every entry is written once in
+    # the reference's loop, so the order does not enter); repeated pairs (373-383) in the reference's loop order
+    diff = lam[:, None] - lam[None, :]
+    distinct = ~(np.fabs(diff) < eig_atol)
+    np.fill_diagonal(distinct, False)
     Cc = np.zeros((N, N))
+    np.divide(G0, diff, out=Cc, where=distinct)
     data = {}
     ld = np.longdouble
-    for i in range(N):
-        for j in range(i):
-            gap = lam[j] - lam[i]
-            if _is_close(lam[i], lam[j], atol=eig_atol):
-                if Glo is None:
-                    xi = 0.5 * (G0[j, i] - G0[i, j]) / gap
-                    eta = 0.5 * (lam[i] * G0[j, i] - lam[j] * G0[i, j]) / gap
-                else:
-                    gji, gij = ld(G[j, i]) + ld(Glo[j, i]), ld(G[i, j]) + ld(Glo[i, j])
-                    if mode != "normal":                      # G0 = diag(lam) G
-                        gji, gij = ld(lam[j]) * gji, ld(lam[i]) * gij
-                    xi = float(ld(0.5) * (gji - gij) / ld(gap))
-                    eta = float(ld(0.5) * (ld(lam[i]) * gji - ld(lam[j]) * gij) / ld(gap))
-                data.setdefault(i, [])
-                data.setdefault(j, [])
-                data[i].append((j, xi, eta))
-                data[j].append((i, xi, eta))
-            else:
-                Cc[j, i] += G0[j, i] / gap
-                Cc[i, j] += G0[i, j] / (lam[i] - lam[j])
+    for i, j in repeated_pairs(lam, eig_atol):
+        gap = lam[j] - lam[i]
+        if Glo is None:
+            xi = 0.5 * (G0[j, i] - G0[i, j]) / gap
+            eta = 0.5 * (lam[i] * G0[j, i] - lam[j] * G0[i, j]) / gap
+        else:
+            gji, gij = ld(G[j, i]) + ld(Glo[j, i]), ld(G[i, j]) + ld(Glo[i, j])
+            if mode != "normal":                      # G0 = diag(lam) G
+                gji, gij = ld(lam[j]) * gji, ld(lam[i]) * gij
+            xi = float(ld(0.5) * (gji - gij) / ld(gap))
+            eta = float(ld(0.5) * (ld(lam[i]) * gji - ld(lam[j]) * gij) / ld(gap))
+        data.setdefault(i, [])
+        data.setdefault(j, [])
+        data[i].append((j, xi, eta))
+        data[j].append((i, xi, eta))
     return Cc, data
 
 
