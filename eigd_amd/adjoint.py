@@ -1126,8 +1126,20 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist, h
             return z
         q, i = divmod(j - 1, _CG_CHUNK)
         while len(zchunks) <= q:
-            zchunks.append(ctx.workspace_stack(("cg_z", len(zchunks), k), _CG_CHUNK, n, k))
+            zchunks.append(ctx.workspace_stack(("cg_z", len(zchunks), n, k), _CG_CHUNK, n, k))
         return zchunks[q][i]
+
+    if deferred:
+        # the history stacks are kept between calls per block shape; a caller that walks through many widths keeps the two
+        # last ones only (16 slabs of n x k each per allocation)
+        shapes = ctx.__dict__.setdefault("_cg_z_shapes", [])
+        if (n, k) in shapes:
+            shapes.remove((n, k))
+        shapes.append((n, k))
+        for old in shapes[:-2]:
+            for tag in [t for t in ctx.__dict__.get("_ws", {}) if isinstance(t, tuple) and t[0] == "cg_z" and t[2:] == old]:
+                del ctx.__dict__["_ws"][tag]
+        del shapes[:-2]
 
     norms_of = {}                                          # step -> device block of its residual norms (unprojected steps)
 

@@ -192,6 +192,21 @@ def test_short_recurrence_keeps_the_residual_out_of_the_deflated_directions(monk
     assert max(v for _, v in seen) > 1e-5, seen
 
 
+def test_history_stacks_are_kept_for_the_two_last_block_shapes_only():
+    import eigd_amd as eg
+    from eigd_amd.device import default_context
+
+    ctx = default_context()
+    g = load_golden("g4_laplace900_basiclanczos")
+    K, M = csr_from(g, "K"), csr_from(g, "M")
+    lam, Phi, Phib = g["normal_lam"], g["normal_Phi"], g["Phib"]
+    fac = eg.SpLuOperator((K + 0.1 * M).tocsc(), ctx=ctx)
+    for N in (6, 5, 4, 3):
+        eg.sibk(Phib[:, :N], K, M, lam[:N], Phi[:, :N], factor=fac, sigma=-0.1, rtol=1e-10, ctx=ctx)
+    tags = [t for t in ctx.__dict__.get("_ws", {}) if isinstance(t, tuple) and t[0] == "cg_z"]
+    assert sorted({t[3] for t in tags}) == [3, 4], tags
+
+
 def test_solution_coefficients_on_the_device_match_the_host_twin():
     """eigd_cg_solution_coefficients against adjoint._cg_solution_coefficients on a made-up log: columns that stop moving
     at different steps, a restart (rho = 1) in the middle, a column that never moves"""
@@ -234,7 +249,7 @@ def test_short_recurrence_without_memory_for_its_history_hands_over(monkeypatch)
     orig = dev.Context.workspace_stack
 
     def stingy(self, tag, ns, n, k=1):
-        if isinstance(tag, tuple) and tag[0] == "cg_z" and tag[1] >= 1:
+        if isinstance(tag, tuple) and tag[0] == "cg_z" and tag[1] >= 1:   # (tag: name, allocation number, n, k)
             raise _ffi.EigdHipError("out of memory (test)")
         return orig(self, tag, ns, n, k)
 
