@@ -199,12 +199,47 @@ def measured_mfma(entry, sources, useful_flops, us_per_launch):
                     "really issued need pipe_time_us; the launch takes us_per_launch"}
 
 
-def main_c5(args):
+class _LastOfMany:
+    """stand-in communicator of the LAST rank of P (it owns the slowest mode): no collective, partial results"""
+
+    def __init__(self, p):
+        self.rank, self.size = p - 1, p
+
+    def allreduce_sum(self, a):
+        return a
+
+    def allreduce_max(self, x):
+        return x
+
+    def barrier(self):
+        pass
+
+
+def scaling_model_of(ctx, rank_step, N, ms_per_step, what):
     """
-    Config C5 (SURVEY 8d; stand-in for the reference's CRM wingbox, examples/crm.py): thin-walled shell box, 6 dof per
-    node, ~2.0 M dof, 64 modes, IRAM m = 129; step = solve_adjoint (sibk, rtol 1e-10, 80 Krylov vectors) +
-    add_total_derivative w.r.t. the wall-thickness groups, operands resident in HBM.  One GPU.
+    What mode sharding can give: the block-cyclic share of the slowest rank of P = 2, 4, 8, timed on this one GPU with a
+    stand-in communicator (the 4 MB all-reduce of df/dx adds < 0.1 ms).  efficiency = ms_per_step / (P * rank_ms).
     """
+    model = {"note": f"slowest rank's share of the same {N}-mode step ({what}), timed on this one GPU (no collective); "
+                     "efficiency = ms_per_step / (P * rank_ms)", "ms_per_step_one_gpu": round(ms_per_step, 3), "ranks": {}}
+    for P_ in (2, 4, 8):
+        if P_ > N:
+            continue
+        cm = _LastOfMany(P_)
+        rank_step(cm)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            rank_step(cm)
+        ctx.sync()
+        t_r = (time.perf_counter() - t0) / 3
+        model["ranks"][str(P_)] = {"rank_ms": round(1e3 * t_r, 3), "modes_of_rank": int(len(range(P_ - 1, N, P_))),
+                                   "predicted_efficiency": round(ms_per_step * 1e-3 / (P_ * t_r), 3)}
+    return model
+
+
+def c5_setup(args):
+    """config C5 up to the eigenpairs: (box, dev, ctx, solver, sigma, fstats, lam, times)"""
     import eigd_amd as eg
     from eigd_amd.problems import ShellBox, ShellBoxOnDevice
 
@@ -242,11 +277,39 @@ def main_c5(args):
     dPhib = ctx.from_host(Phib)
     dAdx, dBdx = dev.callbacks()
 
-    def step():
-        dpsi, data = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1, maxiter=80)
+    def step(comm=None):
+        dpsi, data = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1, maxiter=80,
+                                          comm=comm)
         dfdx = solver.add_total_derivative(w, dPhib, dpsi, dAdx, dBdx, np.zeros(box.ngroups), adj_corr_data=data,
-                                           deriv_type="tensor")
+                                           deriv_type="tensor", comm=comm)
         return dpsi, data, dfdx
+
+    return box, dev, ctx, solver, sigma, fstats, Phib, dPhib, step, (t_setup, t_eig), (N, m)
+
+
+def c5_scaling_model(args):
+    """the scaling model of config C5 (64 modes: 8 per rank at 8 GPUs) for the default run's JSON line"""
+    box, dev, ctx, solver, sigma, fstats, Phib, dPhib, step, times, (N, m) = c5_setup(args)
+    step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        step()
+    ctx.sync()
+    ms = 1e3 * (time.perf_counter() - t0) / 2
+    model = scaling_model_of(ctx, lambda cm: step(cm), N, ms, f"config C5: shell box, {box.n / 1e6:.2f}M dof, {N} modes")
+    ctx.release_workspaces()
+    return model
+
+
+def main_c5(args):
+    """
+    Config C5 (SURVEY 8d; stand-in for the reference's CRM wingbox, examples/crm.py): thin-walled shell box, 6 dof per
+    node, ~2.0 M dof, 64 modes, IRAM m = 129; step = solve_adjoint (sibk, rtol 1e-10, 80 Krylov vectors) +
+    add_total_derivative w.r.t. the wall-thickness groups, operands resident in HBM.  One GPU.
+    """
+    box, dev, ctx, solver, sigma, fstats, Phib, dPhib, step, (t_setup, t_eig), (N, m) = c5_setup(args)
+    rng = np.random.default_rng(2)
 
     for _ in range(max(args.warmup, 1)):  # (the first call allocates ~170 GB of Krylov workspace)
         step()
@@ -283,6 +346,8 @@ def main_c5(args):
         "accuracy": {"adjoint_residual_rel_max": float(np.max(res) / np.linalg.norm(Phib, axis=0).max()),
                      "sibk_iterations_max": int(max(solver.last_info))},
         "preamble_s": {"setup_s": round(t_setup, 2), "eigensolve_s": round(t_eig, 2)},
+        "scaling_model": (None if args.no_scaling_model else
+                          scaling_model_of(ctx, lambda cm: step(cm), N, 1e3 * elapsed / args.steps, "config C5")),
     }
     print(json.dumps(out), flush=True)
     return 0
@@ -321,6 +386,8 @@ def main():
     ap.add_argument("--no-fd-check", action="store_true", help="skip the directional finite-difference check of df/dx")
     ap.add_argument("--no-arnoldi-leg", action="store_true", help="skip the untimed comparison solve in the Arnoldi form")
     ap.add_argument("--no-scaling-model", action="store_true", help="skip the slowest-rank timings for P = 2, 4, 8")
+    ap.add_argument("--no-extras0-leg", action="store_true", help="skip the untimed step without extra deflated pairs")
+    ap.add_argument("--no-c5-scaling-model", action="store_true", help="skip the scaling model of config C5 (64 modes)")
     ap.add_argument("--dump-dfdx", default=None, help="rank 0 saves the df/dx of the last timed step to this .npy file")
     ap.add_argument("--force-launch", action="store_true",
                     help="start the rank processes through the launcher even for --gpus 1 (test of the launcher)")
@@ -427,7 +494,10 @@ def main():
     factor.count = eig_count
     eig_info = {"block_size": int(getattr(solver, "block_size", 1)), "internal_basis": int(getattr(solver, "internal_basis", args.m)),
                 "restarts": int(solver.n_restarts), "sweeps": int(getattr(solver, "sweeps", eig_count)),
-                "factor_applications": int(eig_count), "extra_pairs_for_deflation": int(solver.n_extra)}
+                "factor_applications": int(eig_count), "extra_pairs_for_deflation": int(solver.n_extra),
+                # the true-residual check of the returned pairs inside solve(): one N-column sweep + product, inside
+                # eigensolve_s but counted neither in `sweeps` nor in `factor_applications` (a check, not a solve)
+                "residual_check_sweeps": 1, "residual_check_columns": int(N)}
     log(rank, f"eigensolve: {timing['eigensolve_s']:.2f}s (repeated: {timing['eigensolve_repeat_s']:.2f}s), {eig_info}; "
               f"BLF = {lam[:4]} ... {lam[-1]:.4f}")
 
@@ -542,7 +612,7 @@ def main():
         for _ in range(args.numpy_steps + 2):          # two untimed: page-locked result buffers and Phib's registration
             # a design loop brings new right-hand sides every step: the content of the caller's array changes (outside
             # the timed region), so the device copy kept from the last step is found stale and Phib is uploaded again --
-            # once per step; what the kept copies save is the SECOND upload of Phib and the upload of psi (tuning.host_twins)
+            # by both calls; what the kept copy saves is the upload of psi (tuning.host_twins = "returned")
             np.multiply(Phib_np, 1.0 + 1e-9, out=Phib_np)
             ctx.sync()
             t0 = time.perf_counter()
@@ -605,11 +675,13 @@ def main():
                      "host_wait_by_entry_point_ms": abi_top,
                      "transfer_alone_ms": {"h2d_phib": round(1e3 * t_h2d, 3), "d2h_psi": round(1e3 * t_d2h, 3)},
                      "steps": args.numpy_steps, "first_calls_ms": [round(1e3 * t, 1) for t in t_each[:2]],
-                     "note": "same step with numpy arrays in and out: Phib (new content every step) is uploaded once, psi "
-                             "downloaded once; add_total_derivative finds the device copies of both arrays (validated "
-                             "against a content sample, tuning.host_twins) instead of two more transfers.  Results come back "
-                             "in pooled page-locked memory, the caller's Phib is page-locked in place from its second use; "
-                             "the first two calls (listed) pay for that once"}
+                     "host_twins": str(__import__("eigd_amd").tuning.host_twins),
+                     "note": "same step with numpy arrays in and out: the caller's Phib is transferred by BOTH calls (it is "
+                             "read as given, like the reference does), psi is downloaded once and comes back read-only: "
+                             "handed to add_total_derivative as it is, the device block it came from is used again "
+                             "(tuning.host_twins = 'returned'; an in-place edit of it raises).  Three transfers of "
+                             "n x N doubles per step.  Results live in pooled page-locked memory, the caller's Phib is "
+                             "page-locked in place from its second use; the first two calls (listed) pay for that once"}
         if args.pyprofile:
             import cProfile
             import pstats
@@ -655,46 +727,57 @@ def main():
         ctx.release_workspaces()                         # the Krylov stacks of the Arnoldi form (26 GB at C3) go back
         log(rank, f"Arnoldi form: {arnoldi_form['ms_per_step']} ms/step, iterations {sum(it_arn)} against {sum(it_short)}, "
                   f"psi rel diff {arnoldi_form['psi_rel_diff']:.1e}")
+    # ------------------------------------------------------------------ the reference's deflation set: no extra pairs
+    # (untimed leg: the eigensolver keeps up to 32 converged pairs beyond N for the adjoint stage's deflation -- paid for
+    # in the untimed eigensolve; with extra = 0 the Krylov solves deflate the N requested pairs only, as the reference does)
+    extras0 = None
+    if world == 1 and comm is None and not args.emulate_rank and not args.no_extras0_leg:
+        import eigd_amd as _eg
+
+        keep_x = _eg.tuning.iram_extra
+        _eg.tuning.iram_extra = 0
+        try:
+            solver0 = _eg.IRAM(N=N, m=args.m, mode="buckling", ctx=ctx)
+            ctx.sync()
+            t0 = time.perf_counter()
+            solver0.solve(dG, dK, factor, sigma)
+            ctx.sync()
+            t_eig0 = time.perf_counter() - t0
+
+            def step0():
+                dpsi0, data0 = solver0.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1)
+                return dpsi0, solver0.add_total_derivative(lamb, dPhib, dpsi0, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data0,
+                                                           deriv_type="tensor")
+
+            step0()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                dpsi0, dfdx0 = step0()
+            ctx.sync()
+            t_x0 = (time.perf_counter() - t0) / 3
+            extras0 = {"ms_per_step": round(1e3 * t_x0, 3), "value": round(N / t_x0, 3), "eigensolve_s": round(t_eig0, 4),
+                       "sibk_iterations": [int(i) for i in solver0.last_info], "extra_pairs_for_deflation": int(solver0.n_extra),
+                       "recurrence": _adj.LAST_ROUND.get("recurrence"),
+                       "dfdx_rel_diff": float(np.linalg.norm(dfdx0 - dfdx) / np.linalg.norm(dfdx)),
+                       "design_point_s": None}
+            del dpsi0, solver0
+            log(rank, f"extra = 0 (the reference's deflation set): {extras0['ms_per_step']} ms/step, eigensolve {t_eig0:.3f}s")
+        finally:
+            _eg.tuning.iram_extra = keep_x
+            factor.count = adj_count
     # ------------------------------------------------------------------ what mode sharding can give: the slowest rank's share
     # (one GPU: the block-cyclic share of the LAST rank of P -- it owns the slowest mode -- timed with a stand-in
     # communicator; no collective: the 4 MB all-reduce of df/dx adds < 0.1 ms.  A prediction for the next multi-GPU run.)
     scaling_model = None
     if world == 1 and comm is None and not args.no_scaling_model:
-        class _LastOfMany:
-            def __init__(self, p):
-                self.rank, self.size = p - 1, p
+        def rank_step(cm):
+            dpsi_r, data_r = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1,
+                                                  comm=cm, streams=args.streams)
+            solver.add_total_derivative(lamb, dPhib, dpsi_r, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data_r,
+                                        deriv_type="tensor", comm=cm)
 
-            def allreduce_sum(self, a):
-                return a
-
-            def allreduce_max(self, x):
-                return x
-
-            def barrier(self):
-                pass
-
-        scaling_model = {"note": "slowest rank's share of the same 32-mode step, timed on this one GPU (no collective); "
-                                 "efficiency = ms_per_step / (P * rank_ms)", "ranks": {}}
-        for P_ in (2, 4, 8):
-            if P_ > N:
-                continue
-            cm = _LastOfMany(P_)
-
-            def rank_step():
-                dpsi_r, data_r = solver.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1,
-                                                      comm=cm, streams=args.streams)
-                solver.add_total_derivative(lamb, dPhib, dpsi_r, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data_r,
-                                            deriv_type="tensor", comm=cm)
-
-            rank_step()
-            ctx.sync()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                rank_step()
-            ctx.sync()
-            t_r = (time.perf_counter() - t0) / 3
-            scaling_model["ranks"][str(P_)] = {"rank_ms": round(1e3 * t_r, 3), "modes_of_rank": int(len(range(P_ - 1, N, P_))),
-                                                "predicted_efficiency": round(ms_per_step * 1e-3 / (P_ * t_r), 3)}
+        scaling_model = scaling_model_of(ctx, rank_step, N, ms_per_step, "config C3")
         log(rank, f"scaling model (slowest rank of P on one GPU): {scaling_model['ranks']}")
     # ------------------------------------------------------------------ accuracy of the timed result
     res, ortho = solver.eval_adjoint_residual_norm(dPhib, dpsi, b_ortho=False) if world == 1 else (None, None)
@@ -874,6 +957,8 @@ def main():
         "sibk_iterations": sibk_iterations,
         "arnoldi_form": arnoldi_form,
         "scaling_model": scaling_model,
+        "scaling_model_c5": None,
+        "extras0": extras0,
         "eigensolve_sweeps": int(eig_count),
         "eigensolver": eig_info,
         "lock_step": {"recurrence": last_round.get("recurrence"),
@@ -894,6 +979,20 @@ def main():
         "design_point_s": round(timing["device_assemble_and_refactor_s"] + timing["eigensolve_repeat_s"] + ms_per_step * 1e-3, 4),
         "first_design_point_s": round(timing["device_assemble_and_refactor_s"] + timing["eigensolve_s"] + ms_per_step * 1e-3, 4),
     }
+    out["design_point_modes_per_s"] = round(N / out["design_point_s"], 3)
+    if extras0 is not None:
+        extras0["design_point_s"] = round(timing["device_assemble_and_refactor_s"] + extras0["eigensolve_s"]
+                                          + extras0["ms_per_step"] * 1e-3, 4)
+        extras0["design_point_modes_per_s"] = round(N / extras0["design_point_s"], 3)
+    if world == 1 and comm is None and default_c3 and not args.no_scaling_model and not args.no_c5_scaling_model:
+        # config C5 (64 modes: 8 per rank at 8 GPUs) through the same model; the C3 objects go first
+        try:
+            solver = factor = dK = dG = dPhib = dpsi = Xs = None   # (the closures above hold these names, not the objects)
+            ctx.release_workspaces()
+            out["scaling_model_c5"] = c5_scaling_model(args)
+            log(rank, f"scaling model, config C5: {out['scaling_model_c5']['ranks']}")
+        except Exception as exc:                       # (a model for the record: it must not take the bench line with it)
+            out["scaling_model_c5"] = {"error": repr(exc)}
     print(json.dumps(out), flush=True)
 
 
@@ -950,8 +1049,9 @@ def cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, solver, dPhib, dp
         return np.where(ed[:, :, None] >= 0, M[np.maximum(ed, 0)], 0.0)
 
     wAe, wBe, pe = gather(WA[:, sample]), gather(WB[:, sample]), gather(Phi[:, sample])
-    dfdx_c = (col.dG_scale() * np.einsum("nak,nab,nbk->n", wAe, col.Ge_unit, pe)
-              + col.dK_scale() * np.einsum("nak,ab,nbk->n", wBe, col.Ke0, pe))
+    dfdx_ck = (col.dG_scale()[:, None] * np.einsum("nak,nab,nbk->nk", wAe, col.Ge_unit, pe)
+               + col.dK_scale()[:, None] * np.einsum("nak,ab,nbk->nk", wBe, col.Ke0, pe))   # per element and sampled mode
+    dfdx_c = dfdx_ck.sum(axis=1)
     t_der = time.perf_counter() - t0
     best = (t_laa + t_sibk + t_der, t_laa, t_sibk, t_der)
     log(0, f"cpu: {len(sample)} modes: laa {t_laa:.1f}s sibk {t_sibk:.1f}s derivative {t_der:.2f}s (iterations {iters})")
@@ -962,8 +1062,16 @@ def cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, solver, dPhib, dp
                                           "buckling", "tensor", np.asarray(sample))
     err_df = float(np.linalg.norm(dfdx_g - dfdx_c) / np.linalg.norm(dfdx_c))
     psi_g = dpsi.get()[:, sample]
-    err_psi = float(np.max(np.linalg.norm(psi_g - psi_c[:, sample], axis=0) / np.linalg.norm(psi_c[:, sample], axis=0)))
-    log(0, f"cpu: GPU-vs-CPU on modes {sample}: psi rel-err {err_psi:.2e}, df/dx rel-err {err_df:.2e}")
+    err_psi_k = np.linalg.norm(psi_g - psi_c[:, sample], axis=0) / np.linalg.norm(psi_c[:, sample], axis=0)
+    err_psi = float(np.max(err_psi_k))
+    per_mode = {}
+    for q, i in enumerate(sample):                       # every sampled mode's own share of df/dx on both sides
+        dg_i = adj._total_derivative_device(solver._prob.Phi, dPhib, dpsi, lam, lamb, dAdx, dBdx, np.zeros(ndv), data,
+                                            "buckling", "tensor", np.asarray([i]))
+        per_mode[str(i)] = {"sibk_iterations_cpu": int(iters[q]), "sibk_iterations_gpu": int(solver.last_info[i]),
+                            "psi_rel_err": float(err_psi_k[q]),
+                            "dfdx_rel_err": float(np.linalg.norm(dg_i - dfdx_ck[:, q]) / np.linalg.norm(dfdx_ck[:, q]))}
+    log(0, f"cpu: GPU-vs-CPU on modes {sample}: psi rel-err {err_psi:.2e}, df/dx rel-err {err_df:.2e}; per mode {per_mode}")
     tot, t_laa, t_sibk, t_der = best
     return {"value": round(len(sample) / tot, 5), "unit": "modes/s", "cores": 1,
             "cores_note": "1 = threads that do work: SuperLU's solve and scipy's CSR products are sequential kernels (the "
@@ -973,7 +1081,8 @@ def cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, solver, dPhib, dp
                       f"eigenpairs, Lanczos basis and right-hand sides: oracle laa guess {t_laa:.1f}s + sibk {t_sibk:.1f}s "
                       f"({iters} iterations) + derivative {t_der:.2f}s, one repetition; SuperLU factor {t_fac:.0f}s untimed, "
                       f"like the GPU's; SuperLU / scipy CSR kernels are sequential whatever the thread settings",
-            "factor_s": round(t_fac, 1), "psi_rel_err_gpu_vs_cpu": err_psi, "dfdx_rel_err_gpu_vs_cpu": err_df}
+            "factor_s": round(t_fac, 1), "psi_rel_err_gpu_vs_cpu": err_psi, "dfdx_rel_err_gpu_vs_cpu": err_df,
+            "per_mode_gpu_vs_cpu": per_mode}
 
 
 if __name__ == "__main__":

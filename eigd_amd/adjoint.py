@@ -22,6 +22,7 @@ exactly as in the reference.
 import numpy as np
 
 from . import tuning
+from .device import writable_result
 from .operators import DeviceOperator, FactorApply, SpLuOperator
 
 MODES = ("normal", "buckling")
@@ -328,7 +329,7 @@ def generate_adjoint_correction(lam, Phi, psi, G=None, Phib=None, eig_atol=1e-5,
     Cc, data = correction_coefficients(lam, G, eig_atol, mode, Glo)
     dpsi = ctx.from_host(psi)
     _apply_correction(dpsi, dPhi, Cc)
-    psi[:] = dpsi.get()  # in place, as ref 386-389
+    writable_result(psi)[:] = dpsi.get()  # in place, as ref 386-389
     return data
 
 
@@ -1092,6 +1093,7 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist, h
         psi_old, z = ctx.zeros(n, k), ctx.empty(n, k)
         log = None
     failed = []                                            # (no memory for another chunk of the history)
+    gave_up = []                                           # columns seen frozen or stalled while the loop ran
     # what the measured projection lets pass: a component along B Phi_D of relative size 1e-11 grows by |1 - alpha theta_j|
     # per step until it is taken out again; psi carries it at that relative size at most, and is projected once at the end
     proj_tol = tuning.cg_projection_tol
@@ -1235,6 +1237,16 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist, h
                 done[c] = converged[c] = True
         if failed:
             break
+        # A column that broke down stops moving (gam = 0: flag 2 on the device) and never meets the tolerance; a
+        # recurrence that has lost its footing stalls.  Both are visible in the norms the host reads anyway: give up at
+        # once -- not after maxsteps sweeps and as many slabs of z history -- and let the Arnoldi form decide.
+        for c in np.flatnonzero(~done):
+            h = hist[c]
+            frozen = len(h) >= 3 and h[-1] > 0.0 and abs(h[-1] - h[-2]) <= 1e-14 * h[-1] and abs(h[-2] - h[-3]) <= 1e-14 * h[-2]
+            if frozen or (len(h) > 12 and not h[-1] < 0.5 * h[-11]):
+                gave_up.append(int(c))
+        if gave_up:
+            break
         if done.all() or j == maxsteps:
             # (a step in flight behind the last one only copies: every column is frozen by then, both buffers hold psi)
             LAST_ROUND["cg_sweeps_for_nothing"] = LAST_ROUND.get("cg_sweeps_for_nothing", 0) + int(in_flight)
@@ -1242,9 +1254,11 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist, h
         if not in_flight:
             LAST_ROUND["cg_waited_for"] = LAST_ROUND.get("cg_waited_for", 0) + 1
             first_part(j + 1, nxt[0], nxt[1], n2, lo)
+            if failed:                                     # (no memory for the step's slab: nothing was enqueued)
+                break
         rng_j = nxt
         j += 1
-    if deferred and not failed:
+    if deferred and not failed and not gave_up:
         # psi = sum_j s_j z_j, coefficients and sum on the device, enqueued before the host looks at the flags (a solve
         # that ends in the Arnoldi form throws the block away)
         nlog = nsteps + 1
@@ -1262,9 +1276,14 @@ def _sibk_cg_round(prob, R0, lam_c, sigma, rnorm0, rtol, atol, maxsteps, hist, h
     # an unfinished mode whose residual has not halved over its last ten steps: the recurrence is not converging (the
     # caller's Phi is not invariant enough for the deflated operator to stay positive definite in finite precision, or
     # lam is not the eigenvalue of its column): the Arnoldi form, which minimises the true residual step by step, decides
-    stalled = [c for c in range(k) if not converged[c] and len(hist[c]) > 12 and not hist[c][-1] < 0.5 * hist[c][-11]]
+    stalled = sorted(set(gave_up) | {c for c in range(k) if not converged[c] and len(hist[c]) > 12 and not hist[c][-1] < 0.5 * hist[c][-11]})
     if stalled:
         ok = False
+    if not ok and deferred:
+        # the z history of a failed attempt goes before the Arnoldi form allocates its own stacks (16 slabs of n x k per chunk)
+        zchunks.clear()
+        for tag in [t for t in ctx.__dict__.get("_ws", {}) if isinstance(t, tuple) and t[0] == "cg_z" and t[2:] == (n, k)]:
+            del ctx.__dict__["_ws"][tag]
     if not ok:                                             # (why the Arnoldi form takes over: for the caller's log)
         LAST_ROUND["cg_exit"] = {"steps": nsteps, "broke_down": [int(c) for c in np.flatnonzero(st[_CG_ROWS["flag"], :k] == 2.0)],
                                  "stalled": stalled, "no_memory_at_step": failed[:1],
@@ -1597,7 +1616,7 @@ def sibk(Phib, A, B, lam, Phi, mode="normal", psi=None, sigma=None, factor=None,
                                 callback, nrestart)
     Cc, data = correction_coefficients(lam, G, eig_atol, mode, Glo)  # ref 1324-1326
     _apply_correction(dpsi, prob.Phi, Cc)
-    _psi[:] = dpsi.get()
+    writable_result(_psi)[:] = dpsi.get()
     return _psi, data, info
 
 
@@ -1686,7 +1705,7 @@ def pgmres(Phib, A, B, lam, Phi, mode="normal", psi=None, sigma=None, factor=Non
                                     refine=lambda Gm, R: refine_repeated_entries(Gm, lam, prob.Phi, R, eig_atol, sign=1.0))
     Cc, data = correction_coefficients(lam, G, eig_atol, mode, Glo)
     _apply_correction(dpsi, prob.Phi, Cc)
-    _psi[:] = dpsi.get()
+    writable_result(_psi)[:] = dpsi.get()
     return _psi, data, info
 
 
@@ -1758,7 +1777,7 @@ def pcpg(Phib, A, B, lam, Phi, mode="normal", psi=None, sigma=None, factor=None,
                                   refine=lambda Gm, R: refine_repeated_entries(Gm, lam, prob.Phi, R, eig_atol, sign=1.0))
     Cc, data = correction_coefficients(lam, G, eig_atol, mode, Glo)
     _apply_correction(dpsi, prob.Phi, Cc)
-    _psi[:] = dpsi.get()
+    writable_result(_psi)[:] = dpsi.get()
     return _psi, data, info
 
 

@@ -97,8 +97,16 @@ def exchange_unique_id(rank, size, make_id, tag="uid", timeout=300.0):
             pass
         uid = make_id()
         tmp = path + f".tmp{os.getpid()}"
-        with open(tmp, "wb") as fh:
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        # mode 0600 whatever the umask: the readers accept only a file that nobody else can write (under umask 002 a
+        # plain open() would publish 0664, which every other rank rejects until its timeout)
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as fh:
             fh.write(uid)
+        os.chmod(tmp, 0o600)
         os.replace(tmp, path)
         return uid
     t0 = time.monotonic()

@@ -90,31 +90,41 @@ class Context:
     # -- device twins of host arrays (the reference's two-call surface hands the same arrays in twice) ---------------
     def twin_upload(self, a):
         """
-        Device block holding the host array ``a`` for READ-ONLY use.  The reference's surface passes Phib to solve_adjoint
-        and again to add_total_derivative, and psi back in as it came out: with ``tuning.host_twins`` the device copy of
-        such an array is kept (as long as the array object lives; four arrays at most) and handed out again instead of a
-        second PCIe transfer.  It is validated on every reuse against the host array itself -- same object, same shape,
-        and a sample of its content kept from the time of the copy: 1024 rows spread over the array plus its first and
-        last page.  A change of the array that touches none of those rows goes unnoticed: callers that edit single
-        entries between the two calls set ``tuning.host_twins = False`` (every call then transfers what it is given).
+        Device block holding the host array ``a`` for READ-ONLY use.  The reference's surface hands psi back to
+        add_total_derivative / eval_adjoint_residual_norm as solve_adjoint returned it: with ``tuning.host_twins ==
+        "returned"`` (the default) the device block such an array was downloaded from is kept and handed out again instead
+        of a second PCIe transfer -- as long as the array is still the read-only array the library returned (see
+        twin_adopt: an in-place edit raises, a caller that makes it writable again gets a transfer).  Arrays the caller
+        owns (Phib) are transferred every time: the library reads what it is given, as the reference does
+        (eigenvector_derivatives.py:1830-1870, 2167-2207).  ``tuning.host_twins = True`` also keeps copies of caller-owned
+        arrays, validated against a content sample only (1024 rows + first and last page: an edit between the sampled
+        rows goes unnoticed -- opt-in); ``False`` keeps nothing.
         """
         from . import tuning
 
+        mode = tuning.host_twins
         big = isinstance(a, np.ndarray) and a.dtype == np.float64 and a.ndim == 2 and a.flags.c_contiguous and a.nbytes >= _PIN_MIN_BYTES
-        if not (tuning.host_twins and big):
+        if not (mode and big):
             return self.from_host(a)
-        blk = _twins.lookup(self, a)
+        blk = _twins.lookup(self, a, owned_only=(mode != True))  # noqa: E712 (True = every array, "returned" = the library's own)
         if blk is None:
             blk = self.from_host(a)
-            _twins.remember(self, a, blk)
+            if mode is True:
+                _twins.remember(self, a, blk)
         return blk
 
     def twin_adopt(self, a, block):
-        """``a`` has just been downloaded from ``block`` (which nobody modifies any more): keep the pair (see twin_upload)"""
+        """
+        ``a`` has just been downloaded from ``block`` (which nobody modifies any more): keep the pair (see twin_upload).
+        The array goes back to the caller READ-ONLY: writing into it raises (numpy's "assignment destination is read-only")
+        instead of leaving a stale device copy behind; ``a.flags.writeable = True`` (or a copy) gives a writable array, and
+        the next call that is handed it transfers it.
+        """
         from . import tuning
 
         if tuning.host_twins and isinstance(a, np.ndarray) and a.ndim == 2 and a.nbytes >= _PIN_MIN_BYTES and block.ld == block.k:
-            _twins.remember(self, a, block)
+            a.flags.writeable = False
+            _twins.remember(self, a, block, owned=True)
 
     def project_stats(self):
         """(projections measured, updates applied) by project_norm2 since the last call; resets the counters"""
@@ -147,15 +157,14 @@ class Context:
 
     def trim_pool(self):
         """give the pooled (released, reusable) device blocks back to the driver"""
-        pool = self.__dict__.pop("_pool", {})
-        self.__dict__["_pool_bytes"] = 0
+        pool = self.__dict__.get("_pool")
+        ptrs = pool.drain() if pool is not None else []
         _pinned.trim()
         _twins.clear()
         if self.h is None:
             return
-        for free in pool.values():
-            for ptr in free:
-                _ffi.lib().eigd_free(self.h, c_vp(ptr))
+        for ptr in ptrs:
+            _ffi.lib().eigd_free(self.h, c_vp(ptr))
 
 
 def default_context():
@@ -199,12 +208,14 @@ class _PinnedHost:
         self.seen = {}            # id(array) -> [weak reference, sightings] of a caller-owned array
         self.registered = {}      # address -> nbytes
         self.asked = {}           # nbytes -> results of that size asked for so far
+        self.surplus = []         # buffers beyond the pool's budget: freed by the next caller of empty() / trim()
         self._lock = threading.RLock()   # (mode groups on several streams upload and download from their own host threads)
 
     def empty(self, shape):
         import weakref
 
         nbytes = int(np.prod(shape)) * 8
+        self._free_surplus()
         with self._lock:
             lst = self.free.get(nbytes)
             ptr = lst.pop() if lst else None
@@ -231,13 +242,19 @@ class _PinnedHost:
         return np.frombuffer(buf, dtype=np.float64).reshape(shape)
 
     def _release(self, ptr, nbytes):
+        """finaliser of a result array (any thread, any time): list moves only, see _DevicePool"""
         with self._lock:
             lst = self.free.setdefault(nbytes, [])
-            keep = len(lst) < _PIN_KEEP_PER_SIZE and self.held + nbytes <= _PIN_POOL_MAX_BYTES
-            if keep:
+            if len(lst) < _PIN_KEEP_PER_SIZE and self.held + nbytes <= _PIN_POOL_MAX_BYTES:
                 lst.append(ptr)
                 self.held += nbytes
-        if not keep:
+            else:
+                self.surplus.append(ptr)
+
+    def _free_surplus(self):
+        with self._lock:
+            ptrs, self.surplus = self.surplus, []
+        for ptr in ptrs:
             try:
                 _ffi.lib().eigd_host_free(c_vp(ptr))
             except Exception:
@@ -249,11 +266,8 @@ class _PinnedHost:
             ptrs = [p for lst in self.free.values() for p in lst]
             self.free.clear()
             self.held = 0
-        for ptr in ptrs:
-            try:
-                _ffi.lib().eigd_host_free(c_vp(ptr))
-            except Exception:
-                pass
+            self.surplus.extend(ptrs)
+        self._free_surplus()
 
     def note_source(self, a):
         """a large caller-owned array is about to be uploaded: page-lock it in place from its second upload on"""
@@ -306,7 +320,7 @@ class _HostTwins:
     def __init__(self):
         import threading
 
-        self.items = []           # [weakref to the array, context, block, sampled row indices, their content], newest last
+        self.items = []           # [weakref to the array, context, block, sampled row indices, their content, owned], newest last
         self._lock = threading.RLock()
 
     @staticmethod
@@ -317,25 +331,36 @@ class _HostTwins:
                                         np.arange(max(0, n - per_page), n)]))
         return idx
 
-    def remember(self, ctx, a, block):
+    def remember(self, ctx, a, block, owned=False):
+        """owned: the library made ``a`` (a download of ``block``) and handed it out read-only"""
         import weakref
 
-        idx = self._rows(a)
+        idx = None if owned else self._rows(a)
         with self._lock:
             self.items = [it for it in self.items if it[0]() is not None and it[0]() is not a]
-            self.items.append([weakref.ref(a), ctx, block, idx, a[idx].copy()])
+            self.items.append([weakref.ref(a), ctx, block, idx, None if owned else a[idx].copy(), owned])
             del self.items[: max(0, len(self.items) - self.KEEP)]
 
-    def lookup(self, ctx, a):
+    def lookup(self, ctx, a, owned_only=False):
         with self._lock:
             for it in self.items:
                 if it[0]() is a and it[1] is ctx:
                     blk = it[2]
-                    if (blk.n, blk.k) == a.shape and np.array_equal(a[it[3]], it[4]):
+                    if it[5]:
+                        # the library's own array: nobody can have written into it while it stayed read-only
+                        ok = (blk.n, blk.k) == a.shape and not a.flags.writeable
+                    else:
+                        ok = (not owned_only) and (blk.n, blk.k) == a.shape and np.array_equal(a[it[3]], it[4])
+                    if ok:
                         return blk
-                    self.items.remove(it)               # the array was changed (or reshaped) since: forget the copy
+                    self.items.remove(it)               # the array was changed (or made writable, or reshaped): forget the copy
                     return None
         return None
+
+    def forget(self, a):
+        """``a`` is about to be modified by the library itself (a psi handed back in as the initial guess)"""
+        with self._lock:
+            self.items = [it for it in self.items if it[0]() is not None and it[0]() is not a]
 
     def clear(self):
         with self._lock:
@@ -343,6 +368,18 @@ class _HostTwins:
 
 
 _twins = _HostTwins()
+
+
+def writable_result(a):
+    """
+    the library is about to write into the caller's array ``a`` (a psi updated in place, reference 386-389, 793, 968,
+    1184): if it is one of the read-only arrays the library handed out itself (Context.twin_adopt), it becomes writable
+    again and its kept device copy is dropped
+    """
+    if isinstance(a, np.ndarray) and not a.flags.writeable:
+        _twins.forget(a)
+        a.flags.writeable = True       # (raises for memory that is read-only for good: the caller's business, as in the reference)
+    return a
 
 
 def pinned_empty(shape):
@@ -354,22 +391,71 @@ _POOL_KEEP_PER_SIZE = 16          # blocks of one size kept for reuse (a short-r
 _POOL_MAX_BYTES = 24 * 1024**3     # and in total (the Krylov workspaces have their own cache)
 
 
+class _DevicePool:
+    """
+    Released device blocks of one context, keyed by size.  A block can die on ANY host thread and at any time (the
+    garbage collector runs finalisers wherever an allocation happens to trigger it; mode groups on several streams have
+    their own host threads): ``give`` therefore only moves pointers between lists under the pool's lock and never calls
+    into HIP.  Blocks beyond the pool's budget wait in ``surplus`` and are freed by the next ``take`` / ``trim`` --
+    calls made by code that is using the context, on its thread, in stream order.
+    """
+
+    def __init__(self):
+        import threading
+
+        self.lock = threading.Lock()
+        self.free = {}      # nbytes -> [device pointers]
+        self.bytes = 0
+        self.surplus = []   # pointers to hand back to the driver
+
+    def take(self, nbytes):
+        with self.lock:
+            lst = self.free.get(nbytes)
+            ptr = lst.pop() if lst else None
+            if ptr is not None:
+                self.bytes -= nbytes
+            surplus, self.surplus = self.surplus, []
+        return ptr, surplus
+
+    def give(self, ptr, nbytes):
+        with self.lock:
+            lst = self.free.setdefault(nbytes, [])
+            # (small blocks: more of one size may be in flight at once -- hipFree stalls the stream)
+            if len(lst) < max(_POOL_KEEP_PER_SIZE, (1 << 30) // max(nbytes, 1)) and self.bytes + nbytes <= _POOL_MAX_BYTES:
+                lst.append(ptr)
+                self.bytes += nbytes
+            else:
+                self.surplus.append(ptr)
+
+    def drain(self):
+        with self.lock:
+            ptrs = [p for lst in self.free.values() for p in lst] + self.surplus
+            self.free, self.bytes, self.surplus = {}, 0, []
+        return ptrs
+
+
+def _pool_of(ctx):
+    pool = ctx.__dict__.get("_pool")
+    if pool is None:
+        pool = ctx.__dict__.setdefault("_pool", _DevicePool())   # (dict.setdefault is atomic: one pool per context)
+    return pool
+
+
 class _Buffer:
     """
     Owning device allocation.  Released blocks go to a per-context pool keyed by size and are handed out again:
     a step allocates the same n x k temporaries every time, and hipMalloc / hipFree of 256 MB blocks cost up to
-    milliseconds (hipFree also waits for the device).  Stream order makes the reuse safe: all work goes through the
-    context's one stream.
+    milliseconds (hipFree also waits for the device).  Stream order makes the reuse safe: all work of a context goes
+    through its one stream, and a block is only ever handed out again by the context it came from.
     """
 
     def __init__(self, ctx, nbytes):
         self.ctx = ctx
         self.nbytes = int(nbytes)
-        pool = ctx.__dict__.setdefault("_pool", {})
-        free = pool.get(self.nbytes)
-        if free:
-            self.ptr = free.pop()
-            ctx.__dict__["_pool_bytes"] = ctx.__dict__.get("_pool_bytes", 0) - self.nbytes
+        self.ptr, surplus = _pool_of(ctx).take(self.nbytes)
+        for p in surplus:
+            _ffi.lib().eigd_free(ctx.h, c_vp(p))
+        if self.ptr is not None:
             return
         p = c_vp()
         try:
@@ -381,18 +467,9 @@ class _Buffer:
 
     def __del__(self):
         try:
-            if getattr(self, "ptr", None) and self.ctx.h is not None:
-                pool = self.ctx.__dict__.setdefault("_pool", {})
-                free = pool.setdefault(self.nbytes, [])
-                held = self.ctx.__dict__.get("_pool_bytes", 0)
-                # (small blocks: more of one size may be in flight at once -- hipFree stalls the stream)
-                if len(free) < max(_POOL_KEEP_PER_SIZE, (1 << 30) // max(self.nbytes, 1)) \
-                        and held + self.nbytes <= _POOL_MAX_BYTES:
-                    free.append(self.ptr)
-                    self.ctx.__dict__["_pool_bytes"] = held + self.nbytes
-                else:
-                    _ffi.lib().eigd_free(self.ctx.h, c_vp(self.ptr))
-                self.ptr = None
+            ptr, self.ptr = getattr(self, "ptr", None), None
+            if ptr and self.ctx.h is not None:
+                _pool_of(self.ctx).give(ptr, self.nbytes)
         except Exception:
             pass
 

@@ -28,8 +28,11 @@ predict_finish = True      # enqueue the next cycle only for the modes not expec
 reorth_tol = 1e-13         # measured second Gram-Schmidt pass: applied where |h2| > reorth_tol |h1|
 
 # ---- the numpy-in / numpy-out surface (device.py: Context.twin_upload)
-host_twins = True          # keep the device copies of Phib and of a returned psi for the next call that is handed the same
-                           # array object (validated against a content sample of 1024 rows + first and last page)
+host_twins = "returned"    # "returned": the device block a returned psi was downloaded from is handed out again when the same
+                           # array comes back (it is returned read-only: an in-place edit raises); caller-owned arrays (Phib)
+                           # are transferred every time.  True: caller-owned arrays keep device copies too, validated against
+                           # a content sample of 1024 rows + first and last page only (an edit between sampled rows goes
+                           # unnoticed: opt-in).  False: every call transfers what it is given, results are writable
 
 # ---- restarted block Lanczos (lanczos.py)
 iram_block = 0             # block size (0: 8 for n >= 200 000, 4 for n >= 50 000, else the single-vector solver)

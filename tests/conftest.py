@@ -11,8 +11,43 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+_FAULT_LOG = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A crash below Python (an abort in a native library, a fault in a finaliser thread) must leave its stacks behind --
+    # of every thread, in a file that survives the process and whatever the output was piped through (docs/LOG.md,
+    # round 4: one abort of the GPU suite was lost behind a `tail`).  EIGD_FAULT_LOG names the file; by default it is
+    # gpurun_out/faulthandler_<pid>.log where that directory exists (the GPU box), else the system's temporary directory.
+    import faulthandler
+    import tempfile
+
+    global _FAULT_LOG
+    d = os.path.join(ROOT, "gpurun_out")
+    path = os.environ.get("EIGD_FAULT_LOG") or os.path.join(d if os.path.isdir(d) else tempfile.gettempdir(),
+                                                            f"faulthandler_{os.getpid()}.log")
+    try:
+        _FAULT_LOG = open(path, "w")
+        faulthandler.enable(file=_FAULT_LOG, all_threads=True)
+    except OSError:
+        faulthandler.enable(all_threads=True)                 # (no writable place: at least stderr)
+
+
+def pytest_unconfigure(config):
+    import faulthandler
+
+    global _FAULT_LOG
+    if _FAULT_LOG is not None:
+        faulthandler.disable()
+        path, size = _FAULT_LOG.name, _FAULT_LOG.tell()
+        _FAULT_LOG.close()
+        _FAULT_LOG = None
+        if size == 0:                                         # a clean run leaves nothing behind
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
 
 
 def load_golden(name):

@@ -34,3 +34,17 @@ def test_rendezvous_directory_must_be_private(tmp_path, monkeypatch):
     monkeypatch.setenv("EIGD_COMM_DIR", str(d))
     with pytest.raises(PermissionError):
         comm.exchange_unique_id(0, 2, lambda: b"x", tag="uid")
+
+
+def test_published_id_is_private_whatever_the_umask(tmp_path, monkeypatch):
+    """under umask 002 (the default of non-root users on RHEL-family systems) a plain open() would publish the id 0664 and
+    every other rank would reject it until its timeout: the writer sets the mode itself"""
+    monkeypatch.setenv("EIGD_COMM_DIR", str(tmp_path / "rdv"))
+    old = os.umask(0o002)
+    try:
+        assert comm.exchange_unique_id(0, 2, lambda: b"ID" * 16, tag="uid2") == b"ID" * 16
+    finally:
+        os.umask(old)
+    st = os.stat(tmp_path / "rdv" / "uid2.bin")
+    assert (st.st_mode & 0o777) == 0o600
+    assert comm.exchange_unique_id(1, 2, None, tag="uid2", timeout=5.0) == b"ID" * 16
