@@ -151,7 +151,7 @@ def measured_traffic(entry, sources):
     the rocprofv3 --pmc CSVs), valid only for the kernel sources they were taken with: a changed kernel file gives null.
     """
     rec = None
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):      # the newest round's passes first
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):      # the newest round's passes first
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))[entry]
             break
@@ -177,7 +177,7 @@ def measured_mfma(entry, sources, useful_flops, us_per_launch):
     the time the issued ones need at the matrix pipe's peak, and the fraction of the launch the pipe was busy.
     """
     rec = None
-    for name in ("r04_traffic.json",):
+    for name in ("r05_traffic.json", "r04_traffic.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))[entry]
         except (OSError, KeyError, ValueError):
@@ -546,6 +546,7 @@ def main():
     adj_count = factor.count
     last_round = dict(_adj.LAST_ROUND)              # the counters of the last timed step (later legs run more solves)
     sibk_iterations = [int(i) for i in solver.last_info]
+    args.timed_sibk_iterations = sibk_iterations
     ms_per_step = 1e3 * elapsed / args.steps
     value = N * args.steps / elapsed
 
@@ -744,9 +745,14 @@ def main():
             ctx.sync()
             t_eig0 = time.perf_counter() - t0
 
+            # (eigenvectors are determined up to their signs, and with a FIXED right-hand side block df/dx follows them:
+            # the same design derivative needs Phib's columns flipped along)
+            sg0 = np.sign(np.einsum("ij,ij->j", np.asarray(solver0.Phi), Phi))
+            dPhib0 = ctx.from_host(Phib * sg0)
+
             def step0():
-                dpsi0, data0 = solver0.solve_adjoint(dPhib, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1)
-                return dpsi0, solver0.add_total_derivative(lamb, dPhib, dpsi0, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data0,
+                dpsi0, data0 = solver0.solve_adjoint(dPhib0, method="sibk", rtol=args.rtol, update_guess=False, bs_target=1)
+                return dpsi0, solver0.add_total_derivative(lamb, dPhib0, dpsi0, dAdx, dBdx, np.zeros(ndv), adj_corr_data=data0,
                                                            deriv_type="tensor")
 
             step0()
@@ -760,8 +766,9 @@ def main():
                        "sibk_iterations": [int(i) for i in solver0.last_info], "extra_pairs_for_deflation": int(solver0.n_extra),
                        "recurrence": _adj.LAST_ROUND.get("recurrence"),
                        "dfdx_rel_diff": float(np.linalg.norm(dfdx0 - dfdx) / np.linalg.norm(dfdx)),
+                       "lam_rel_diff": float(np.max(np.abs(np.asarray(solver0.lam) - lam) / np.abs(lam))),
                        "design_point_s": None}
-            del dpsi0, solver0
+            del dpsi0, solver0, dPhib0
             log(rank, f"extra = 0 (the reference's deflation set): {extras0['ms_per_step']} ms/step, eigensolve {t_eig0:.3f}s")
         finally:
             _eg.tuning.iram_extra = keep_x
@@ -1068,7 +1075,8 @@ def cpu_baseline(args, K, G, sigma, lam, Phi, Phib, lamb, col, solver, dPhib, dp
     for q, i in enumerate(sample):                       # every sampled mode's own share of df/dx on both sides
         dg_i = adj._total_derivative_device(solver._prob.Phi, dPhib, dpsi, lam, lamb, dAdx, dBdx, np.zeros(ndv), data,
                                             "buckling", "tensor", np.asarray([i]))
-        per_mode[str(i)] = {"sibk_iterations_cpu": int(iters[q]), "sibk_iterations_gpu": int(solver.last_info[i]),
+        it_gpu = getattr(args, "timed_sibk_iterations", None)   # (of the timed step: later legs ran other solves)
+        per_mode[str(i)] = {"sibk_iterations_cpu": int(iters[q]), "sibk_iterations_gpu": int(it_gpu[i]) if it_gpu else None,
                             "psi_rel_err": float(err_psi_k[q]),
                             "dfdx_rel_err": float(np.linalg.norm(dg_i - dfdx_ck[:, q]) / np.linalg.norm(dfdx_ck[:, q]))}
     log(0, f"cpu: GPU-vs-CPU on modes {sample}: psi rel-err {err_psi:.2e}, df/dx rel-err {err_df:.2e}; per mode {per_mode}")

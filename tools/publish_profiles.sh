@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy what tools/collect_profiles.sh left under gpurun_out/<tag>/ into profiles/ and rebuild profiles/<tag>_traffic.json
 # (run here, after the gpurun call has merged gpurun_out/ back):   tools/publish_profiles.sh r03 [stats|pmc|steppmc|all]
-tag=${1:-r04}
+tag=${1:-r05}
 what=${2:-all}
 src=gpurun_out/$tag
 if [ "$what" = "stats" ] || [ "$what" = "all" ]; then
