@@ -716,6 +716,14 @@ def test_c2_natural_frequency_properties_at_full_size():
     assert res[3:].max() < 1e-7 * rn0
     assert ortho[3:].max() < 1e-7 * np.abs(psi).max()
     assert set(data.keys()) <= {0, 1, 2}                                   # only the rigid-body cluster is repeated
+    # the oracle (SuperLU + the reference's Arnoldi loop from a zero guess) at full size, for the first elastic mode and
+    # the last one: psi to the 1e-8 of north_star
+    from oracle import eigd_oracle as orc
+
+    fac_o = orc.SpLuOperator((K - sigma * M).tocsc())
+    for i in (3, N - 1):
+        psi_o, _, info_o = orc.sibk(Phib, K, M, lam, Phi, mode="normal", sigma=sigma, factor=fac_o, rtol=1e-10, modes=[i])
+        assert relerr(psi[:, i], psi_o[:, i]) < RTOL, (i, info_o, relerr(psi[:, i], psi_o[:, i]))
 
 
 def test_c4_thermal_repeated_eigenvalues_at_full_size():
@@ -747,6 +755,17 @@ def test_c4_thermal_repeated_eigenvalues_at_full_size():
     _, ortho = s.eval_adjoint_residual_norm(Phib, psi, b_ortho=False)
     assert res.max() < 1e-7 * max(np.linalg.norm(Phib, axis=0).max(), 1.0)
     assert ortho.max() < 1e-7 * max(np.abs(psi).max(), 1.0)
+    # the oracle at full size on the same eigenpairs and right-hand sides: a single mode (3) and one member of an exactly
+    # repeated pair (4; its correction along the partner divides rounding by rounding in the reference's formulas
+    # 373-383: the part of psi orthogonal to the pair is what both must agree on)
+    from oracle import eigd_oracle as orc
+
+    fac_o = orc.SpLuOperator((K - sigma * M).tocsc())
+    BPhi = M @ Phi
+    for i in (3, 4):
+        psi_o, _, info_o = orc.sibk(Phib, K, M, lam, Phi, mode="normal", sigma=sigma, factor=fac_o, rtol=1e-12, modes=[i])
+        a, b = psi[:, i] - Phi @ (BPhi.T @ psi[:, i]), psi_o[:, i] - Phi @ (BPhi.T @ psi_o[:, i])
+        assert relerr(a, b) < RTOL, (i, info_o, relerr(a, b))
 
 
 @pytest.mark.parametrize("variant", ["generalized", "standard"])
