@@ -783,6 +783,7 @@ struct LevelArgs {
   int kd;         // rows of the LDS tiles this launch was given (multiple of 8, <= 64): the longest product of the level
   int nwg;        // records of this launch
   int per_xcd;    // multi-tile launches: records per XCD (grid = 8 * per_xcd, see xcd_record); 0 = blockIdx is the record
+  double* V1;     // pre-assembled levels (PRE): the plane that holds v1 at the fronts' own rows (rows of KB columns)
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one; observed, used for speed only):
@@ -869,7 +870,10 @@ __device__ __forceinline__ bool fold_groups(const WgRec& w, const LevelArgs& la,
 // around the load would serialise the loads of a tile.
 // NSL: carry planes compiled in (2: binary trees, else kMaxS + 1); FRAG (fronts with several column tiles, MFMA widths):
 // matrix operands straight from the fragment-major copy instead of staged through LDS
-template <int KPT, bool SINGLE, int NSL, bool FRAG = false>
+// PRE (FRAG only; levels with thousands of workgroups, see v1_assemble_kernel): v1 has been written to the plane la.V1 at
+// the fronts' own rows by a launch of its own -- every row-tile workgroup of a front reads ONE contiguous 16 KB block per
+// step instead of an index round, gathered rows of the caller's block and NSL planes
+template <int KPT, bool SINGLE, int NSL, bool FRAG = false, bool PRE = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(((SINGLE && KPT >= 4) || (FRAG && KPT >= 4)) ? ((FRAG && KPT >= 8) ? kFragWavesFwd : 3) : 1)))
 void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
                                                             const double* __restrict__ Tb, const double* X, int ldx,
@@ -899,7 +903,9 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
   const int64_t vslot = fa.vrows * T::KB;  // plane size: rows of all fronts x KB (the planes of this sweep width)
   double* Vout = V + static_cast<int64_t>(w.slot) * vslot;
 
+  static_assert(!PRE || FRAG, "pre-assembled right-hand sides: the fragment path only");
   auto fetch_idx = [&](int ct) {
+    if constexpr (PRE) return;
     const int wd = min(TW, ns - ct * TW);
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
@@ -910,6 +916,16 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
     }
   };
   auto fetch_b = [&](int ct) {
+    if constexpr (PRE) {
+      const int wd = min(TW, ns - ct * TW);
+      const double* V1 = la.V1 + (vbase + ct * TW) * T::KB;
+#pragma unroll
+      for (int e = 0; e < IT; ++e) {
+        const int idx = threadIdx.x + e * kThreads;
+        bv[e] = *(((idx & (T::KB - 1)) < kb && idx / T::KB < wd) ? V1 + idx : fa.zero);
+      }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
       const int idx = threadIdx.x + e * kThreads;
@@ -1184,6 +1200,47 @@ void fwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
   if (rt >= nst) fetch_carry(rt, cg, di);  // in flight while the groups of a split chain are joined
   if (w.G > 1 && !fold_groups<KPT>(w, la, acc, reinterpret_cast<int*>(As))) return;
   store_tile(rt, acc, cg, di);
+  }
+}
+
+// v1 of one level, written once: workgroup (front, column tile ct) forms alpha X[own rows] + (p0 + p1 + ..) for the 64 rows
+// of the tile -- the expression of fetch_b above, entry by entry: bitwise what the row-tile workgroups would have formed
+// themselves -- and leaves it in the plane V1 at the front's own rows.
+template <int KPT, int NSL>
+__global__ __launch_bounds__(kThreads) void v1_assemble_kernel(FrontArrays fa, const WgRec* __restrict__ recs, const double* X,
+                                                              int ldx, double alpha, const double* V, double* V1p, int kb) {
+  using T = Tile<KPT>;
+  constexpr int IT = KPT;
+  const WgRec w = recs[blockIdx.x];
+  const int ct = w.tile;
+  const int wd = min(TW, w.ns - ct * TW);
+  const int64_t vrow0 = w.voff + ct * TW;
+  const int nslot = ((w.flags & 2) != 0) ? fa.nslot : 0;
+  const int64_t vslot = fa.vrows * T::KB;
+  int xi[IT];
+#pragma unroll
+  for (int e = 0; e < IT; ++e) {
+    const int r = (threadIdx.x + e * kThreads) / T::KB;
+    xi[e] = *((r < wd) ? fa.v_src + vrow0 + r : fa.neg1);
+  }
+  double bv[IT];
+#pragma unroll
+  for (int e = 0; e < IT; ++e) {
+    const int idx = threadIdx.x + e * kThreads;
+    const int c = idx & (T::KB - 1);
+    const bool ok = c < kb && xi[e] >= 0;
+    const double xv = alpha * *(ok ? X + static_cast<int64_t>(xi[e]) * ldx + c : fa.zero);
+    const double* cp = V + vrow0 * T::KB + idx;
+    double v = 0.0;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) v += *((ok && s < nslot) ? cp + s * vslot : fa.zero);
+    bv[e] = xv + v;
+  }
+  double* V1 = V1p + vrow0 * T::KB;
+#pragma unroll
+  for (int e = 0; e < IT; ++e) {
+    const int idx = threadIdx.x + e * kThreads;
+    if ((idx & (T::KB - 1)) < kb && xi[e] >= 0) V1[idx] = bv[e];
   }
 }
 
@@ -1935,6 +1992,10 @@ struct eigd_factor {
   std::vector<char> h_lvl_two;            // per level: every front has at most two children (two-plane kernels)
   std::vector<char> h_lvl_leaf;           // per level: no front has children (kernels without carry loads)
   std::vector<int> h_fwd_nsingle;         // per level: leading records of single-column-tile fronts (own kernel)
+  // levels whose multi-tile fronts get v1 pre-assembled (v1_assemble_kernel): one record per front and column tile
+  WgRec* d_pre_wg = nullptr;
+  std::vector<int> h_pre_ptr;             // per level: first record (none: the level's workgroups gather v1 themselves)
+  bool has_v1 = false;                    // one more plane per sweep width, behind all carry planes: receives v1
   std::vector<int> h_bwd_nsingle;         // per level: leading backward records of single-column-tile fronts
   // narrow sweeps (k <= 8): one record per single-tile front and level, the transposed copy of [T; M21]
   WgRec* d_wave_wg = nullptr;
@@ -2103,6 +2164,13 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false, bool piv
 }
 
 
+// Fewest multi-tile workgroups of a level whose right-hand sides are pre-assembled (EIGD_PRE_MIN_WG: experiments)
+int pre_assembly_min_workgroups() {
+  const char* e = std::getenv("EIGD_PRE_MIN_WG");
+  const int v = e ? std::atoi(e) : 0;
+  return v > 0 ? v : 2048;
+}
+
 // Launch policy of the sweeps (all measured on the 1 M-dof benchmark; the experiments behind each number are in
 // docs/LOG.md).  Sweeps of up to 8 columns run their single-tile fronts wave by wave (VALU, readlane broadcast); 5 to 8
 // columns otherwise go through the 16-column MFMA kernels.
@@ -2116,7 +2184,12 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
   // every sweep width (KB = 4, 8, 16, 32 columns) has its own set of carry planes: rows are KB wide and the
   // entries no child writes stay zero for good
   constexpr int KB = 4 * KPT;
-  wV += static_cast<int64_t>(f->nplanes) * f->v_rows * (KB - 4);  // 4 + 8 + ... below KB = KB - 4
+  // (the planes of pre-assembled right-hand sides lie behind the carry planes of ALL widths: with one more plane inside
+  // every width's set the thin forward kernels of the shell model ran 4 to 10 % slower -- same kernels, same bytes, other
+  // addresses)
+  const int ncarry = f->nplanes - (f->has_v1 ? 1 : 0);
+  double* const wV1 = f->has_v1 ? wV + static_cast<int64_t>(ncarry) * f->v_rows * kPlaneCols + f->v_rows * (KB - 4) : nullptr;
+  wV += static_cast<int64_t>(ncarry) * f->v_rows * (KB - 4);  // 4 + 8 + ... below KB = KB - 4
   // multi-tile levels: every XCD gets a contiguous range of the level's records (see xcd_record)
   auto level_args = [&](const WgRec* wg, int kd = TW, int nwg = 0, bool multi = false) {
     LevelArgs la;
@@ -2127,6 +2200,7 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     la.kd = kd;
     la.nwg = nwg;
     la.per_xcd = multi ? (nwg + 7) / 8 : 0;
+    la.V1 = wV1;
     return la;
   };
   auto multi_grid = [&](int nwg) { return dim3(8 * ((nwg + 7) / 8)); };
@@ -2245,7 +2319,21 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     if (nwg > nsingle) {
       const LevelArgs la = level_args(f->d_fwd_wg + f->h_fwd_ptr[l] + nsingle, TW, nwg - nsingle, true);
       if constexpr (Tile<KPT>::kMfma) {
-        if (two)
+        const int npre = f->h_pre_ptr[l + 1] - f->h_pre_ptr[l];
+        if (npre > 0) {  // v1 of the level's fronts once, then row-tile workgroups that read it as it lies
+          const WgRec* pre = f->d_pre_wg + f->h_pre_ptr[l];
+          if (two) {
+            hipLaunchKernelGGL((v1_assemble_kernel<KPT, 2>), dim3(npre), dim3(kThreads), 0, st, fa, pre, dIn, ldin, alpha, wV,
+                               wV1, kb);
+            hipLaunchKernelGGL((fwd_level_kernel<KPT, false, 2, true, true>), multi_grid(nwg - nsingle), dim3(kThreads),
+                               lds_frag, st, fa, la, f->d_Fm, sT, dIn, ldin, alpha, wV, wY);
+          } else {
+            hipLaunchKernelGGL((v1_assemble_kernel<KPT, kMaxS + 1>), dim3(npre), dim3(kThreads), 0, st, fa, pre, dIn, ldin,
+                               alpha, wV, wV1, kb);
+            hipLaunchKernelGGL((fwd_level_kernel<KPT, false, kMaxS + 1, true, true>), multi_grid(nwg - nsingle),
+                               dim3(kThreads), lds_frag, st, fa, la, f->d_Fm, sT, dIn, ldin, alpha, wV, wY);
+          }
+        } else if (two)
           hipLaunchKernelGGL((fwd_level_kernel<KPT, false, 2, true>), multi_grid(nwg - nsingle), dim3(kThreads),
                              lds_frag, st, fa, la, f->d_Fm, sT, dIn, ldin, alpha, wV, wY);
         else
@@ -2418,7 +2506,7 @@ int eigd_factor_free(eigd_factor* f) {
                   f->d_bwd_wg,    f->d_tri_pref,    f->d_m_pref,     f->d_ov_dst,   f->d_ov_ptr, f->d_ov_src,
                   f->d_toff,      f->d_T,           f->d_sgn,        f->d_aux,      f->d_bout,  f->d_tickets,
                   f->d_P,         f->d_wave_wg,     f->d_ftoff,      f->d_tr_pref,  f->d_Ft,  f->d_Fb,
-                  f->d_Fm,        f->d_Bm,          f->d_ff,         f->d_mt_pref,  f->d_red};
+                  f->d_Fm,        f->d_Bm,          f->d_ff,         f->d_mt_pref,  f->d_red,   f->d_pre_wg};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;
@@ -2480,7 +2568,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   const bool surplus = maxchild > kMaxS;
   const int ndirect = std::min(maxchild, kMaxS);
   const int nslot = ndirect + (surplus ? 1 : 0);
-  const int nplanes = std::max(1, nslot + (surplus ? 1 : 0));
+  int nplanes = std::max(1, nslot + (surplus ? 1 : 0));   // (+ 1 below: the plane of pre-assembled right-hand sides)
   struct Extra { int level; int dst; std::vector<int> src; };
   std::vector<Extra> extras;
   if (surplus) {
@@ -2573,10 +2661,13 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     }
   };
   std::vector<int> h_fwd_nsingle(static_cast<size_t>(s.nlevels), 0), h_bwd_nsingle(static_cast<size_t>(s.nlevels), 0);
+  std::vector<WgRec> pre_wg;
+  std::vector<int> h_pre_ptr(static_cast<size_t>(s.nlevels) + 1, 0);
+  const int pre_min_wg = pre_assembly_min_workgroups();
   std::vector<WgRec> wave_wg;
   std::vector<int> h_wave_ptr(static_cast<size_t>(s.nlevels) + 1, 0);
   for (int l = 0; l < s.nlevels; ++l) {
-    std::vector<WgRec> multi, bmulti;
+    std::vector<WgRec> multi, bmulti, pre_lvl;
     const int nfl = s.lvl_ptr[l + 1] - s.lvl_ptr[l];
     const bool sparse_level = nfl < 256;  // few fronts: parallelism has to come from inside the fronts
     const bool split_level = nfl <= split_nfl;   // the join of split chains costs an agent-scope acquire: only where chains are long
@@ -2611,6 +2702,16 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
       } else {
         for (int t = nst + nbt - 1; t >= 0; --t)  // border tiles (nst products) first, then the own tiles, longest first
           push_chain(multi, fwd_slabs, fr, t, t < nst ? t + 1 : nst, split_level, kids, false);
+        for (int t = 0; t < nst; ++t) {
+          WgRec w;
+          front_numbers(w, fr);
+          w.tile = t;
+          w.s0 = w.s1 = 0;
+          w.slab = w.cnt = 0;
+          w.G = 1;
+          w.flags = kids;
+          pre_lvl.push_back(w);
+        }
       }
       const int nbt_b = (s.f_parent[fr] >= 0) ? nbt : 0;
       for (int t = 0; t < nst; ++t)
@@ -2624,9 +2725,16 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     h_wave_ptr[l + 1] = static_cast<int>(wave_wg.size());
     fwd_wg.insert(fwd_wg.end(), multi.begin(), multi.end());
     h_fwd_ptr[l + 1] = static_cast<int>(fwd_wg.size());
+    // v1 written once per level where the row-tile workgroups that would each gather it are thousands (the shell model's
+    // levels of 4000 to 14000; measured a loss where a level has fewer: the launch costs more than the rounds it saves)
+    if (static_cast<int>(multi.size()) >= pre_min_wg)
+      pre_wg.insert(pre_wg.end(), pre_lvl.begin(), pre_lvl.end());
+    h_pre_ptr[l + 1] = static_cast<int>(pre_wg.size());
     h_bwd_ptr[l + 1] = static_cast<int>(bwd_wg.size());
   }
   const int64_t n_slabs = std::max<int64_t>(1, std::max(fwd_slabs, bwd_slabs));
+  const bool has_v1 = !pre_wg.empty();
+  if (has_v1) nplanes += 1;
   // rows of the caller's block behind every border entry (backward sweep gathers x there)
   std::vector<int> bout(s.border.size());
   for (size_t e = 0; e < s.border.size(); ++e) bout[e] = s.perm[s.border[e]];
@@ -2645,6 +2753,8 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   f->sym = &h->s;
   f->h_fwd_ptr = h_fwd_ptr;
   f->h_fwd_nsingle = h_fwd_nsingle;
+  f->h_pre_ptr = h_pre_ptr;
+  f->has_v1 = has_v1;
   f->h_lvl_leaf.assign(static_cast<size_t>(s.nlevels), 1);
   for (int q = 0; q < nf; ++q)
     if (nchild[q] > 0) f->h_lvl_leaf[s.f_level[q]] = 0;
@@ -2728,6 +2838,7 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   UP(d_fwd_wg, fwd_wg)
   UP(d_bwd_wg, bwd_wg)
   UP(d_wave_wg, wave_wg)
+  UP(d_pre_wg, pre_wg)
   UP(d_ftoff, ftoff)
   UP(d_tr_pref, tr_pref)
   UP(d_mt_pref, mt_pref)
@@ -2926,10 +3037,10 @@ int eigd_factor_lane_solve_to(eigd_lane* l, const double* dIn, int ldin, double*
 
 int eigd_factor_stats(eigd_factor* f, double* out, int nout) {
   EIGD_REQUIRE(f && out && nout >= 1, "null argument");
-  const double v[6] = {static_cast<double>(f->sym->nnzL), static_cast<double>(f->bytes), f->sym->flops,
+  const double v[7] = {static_cast<double>(f->sym->nnzL), static_cast<double>(f->bytes), f->sym->flops,
                        static_cast<double>(f->sym->nfronts), static_cast<double>(f->n_negative),
-                       static_cast<double>(f->n_perturbed)};
-  for (int i = 0; i < nout && i < 6; ++i) out[i] = v[i];
+                       static_cast<double>(f->n_perturbed), static_cast<double>(f->nplanes)};
+  for (int i = 0; i < nout && i < 7; ++i) out[i] = v[i];
   return EIGD_OK;
 }
 

@@ -1154,10 +1154,10 @@ class Factor:
         return lanes[key][0]
 
     def stats(self):
-        out = np.zeros(6)
-        call("eigd_factor_stats", self.h, hptr(out), 6)
+        out = np.zeros(7)
+        call("eigd_factor_stats", self.h, hptr(out), 7)
         return {"nnzL": int(out[0]), "device_bytes": int(out[1]), "flops": float(out[2]), "nfronts": int(out[3]),
-                "negative_pivots": int(out[4]), "static_pivots": int(out[5])}
+                "negative_pivots": int(out[4]), "static_pivots": int(out[5]), "workspace_planes": int(out[6])}
 
     def solve_bytes(self, k):
         b = C.c_double()

@@ -6,7 +6,8 @@ changes what is computed beyond rounding -- they select between equivalent forms
 Environment variables the package reads (all optional): EIGD_DEVICE (device of the default context, else LOCAL_RANK),
 EIGD_STREAMS (concurrent mode groups of the lock-step solvers, default 1), EIGD_COMM_DIR / EIGD_COMM_INIT_TIMEOUT
 (rendezvous directory and watchdog of the RCCL communicator), EIGD_TRACE_IRAM (restart log of the block eigensolver);
-bench.py adds EIGD_LAUNCH_TIMEOUT.
+bench.py adds EIGD_LAUNCH_TIMEOUT.  The library itself reads EIGD_PRE_MIN_WG when a factor is created (fewest row-tile
+workgroups of a tree level whose right-hand sides are written once per level, default 2048; csrc/factor.hip).
 """
 
 # ---- sibk, lock-step form (adjoint.py)

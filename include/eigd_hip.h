@@ -133,7 +133,9 @@ int eigd_factor_lane_create(eigd_factor* f, eigd_ctx* ctx, eigd_lane** out);
 int eigd_factor_lane_free(eigd_lane* lane);
 int eigd_factor_lane_solve_to(eigd_lane* lane, const double* dIn, int ldin, double* dOut, int ldout, int k, double alpha);
 /* stats: [0]=nnz(L) [1]=device bytes held [2]=flops of the numeric factorisation [3]=number of fronts
-          [4]=negative pivots of P M P^T = L S L^T (inertia: eigenvalues of the pencil below the shift; 0 = SPD) */
+          [4]=negative pivots of P M P^T = L S L^T (inertia: eigenvalues of the pencil below the shift; 0 = SPD)
+          [5]=static pivots [6]=planes of the sweeps' vector workspace (carry planes, + 1 where the right-hand sides of
+          levels with thousands of workgroups are pre-assembled) */
 int eigd_factor_stats(eigd_factor* f, double* out, int nout);
 /* bytes of L streamed by one k-column solve (algorithmic, for the roofline) */
 int eigd_factor_solve_bytes(eigd_factor* f, int k, double* bytes);

@@ -972,3 +972,63 @@ def test_multi_tile_fronts_with_ragged_sizes_through_the_fragment_kernels(ctx):
     assert relerr(op(B), splu(Ai.tocsc()).solve(B)) < 1e-8
     Xn = op.factor.solve_inplace(ctx.from_host(B[:, 4:9])).get()
     assert np.array_equal(Xi[:, 4:9], Xn)
+
+
+def hub_star_matrix(nb, g, hub, seed=0):
+    """nb grid blocks coupled only through a dense hub of `hub` nodes: a multi-tile front with dozens of children"""
+    rng = np.random.default_rng(seed)
+    blocks = [grid_matrix(g, g, 1, seed=i) for i in range(nb)]
+    H = sparse.csr_matrix(np.full((hub, hub), 0.01) + np.eye(hub) * 50.0)
+    A = sparse.block_diag(blocks + [H]).tolil()
+    n0, ntot = g * g, nb * g * g + hub
+    for b in range(nb):
+        for h in range(hub):
+            for _ in range(2):
+                i = b * n0 + rng.integers(n0)
+                A[i, ntot - hub + h] = A[ntot - hub + h, i] = 0.3
+    A = A.tocsr()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("case", ["binary", "many_children"])
+def test_pre_assembled_right_hand_sides_are_bitwise_what_the_row_tile_workgroups_gather(ctx, monkeypatch, case):
+    """
+    Levels with thousands of multi-tile workgroups (the shell model) get v1 = alpha x + carries written once per level
+    (v1_assemble_kernel) and row-tile workgroups that read it as it lies; EIGD_PRE_MIN_WG = 1 switches that on for every
+    multi-tile level of a small factor: every MFMA width bitwise against the factor whose workgroups gather v1 themselves,
+    sweeps of other widths in between (the planes keep what a wider sweep left in the columns a narrower one does not use),
+    fronts with two children and with dozens (surplus planes), Cholesky and Bunch-Kaufman.
+    """
+    from eigd_amd.device import Factor, Symbolic
+
+    if case == "binary":
+        A = lap3d(23)
+        sym = Symbolic(A, leaf_size=24)
+    else:
+        A = hub_star_matrix(6, 10, 70)
+        sym = Symbolic(A, leaf_size=16, panel_width=8)
+        ns, parent = sym.array("f_ns"), sym.array("f_parent")
+        nchild = np.bincount(parent[parent >= 0], minlength=len(ns))
+        assert ((ns > 64) & (nchild > 4)).any()
+    assert (sym.array("f_ns") > 64).any()
+    rng = np.random.default_rng(5)
+    B = rng.normal(size=(A.shape[0], 32))
+    for shift in (0.0, None):
+        if shift is None:                                # well inside the spectrum: dense diagonal blocks, 2 x 2 pivots
+            ev = np.sort(np.linalg.eigvalsh(A[:300, :300].toarray()))
+            Ai = (A - 0.5 * (ev[150] + ev[151]) * sparse.identity(A.shape[0])).tocsr()
+        else:
+            Ai = A
+        monkeypatch.delenv("EIGD_PRE_MIN_WG", raising=False)
+        F0 = Factor(ctx, Ai, symbolic=sym)
+        monkeypatch.setenv("EIGD_PRE_MIN_WG", "1")
+        F1 = Factor(ctx, Ai, symbolic=sym)
+        assert F1.stats()["workspace_planes"] == F0.stats()["workspace_planes"] + 1
+        assert (F0.stats()["negative_pivots"] > 20) == (shift is None)
+        for lo, hi in ((0, 32), (3, 23), (0, 16), (7, 12), (0, 32), (1, 2)):
+            X0 = F0.solve_inplace(ctx.from_host(B[:, lo:hi])).get()
+            X1 = F1.solve_inplace(ctx.from_host(B[:, lo:hi])).get()
+            assert np.array_equal(X0, X1), (case, shift, lo, hi)
+        if shift == 0.0:
+            assert relerr(X1, splu(Ai.tocsc()).solve(B[:, 1:2])) < 1e-11
