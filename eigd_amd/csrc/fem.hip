@@ -11,6 +11,7 @@
 // segments, the per-element sum is a fixed shuffle tree (deterministic).
 #include <algorithm>
 #include <cstdint>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -45,20 +46,33 @@ __global__ __launch_bounds__(kThreads) void elem_bilinear_kernel(int nelem, int 
     v[a] = *((dofs[a] >= 0) ? V + static_cast<int64_t>(dofs[a]) * ldv + c : &g_zero_fem);
   }
   double s = 0.0;
-  if (valid) {
-    // per_elem 0: one shared matrix; 1: a matrix per element; 2: a matrix per element TYPE (etype[e])
-    const int64_t which = (per_elem == 1) ? el : (per_elem == 2 ? etype[el] : 0);
-    const double* M = Me + which * nd * nd;
+  // per_elem 0: one shared matrix; 1: a matrix per element; 2: a matrix per element TYPE (etype[e]).
+  // The shared matrix sits at wave-uniform addresses (kernel argument + constant offset when nd == ND): scalar loads.
+  // Through a lane-dependent pointer its nd^2 entries were nd^2 vector loads per lane next to the 2 nd gathers that do
+  // the work -- the address path of the CU, not HBM, set the pace (600 us per call at 1 M dofs and 32 columns).  Same
+  // products in the same order: the same bits.
+  auto form = [&](const double* __restrict__ M, auto full) {
+    constexpr bool kFull = decltype(full)::value;  // nd == ND: no bounds inside the loops
 #pragma unroll
     for (int a = 0; a < ND; ++a) {
-      if (a < nd) {
+      if (kFull || a < nd) {
         double t = 0.0;
 #pragma unroll
         for (int b = 0; b < ND; ++b)
-          if (b < nd) t += M[a * nd + b] * v[b];
+          if (kFull || b < nd) t += M[a * (kFull ? ND : nd) + b] * v[b];
         s += w[a] * t;
       }
     }
+  };
+  if (per_elem == 0) {
+    if (nd == ND)
+      form(Me, std::true_type{});
+    else
+      form(Me, std::false_type{});
+    if (!valid) s = 0.0;
+  } else if (valid) {
+    const int64_t which = (per_elem == 1) ? el : etype[el];
+    form(Me + which * nd * nd, std::false_type{});
   }
 #pragma unroll
   for (int off = KP / 2; off > 0; off >>= 1) s += __shfl_down(s, off, KP);
