@@ -1249,8 +1249,12 @@ __global__ __launch_bounds__(kThreads) void v1_assemble_kernel(FrontArrays fa, c
 // y = S z from the forward sweep (Y); x_border are rows of the caller's block Out that the ancestors' launches
 // have already written (bout = their row numbers).  The solution goes straight to Out.
 // SINGLE: fronts with one column tile, LDS tiles of la.kd rows; FRAG: as in the forward kernel (Ft = the copy Bm then)
-template <int KPT, bool SINGLE, bool FRAG = false>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FRAG ? (KPT >= 8 ? kFragWavesBwd32 : kFragWaves) : 1)))
+// LIDX (FRAG, 32 columns): the front's border rows in the caller's block (bout) are read ONCE into LDS behind the vector
+// block instead of eight index registers per lane requested two chain steps ahead: 170 -> under 168 registers, the third
+// wave per SIMD without spills (levels whose longest border fits kLidxMax entries: 25 + 16 KB of LDS, three workgroups per CU)
+constexpr int kLidxMax = 4096;
+template <int KPT, bool SINGLE, bool FRAG = false, bool LIDX = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FRAG ? (KPT >= 8 ? (LIDX ? 3 : kFragWavesBwd32) : kFragWaves) : 1)))
 void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
                                                             const double* __restrict__ Tb, const double* __restrict__ Ft,
                                                             const double* __restrict__ Y, double* Out, int ldo) {
@@ -1346,6 +1350,8 @@ void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
     const int nko = (ns - TW * (nst - 1) + 3) >> 2;  // K-steps of the last own tile
     const double* Am = Ft + w.moff + wave * 64 + lane;
     int frag_rows = 0;
+    static_assert(!LIDX || FRAG, "index list in LDS: the fragment path only");
+    int* const Is = reinterpret_cast<int*>(Bs + (TW + 1) * T::BLD);  // LIDX: bout of this front, behind the vector block
     auto fetch_vec = [&](int t) {
       const bool border = t >= nown;
       const int rbase = border ? ns + (t - nown) * TW : (ct + t) * TW;
@@ -1357,6 +1363,19 @@ void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
           const int idx = threadIdx.x + e * kThreads;
           const int r = idx / T::KB, c = idx & (T::KB - 1);
           bv[e] = *((r < rows && c < kb) ? Yp + static_cast<int64_t>(r) * kb + c : fa.zero);
+        }
+      } else if constexpr (LIDX) {
+        const int b0 = (t - nown) * TW;
+        int rr[IT];
+#pragma unroll
+        for (int e = 0; e < IT; ++e) {
+          const int r = (threadIdx.x + e * kThreads) / T::KB;
+          rr[e] = (r < rows) ? Is[b0 + r] : -1;
+        }
+#pragma unroll
+        for (int e = 0; e < IT; ++e) {
+          const int c = (threadIdx.x + e * kThreads) & (T::KB - 1);
+          bv[e] = -*((rr[e] >= 0 && c < kb) ? Out + static_cast<int64_t>(rr[e]) * ldo + c : fa.zero);
         }
       } else {
 #pragma unroll
@@ -1393,7 +1412,7 @@ void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
       if (t + 1 < w.s1) {
         fetch_vec(t + 1);
         fetch_frag(t + 1, nxt);
-        if (t + 2 < w.s1) fetch_idx(t + 2);
+        if (!LIDX && t + 2 < w.s1) fetch_idx(t + 2);
       }
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
@@ -1408,9 +1427,29 @@ void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F
     };
     double a0[16], a1[16];
     fetch_frag(w.s0, a0);
-    fetch_idx(w.s0);
-    fetch_vec(w.s0);
-    if (w.s0 + 1 < w.s1) fetch_idx(w.s0 + 1);
+    if constexpr (LIDX) {
+      // the front's border rows: requested with the first fragments; in LDS before the first border tile is fetched (a
+      // chain that starts with its own tiles publishes them with the barrier of its first step)
+      constexpr int NI = 8;          // entries per lane and round: 2048 per workgroup, their loads in flight together
+      int ib[NI];
+      const bool any = w.s1 > nown;  // (uniform) the chain meets border tiles
+#pragma unroll
+      for (int q = 0; q < NI; ++q) ib[q] = *((any && threadIdx.x + q * kThreads < bs) ? bout + threadIdx.x + q * kThreads : fa.neg1);
+      if (w.s0 < nown) fetch_vec(w.s0);
+#pragma unroll
+      for (int q = 0; q < NI; ++q)
+        if (any && threadIdx.x + q * kThreads < bs) Is[threadIdx.x + q * kThreads] = ib[q];
+      if (any)
+        for (int i = NI * kThreads + threadIdx.x; i < bs; i += kThreads) Is[i] = bout[i];  // (borders beyond 2048 rows)
+      if (w.s0 >= nown) {
+        __syncthreads();
+        fetch_vec(w.s0);
+      }
+    } else {
+      fetch_idx(w.s0);
+      fetch_vec(w.s0);
+      if (w.s0 + 1 < w.s1) fetch_idx(w.s0 + 1);
+    }
     for (int t = w.s0; t < w.s1; t += 2) {
       stepb(t, a0, a1);
       if (t + 1 < w.s1) stepb(t + 1, a1, a0);
@@ -1997,6 +2036,7 @@ struct eigd_factor {
   std::vector<int> h_pre_ptr;             // per level: first record (none: the level's workgroups gather v1 themselves)
   bool has_v1 = false;                    // one more plane per sweep width, behind all carry planes: receives v1
   std::vector<int> h_bwd_nsingle;         // per level: leading backward records of single-column-tile fronts
+  std::vector<int> h_bwd_mxbs;            // per level: the longest border among the fronts with several column tiles
   // narrow sweeps (k <= 8): one record per single-tile front and level, the transposed copy of [T; M21]
   WgRec* d_wave_wg = nullptr;
   std::vector<int> h_wave_ptr;
@@ -2361,9 +2401,15 @@ int sweep(eigd_factor* f, hipStream_t st, double* wV, double* wY, double* wP, in
     if constexpr (KPT >= 4) thin = !narrow && nwave > 0 && f->h_thin_bwd[l] > 0;
     if (nwg > nsb) {  // fronts with several column tiles: full 64-row tiles
       const LevelArgs la = level_args(f->d_bwd_wg + f->h_bwd_ptr[l] + nsb, TW, nwg - nsb, true);
-      if constexpr (Tile<KPT>::kMfma)
-        hipLaunchKernelGGL((bwd_level_kernel<KPT, false, true>), multi_grid(nwg - nsb), dim3(kThreads), lds_frag, st, fa, la,
-                           sF, sT, f->d_Bm, wY, dX, ldx);
+      if constexpr (Tile<KPT>::kMfma) {
+        if (KPT >= 8 && f->h_bwd_mxbs[l] <= kLidxMax)
+          hipLaunchKernelGGL((bwd_level_kernel<KPT, false, true, (KPT >= 8)>), multi_grid(nwg - nsb), dim3(kThreads),
+                             lds_frag + 4u * static_cast<unsigned>((f->h_bwd_mxbs[l] + 3) & ~3), st, fa, la, sF, sT, f->d_Bm,
+                             wY, dX, ldx);
+        else
+          hipLaunchKernelGGL((bwd_level_kernel<KPT, false, true>), multi_grid(nwg - nsb), dim3(kThreads), lds_frag, st, fa,
+                             la, sF, sT, f->d_Bm, wY, dX, ldx);
+      }
       else
         hipLaunchKernelGGL((bwd_level_kernel<KPT, false>), multi_grid(nwg - nsb), dim3(kThreads), lds_bytes(TW), st, fa, la, sF,
                            sT, f->d_Ft, wY, dX, ldx);
@@ -2762,6 +2808,10 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   for (int q = 0; q < nf; ++q)
     if (nchild[q] > 2) f->h_lvl_two[s.f_level[q]] = 0;
   f->h_bwd_nsingle = h_bwd_nsingle;
+  f->h_bwd_mxbs.assign(static_cast<size_t>(s.nlevels), 0);
+  for (int q = 0; q < nf; ++q)
+    if (s.f_ns[q] > TW && s.f_parent[q] >= 0)
+      f->h_bwd_mxbs[s.f_level[q]] = std::max<int>(f->h_bwd_mxbs[s.f_level[q]], s.f_bs[q]);
   f->h_fwd_kd.assign(static_cast<size_t>(s.nlevels), 8);
   f->h_bwd_kd.assign(static_cast<size_t>(s.nlevels), 8);
   {

@@ -414,11 +414,11 @@ def lap3d(m):
     return A
 
 
-def hub_matrix(nx, ny, hub, seed=0):
+def hub_matrix(nx, ny, hub, seed=0, density=0.6):
     """a 2-D grid whose every node is coupled to most of a dense hub block: thin fronts with borders of several hundred rows"""
     rng = np.random.default_rng(seed)
     A = grid_matrix(nx, ny, 1, seed=seed)
-    C = sparse.random(A.shape[0], hub, density=0.6, random_state=seed, data_rvs=lambda k: rng.uniform(-0.01, 0.01, k))
+    C = sparse.random(A.shape[0], hub, density=density, random_state=seed, data_rvs=lambda k: rng.uniform(-0.01, 0.01, k))
     M = sparse.bmat([[A, C], [C.T, sparse.identity(hub) * 5.0]]).tocsr()
     M.sort_indices()
     return M
@@ -1032,3 +1032,28 @@ def test_pre_assembled_right_hand_sides_are_bitwise_what_the_row_tile_workgroups
             assert np.array_equal(X0, X1), (case, shift, lo, hi)
         if shift == 0.0:
             assert relerr(X1, splu(Ai.tocsc()).solve(B[:, 1:2])) < 1e-11
+
+
+def test_long_borders_of_multi_tile_fronts_through_the_index_list_in_lds(ctx):
+    """
+    The 32-column backward level kernel keeps a front's border rows (its rows of the caller's block) in LDS, read once
+    -- 2048 entries in one round, the rest in a loop, up to 4096 -- where the narrower kernels hold eight of them per
+    lane in registers, requested two chain steps ahead.  A front with several column tiles and a border of 3226 rows:
+    32 columns against the residual, and bitwise against the 16-column kernels on the same columns.
+    """
+    from eigd_amd.device import Factor, Symbolic
+
+    A = hub_matrix(72, 72, 2200, density=0.3)
+    sym = Symbolic(A, leaf_size=24)
+    ns, bs, parent = sym.array("f_ns"), sym.array("f_bs"), sym.array("f_parent")
+    multi = (ns > 64) & (parent >= 0)
+    assert ((bs[multi] > 2048) & (bs[multi] <= 4096)).any()
+    F = Factor(ctx, A, symbolic=sym)
+    rng = np.random.default_rng(9)
+    B = rng.normal(size=(A.shape[0], 32))
+    for _ in range(2):
+        X = F.solve_inplace(ctx.from_host(B)).get()
+        assert np.linalg.norm(A @ X - B) / np.linalg.norm(B) < 1e-12
+    for lo, hi in ((0, 16), (5, 21), (20, 29)):
+        Xp = F.solve_inplace(ctx.from_host(B[:, lo:hi])).get()
+        assert np.array_equal(X[:, lo:hi], Xp), (lo, hi)
