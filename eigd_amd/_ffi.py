@@ -76,6 +76,7 @@ _SIGNATURES = {
     "eigd_factor_solve_bytes": [c_vp, c_int, P(c_dbl)],
     "eigd_gemm_tn": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_int, c_vp],
     "eigd_gemm_nn": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_dbl, c_dbl],
+    "eigd_panels_times": [c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_int],
     "eigd_project": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int],
     "eigd_project_norm2": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_dbl, c_dbl],
     "eigd_project_stats": [c_vp, c_vp],

@@ -549,8 +549,12 @@ def _laa_relation_device(prob, Vpan, c, p, T, C_last, dPhib, lam, sigma, Y, thet
     if cols is not None:
         Cf = Cf[:, cols]
     psi = prob.ctx.empty(prob.n, Cf.shape[1])
-    Vpan.times_into(psi, T @ Cf, ns=c, alpha=-1.0, beta=0.0)
-    Vpan.times_into(psi, C_last @ Cf[c - p:c], ns=p, alpha=-1.0, beta=1.0, j0=c)
+    if c + p <= 192 and hasattr(Vpan, "times_panels"):
+        # one pass over the panels for both terms: [V | Q] [T Cf; C_last Cf_last]
+        Vpan.times_panels(psi, -np.vstack([T @ Cf, C_last @ Cf[c - p:c]]), c + p)
+    else:
+        Vpan.times_into(psi, T @ Cf, ns=c, alpha=-1.0, beta=0.0)
+        Vpan.times_into(psi, C_last @ Cf[c - p:c], ns=p, alpha=-1.0, beta=1.0, j0=c)
     return psi
 
 

@@ -794,6 +794,95 @@ __global__ __launch_bounds__(kThreads) void gemm_nn_direct_kernel(int n, int ku,
   }
 }
 
+// Out(:, o0 .. o0 + kx) = sum_p U_p C_p for a basis kept as row-major PANELS of 64 columns (U_p at U + p * pstride, leading
+// dimension 64): the restart of the block Lanczos, V <- V S with 168 columns in and 130 out, and V (T Cf) of the first
+// guess.  Panel by panel through gemm_nn_direct_kernel that was np launches per 64 output columns, each re-reading and
+// re-writing the output (13.5 GB per restart matrix); here the coefficient rows of ALL panels sit in LDS (up to 3 x 64 rows
+// of up to 80 + 16 columns: 147 KB, one workgroup of eight waves per CU: 144 registers), a wave streams 16-row groups -- the lane's 16
+// consecutive columns of a panel row as 16-byte loads, the next panel's in flight while this one multiplies -- and writes
+// the finished rows once: np panels read + kx columns written per launch.  Fragment layout and K order as in
+// gemm_nn_direct_kernel<16> (K-step q of a panel multiplies its columns {q, 16 + q, 32 + q, 48 + q}); the sum runs over
+// the panels in order.  Output column j lies in panel j / opw of Out (panels ostride apart, rows of `old` doubles: the
+// layout of U with opw = old = 64, a plain row-major block with opw >= kx).
+constexpr int kPanelW = 64, kPanelsMax = 3, kPanelOutMax = 80, kPanelThreads = 512;
+
+template <int NP>
+__global__ __launch_bounds__(kPanelThreads) void gemm_nn_panels_kernel(int n, int ku, int kx, const double* __restrict__ U,
+                                                                       int64_t pstride, const double* __restrict__ C, int ldc,
+                                                                       int c0, double* __restrict__ Out, int64_t ostride,
+                                                                       int o0, int opw, int old) {
+  extern __shared__ double Cs[];  // NP x 64 slots x cld
+  const int tid = threadIdx.x;
+  const int cld = kx + 16;
+  // slot 4 q + g of panel p holds row 64 p + 16 g + q of C (rows past ku: zeros -- the columns of the last panel beyond
+  // the basis may hold anything, their fragments are masked below as well)
+  for (int e = tid; e < NP * kPanelW * cld; e += kPanelThreads) {
+    const int slot = e / cld, b = e - slot * cld;
+    const int p = slot >> 6, sl = slot & 63;
+    const int k = kPanelW * p + 16 * (sl & 3) + (sl >> 2);
+    Cs[e] = (k < ku && b < kx) ? C[static_cast<int64_t>(k) * ldc + c0 + b] : 0.0;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ntb = (kx + 15) >> 4;  // <= 5
+  const int64_t ngroups = (static_cast<int64_t>(n) + 15) / 16;
+  const int64_t gstride = static_cast<int64_t>(gridDim.x) * (kPanelThreads / 64);
+  auto fetch = [&](int p, int64_t base, int rows, double (&a)[16]) {
+    const double* up = U + p * pstride + (base + li) * kPanelW + 16 * lk;
+    const int left = ku - (kPanelW * p + 16 * lk);  // columns of this lane's piece that belong to the basis
+    if (li < rows && left >= 16) {
+      const double2_t* vp = reinterpret_cast<const double2_t*>(up);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const double2_t v = vp[q];
+        a[2 * q] = v.x;
+        a[2 * q + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a[q] = *((li < rows && q < left) ? up + q : &g_zero_word);
+    }
+  };
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * (kPanelThreads / 64) + wave; g < ngroups; g += gstride) {
+    const int64_t base = g * 16;
+    const int rows = static_cast<int>((n - base) < 16 ? (n - base) : 16);
+    double4_t acc[5];
+#pragma unroll
+    for (int tb = 0; tb < 5; ++tb) acc[tb] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double a0[16], a1[16];
+    fetch(0, base, rows, a0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      double(&cur)[16] = (p & 1) ? a1 : a0;
+      double(&nxt)[16] = (p & 1) ? a0 : a1;
+      if (p + 1 < NP) fetch(p + 1, base, rows, nxt);
+      // (K-steps outside, output tiles inside: consecutive MFMAs write different accumulators -- no wave waits for its own
+      // previous product; the columns of Cs past kx are the 16 spare ones of the row stride: finite, never stored)
+      const double* Cp = Cs + p * kPanelW * cld + lk * cld + li;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+#pragma unroll
+        for (int tb = 0; tb < 5; ++tb)
+          if (tb < ntb) acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[q], Cp[4 * q * cld + tb * 16], acc[tb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int tb = 0; tb < 5; ++tb) {
+      if (tb < ntb) {
+        const int b = tb * 16 + li;
+        const int j = o0 + b, jp = j / opw;  // (output panels of opw columns, rows of `old` doubles: a plain block has one)
+        double* op = Out + jp * ostride + (j - jp * opw);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int r = lk + 4 * reg;  // f64 MFMA result map: row = (l>>4) + 4*reg, col = l&15
+          if (r < rows && b < kx) op[(base + r) * old] = acc[tb][reg];
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void gemm_nn_kernel(int n, int ku, int kx, const double* __restrict__ U,
                                                           int64_t rsu, int64_t csu, const double* __restrict__ C,
                                                           double* __restrict__ X, int ldx, double alpha, double beta) {
@@ -1051,6 +1140,53 @@ int eigd_gemm_nn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t
   EIGD_HIP(hipMemcpyAsync(ctx->coef, hC, sizeof(double) * ku * kx, hipMemcpyHostToDevice, ctx->stream));
   EIGD_HIP(hipStreamSynchronize(ctx->stream));
   return gemm_nn_device(ctx, n, ku, kx, dU, rsu, csu, ctx->coef, dX, ldx, alpha, beta);
+}
+
+int eigd_panels_times(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t pstride, const double* hC,
+                      double* dOut, int64_t ostride, int opw, int ldo) {
+  EIGD_REQUIRE(ctx && dU && hC && dOut, "null argument");
+  EIGD_REQUIRE(n > 0 && ku >= 1 && ku <= kPanelsMax * kPanelW && kx >= 1 && pstride >= static_cast<int64_t>(n) * kPanelW &&
+                   opw >= 1 && ldo >= std::min(opw, kx) && (kx <= opw || ostride >= static_cast<int64_t>(n) * ldo),
+               "bad shape n=%d ku=%d kx=%d opw=%d ldo=%d (at most %d basis columns per call)", n, ku, kx, opw, ldo,
+               kPanelsMax * kPanelW);
+  {
+    const int nop = (kx + opw - 1) / opw;
+    const double* oend = dOut + static_cast<int64_t>(nop - 1) * ostride + static_cast<int64_t>(n) * ldo;
+    EIGD_REQUIRE(oend <= dU || dU + ((ku + kPanelW - 1) / kPanelW) * pstride <= dOut, "the result must not overlap the basis");
+  }
+  int rc = ctx->ensure_coef(sizeof(double) * static_cast<size_t>(ku) * kx);
+  if (rc) return rc;
+  EIGD_HIP(hipMemcpyAsync(ctx->coef, hC, sizeof(double) * static_cast<size_t>(ku) * kx, hipMemcpyHostToDevice, ctx->stream));
+  EIGD_HIP(hipStreamSynchronize(ctx->stream));  // (hC is the caller's pageable memory)
+  const int np = (ku + kPanelW - 1) / kPanelW;
+  // output columns in nearly equal chunks of at most kPanelOutMax, multiples of 2 wide (every chunk re-reads the basis)
+  const int nchunk = (kx + kPanelOutMax - 1) / kPanelOutMax;
+  const int wch = (((kx + nchunk - 1) / nchunk) + 1) & ~1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int cap = static_cast<int>(sizeof(double) * kPanelsMax * kPanelW * (kPanelOutMax + 16));
+    EIGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nn_panels_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    EIGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nn_panels_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    EIGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nn_panels_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    attr_set = true;
+  }
+  const int64_t ngroups = (static_cast<int64_t>(n) + 15) / 16;
+  const int nb = static_cast<int>(std::min<int64_t>(ctx->n_cu, (ngroups + kPanelThreads / 64 - 1) / (kPanelThreads / 64)));
+  for (int o0 = 0; o0 < kx; o0 += wch) {
+    const int kc = std::min(wch, kx - o0);
+    const size_t lds = sizeof(double) * np * kPanelW * (kc + 16);
+    if (np == 1)
+      hipLaunchKernelGGL(gemm_nn_panels_kernel<1>, dim3(nb), dim3(kPanelThreads), lds, ctx->stream, n, ku, kc, dU, pstride,
+                         ctx->coef, kx, o0, dOut, ostride, o0, opw, ldo);
+    else if (np == 2)
+      hipLaunchKernelGGL(gemm_nn_panels_kernel<2>, dim3(nb), dim3(kPanelThreads), lds, ctx->stream, n, ku, kc, dU, pstride,
+                         ctx->coef, kx, o0, dOut, ostride, o0, opw, ldo);
+    else
+      hipLaunchKernelGGL(gemm_nn_panels_kernel<3>, dim3(nb), dim3(kPanelThreads), lds, ctx->stream, n, ku, kc, dU, pstride,
+                         ctx->coef, kx, o0, dOut, ostride, o0, opw, ldo);
+    EIGD_LAUNCH_CHECK();
+  }
+  return EIGD_OK;
 }
 
 // C = V^T X for up to 2 * kMaxK columns of V, left on the device in ctx->coef (ku x kx): the product kernel forms at

@@ -877,6 +877,25 @@ class DevicePanels:
             bb = 1.0
         return X
 
+    def times_panels(self, out, Cmat, ns):
+        """out[:, :kx] = V[:, :ns] @ C (ns x kx) with ``out`` another DevicePanels of the same n or a DeviceBlock (n x kx):
+        every panel of V is read once per 80 output columns and the result written once (eigd_panels_times; at most 192
+        basis columns per call)"""
+        Cmat = np.ascontiguousarray(Cmat, dtype=np.float64)
+        panels = isinstance(out, DevicePanels)
+        if Cmat.ndim != 2 or Cmat.shape[0] != ns or out.n != self.n or ns > self.ncols or ns > 192 or (
+                Cmat.shape[1] > out.ncols if panels else Cmat.shape[1] != out.k):
+            raise ValueError("shape mismatch in the product of a panel basis with a coefficient matrix")
+        if out.buf is self.buf:
+            raise ValueError("the result must not overlap the basis")
+        if panels:
+            call("eigd_panels_times", self.ctx.h, self.n, int(ns), int(Cmat.shape[1]), c_vp(self.buf.ptr), self.n * self.PW,
+                 hptr(Cmat), c_vp(out.buf.ptr), out.n * out.PW, out.PW, out.PW)
+        else:
+            call("eigd_panels_times", self.ctx.h, self.n, int(ns), int(Cmat.shape[1]), c_vp(self.buf.ptr), self.n * self.PW,
+                 hptr(Cmat), out.ptr, 0, 1 << 30, out.ld)
+        return out
+
     def get_block(self, j0, p, out=None):
         """contiguous n x p copy of columns [j0, j0+p)"""
         X = out if out is not None else self.ctx.empty(self.n, p)

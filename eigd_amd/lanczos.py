@@ -555,9 +555,13 @@ class _BlockLanczosDevice:
             self.scratch = (DevicePanels(ctx, self.V.ncols, n), DevicePanels(ctx, self.V.ncols, n))
         S = np.ascontiguousarray(S)
         for src, dst in zip((self.V, self.BV), self.scratch):
-            for a in range(0, keep, 64):                   # new basis = V S, one 64-column panel of it at a time,
-                b = min(keep, a + 64)                      # written where it belongs (no block in between)
-                src.times_into(dst.view(a, b), S[:, a:b], ns=c)
+            if c <= 192 and tuning.lanczos_fused_restart:
+                # new basis = V S straight into the other set of panels: the basis is read once per 80 new columns
+                src.times_panels(dst, S, c)
+            else:
+                for a in range(0, keep, 64):               # one 64-column panel of it at a time, panel by panel of V
+                    b = min(keep, a + 64)
+                    src.times_into(dst.view(a, b), S[:, a:b], ns=c)
             dst.set_block(keep, src.get_block(c, p, out=self._work(p)[2]))   # the residual block follows the kept vectors
             src.swap(dst)
         self._arrow = True

@@ -46,6 +46,8 @@ iram_extra_tol = 1e-11     # convergence tolerance of the extra pairs (relative 
 iram_seed = 12345          # seed of the start block
 lanczos_local_first_pass = True   # Gram-Schmidt of a Lanczos step: first pass against the last two blocks only (the
                            # recurrence), then ONE measured pass over the whole basis; False: both passes over all of it
+lanczos_fused_restart = True      # V <- V S of a thick restart in one pass per 80 new columns (eigd_panels_times; bases of
+                           # up to 192 vectors); False: panel by panel through the general product, 9 launches per 64 columns
 deflate_extra = True       # the adjoint stage deflates the extra pairs and adds their share of psi in closed form
 laa_internal = True        # the block run's own basis serves the first guess of solve_adjoint
 laa_relation = True        # ... formed through the Lanczos relation of that basis (no factor application)

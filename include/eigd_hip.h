@@ -153,6 +153,13 @@ int eigd_gemm_tn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t
  * sites: V @ Y0 1648, B @ V @ (...) 519, Z @ y 1028/1277/1301, Vb @ (...) 678, _project 29   */
 int eigd_gemm_nn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t rsu, int64_t csu, const double* hC,
                  double* dX, int ldx, double alpha, double beta);
+/* Out = U C for a basis kept as row-major panels of 64 columns (panel p at dU + p * pstride doubles, leading dimension
+ * 64; ku <= 192 basis columns, C (ku x kx) on the HOST, row-major): every basis panel is read once per 80 output columns
+ * and the result written once.  Out: panels of opw columns, ostride doubles apart, rows of ldo doubles (opw = ldo = 64:
+ * the layout of the basis; opw >= kx, ldo >= kx: a plain row-major block).  Out must not overlap the basis.
+ * sites: the restart V <- V S of ARPACK's dsaup2/dseupd behind eigsh_mod (arpack.py:41-56, 438-440), V @ (T Cf) 501-521 */
+int eigd_panels_times(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t pstride, const double* hC,
+                      double* dOut, int64_t ostride, int opw, int ldo);
 /* fused oblique projector X <- X - U (V^T X), coefficient matrix stays on the device (26-30); ku <= 128: the N
  * eigenvectors of the caller plus the further converged pairs the adjoint stage deflates */
 int eigd_project(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int ldu, const double* dV, int ldv, double* dX,

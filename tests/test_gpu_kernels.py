@@ -1057,3 +1057,38 @@ def test_long_borders_of_multi_tile_fronts_through_the_index_list_in_lds(ctx):
     for lo, hi in ((0, 16), (5, 21), (20, 29)):
         Xp = F.solve_inplace(ctx.from_host(B[:, lo:hi])).get()
         assert np.array_equal(X[:, lo:hi], Xp), (lo, hi)
+
+
+@pytest.mark.parametrize("n,ns,kx", [(5003, 168, 130), (20011, 64, 64), (9001, 75, 7), (3001, 192, 161), (7000, 130, 81), (4099, 1, 1)])
+def test_panel_basis_times_coefficients_in_one_pass(ctx, n, ns, kx):
+    """V S for a basis kept as row-major panels of 64 columns (the thick restart of the block Lanczos, arpack.py:41-56):
+    all panels of V per launch, the result written once, straight into another set of panels; against numpy and
+    against the panel-by-panel product; columns of the last panel beyond the basis hold NaNs and must not enter"""
+    from eigd_amd.device import DevicePanels
+
+    rng = np.random.default_rng(n + ns)
+    V, S = rng.normal(size=(n, ns)), rng.normal(size=(ns, kx))
+    P, Q = DevicePanels(ctx, ns, n), DevicePanels(ctx, max(kx, 1), n)
+    P.from_host(np.full((n, P.ncols), np.nan))
+    P.from_host(V)
+    Q.from_host(np.full((n, Q.ncols), 7.0))
+    P.times_panels(Q, S, ns)
+    got = Q.to_host(Q.ncols)
+    assert relerr(got[:, :kx], V @ S) < 1e-14
+    assert np.all(got[:, kx:] == 7.0)                       # nothing is written beyond the kx columns
+    R = DevicePanels(ctx, max(kx, 1), n)
+    for a in range(0, kx, 64):
+        b = min(kx, a + 64)
+        P.times_into(R.view(a, b), S[:, a:b], ns=ns)
+    assert relerr(R.to_host(kx), got[:, :kx]) < 1e-14
+    with pytest.raises(ValueError):
+        P.times_panels(P, S, ns)
+    # ... and into a plain row-major block (the first guess of the adjoint solvers: psi0 = -[V | Q] [T Cf; C Cf_last])
+    blk = ctx.empty(n, kx)
+    P.times_panels(blk, S, ns)
+    assert np.array_equal(blk.get(), got[:, :kx])
+    if kx >= 3:
+        wide = ctx.from_host(np.full((n, kx + 2), 3.0))
+        P.times_panels(wide.cols(1, kx - 1), S[:, 1:kx - 1], ns)       # a column view with a leading dimension
+        w = wide.get()
+        assert np.array_equal(w[:, 1:kx - 1], got[:, 1:kx - 1]) and np.all(w[:, [0, kx - 1, kx, kx + 1]] == 3.0)
