@@ -12,7 +12,7 @@ problem (BASELINE.json configs[2]; SURVEY.md section 8d "C3").
 Untimed preamble per rank (reported in the JSON): synthetic K(rho), fundamental path u = K^-1 f,
 G(u), shift selection, factorisation of K + sigma G, the IRAM eigensolve.
 
-  python bench.py [--gpus G] [--steps 3] [--warmup 1]
+  python bench.py [--gpus G] [--steps 10] [--warmup 2]
       G > 1 without a launcher: this process starts G rank processes itself (before it touches the GPU; it never
       does) and relays rank 0's JSON line.
   python -m torch.distributed.run --nproc-per-node G ... bench.py --gpus G ...
@@ -228,11 +228,13 @@ def scaling_model_of(ctx, rank_step, N, ms_per_step, what):
         cm = _LastOfMany(P_)
         rank_step(cm)
         ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(3):
+        times = []
+        for _ in range(3):                                 # the median of three: a share's first calls allocate its block shapes
+            t0 = time.perf_counter()
             rank_step(cm)
-        ctx.sync()
-        t_r = (time.perf_counter() - t0) / 3
+            ctx.sync()
+            times.append(time.perf_counter() - t0)
+        t_r = sorted(times)[1]
         model["ranks"][str(P_)] = {"rank_ms": round(1e3 * t_r, 3), "modes_of_rank": int(len(range(P_ - 1, N, P_))),
                                    "predicted_efficiency": round(ms_per_step * 1e-3 / (P_ * t_r), 3)}
     return model
@@ -356,8 +358,8 @@ def main_c5(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nx", type=int, default=706)
     ap.add_argument("--ny", type=int, default=706)
     ap.add_argument("--modes", type=int, default=32)
