@@ -177,9 +177,10 @@ def measured_mfma(entry, sources, useful_flops, us_per_launch):
     the time the issued ones need at the matrix pipe's peak, and the fraction of the launch the pipe was busy.
     """
     rec = None
-    for name in ("r05_traffic.json", "r04_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json"):      # the newest round's pass first
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))[entry]
+            break
         except (OSError, KeyError, ValueError):
             pass
     if rec is None or "mfma_f64_insts_per_launch" not in rec:
