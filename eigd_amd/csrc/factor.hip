@@ -1251,8 +1251,8 @@ __global__ __launch_bounds__(kThreads) void v1_assemble_kernel(FrontArrays fa, c
 // SINGLE: fronts with one column tile, LDS tiles of la.kd rows; FRAG: as in the forward kernel (Ft = the copy Bm then)
 // LIDX (FRAG, 32 columns): the front's border rows in the caller's block (bout) are read ONCE into LDS behind the vector
 // block instead of eight index registers per lane requested two chain steps ahead: 170 -> under 168 registers, the third
-// wave per SIMD without spills (levels whose longest border fits kLidxMax entries: 25 + 16 KB of LDS, three workgroups per CU)
-constexpr int kLidxMax = 4096;
+// wave per SIMD without spills (levels whose longest border fits kLidxMax entries: 25 + 28 KB of LDS at most, three workgroups per CU)
+constexpr int kLidxMax = 7168;
 template <int KPT, bool SINGLE, bool FRAG = false, bool LIDX = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(FRAG ? (KPT >= 8 ? (LIDX ? 3 : kFragWavesBwd32) : kFragWaves) : 1)))
 void bwd_level_kernel(FrontArrays fa, LevelArgs la, const double* __restrict__ F,
