@@ -64,6 +64,7 @@ struct eigd_ctx {
   double* pinned = nullptr;   // 2 * kMaxK doubles
   hipEvent_t ev_pinned = nullptr;
   int pinned_count = 0;
+  void* bounce = nullptr;      // 64 KB of page-locked memory: small copies from / to pageable host memory go through it
   double* pinned_h = nullptr;  // pinned staging of coefficient blocks (eigd_stack_cgs2)
   size_t pinned_h_bytes = 0;
   // eigd_project_norm2: {projections measured, of those: updates applied} since the last eigd_project_stats

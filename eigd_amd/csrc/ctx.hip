@@ -1,4 +1,6 @@
 // Context, memory and transfer entry points of the C ABI (include/eigd_hip.h).
+#include <cstring>
+
 #include "common.h"
 
 namespace eigd {
@@ -92,6 +94,7 @@ int eigd_ctx_destroy(eigd_ctx* ctx) {
   if (ctx->ev_pinned) (void)hipEventDestroy(ctx->ev_pinned);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pinned_h) (void)hipHostFree(ctx->pinned_h);
+  if (ctx->bounce) (void)hipHostFree(ctx->bounce);
   if (ctx->proj_stats) (void)hipFree(ctx->proj_stats);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -133,8 +136,24 @@ int eigd_memset(eigd_ctx* ctx, void* dptr, int value, size_t bytes) {
   return EIGD_OK;
 }
 
+// Small copies (coefficient blocks, state rows, flags: the host reads and writes dozens of them per solve) go through
+// 64 KB of page-locked memory owned by the context: a copy between the device and PAGEABLE memory is staged by the
+// runtime with a wait of its own (30 to 200 us for a few hundred bytes); the DMA into page-locked memory and a memcpy
+// take 10.  A context is driven by one host thread at a time (forked contexts for worker threads): no lock.
+constexpr size_t kBounceBytes = 64 * 1024;
+static int bounce_of(eigd_ctx* ctx) {
+  if (ctx->bounce == nullptr) EIGD_HIP(hipHostMalloc(&ctx->bounce, kBounceBytes, hipHostMallocDefault));
+  return EIGD_OK;
+}
+
 int eigd_h2d(eigd_ctx* ctx, void* dptr, const void* hsrc, size_t bytes) {
   EIGD_REQUIRE(ctx && dptr && hsrc, "null argument");
+  if (bytes > 0 && bytes <= kBounceBytes && bounce_of(ctx) == EIGD_OK) {
+    std::memcpy(ctx->bounce, hsrc, bytes);
+    EIGD_HIP(hipMemcpyAsync(dptr, ctx->bounce, bytes, hipMemcpyHostToDevice, ctx->stream));
+    EIGD_HIP(hipStreamSynchronize(ctx->stream));  // (the bounce buffer is free again)
+    return EIGD_OK;
+  }
   EIGD_HIP(hipMemcpyAsync(dptr, hsrc, bytes, hipMemcpyHostToDevice, ctx->stream));
   EIGD_HIP(hipStreamSynchronize(ctx->stream));
   return EIGD_OK;
@@ -142,6 +161,12 @@ int eigd_h2d(eigd_ctx* ctx, void* dptr, const void* hsrc, size_t bytes) {
 
 int eigd_d2h(eigd_ctx* ctx, void* hdst, const void* dptr, size_t bytes) {
   EIGD_REQUIRE(ctx && dptr && hdst, "null argument");
+  if (bytes > 0 && bytes <= kBounceBytes && bounce_of(ctx) == EIGD_OK) {
+    EIGD_HIP(hipMemcpyAsync(ctx->bounce, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    EIGD_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(hdst, ctx->bounce, bytes);
+    return EIGD_OK;
+  }
   EIGD_HIP(hipMemcpyAsync(hdst, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
   EIGD_HIP(hipStreamSynchronize(ctx->stream));
   return EIGD_OK;

@@ -1023,10 +1023,7 @@ static int reduce_to_host(eigd_ctx* ctx, const double* partial, int nblocks, int
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 3) / 4), dim3(kThreads), 0, ctx->stream, partial, nblocks,
                      nout, dres, gate);
   EIGD_LAUNCH_CHECK();
-  if (hout) {
-    EIGD_HIP(hipMemcpyAsync(hout, dres, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));
-    EIGD_HIP(hipStreamSynchronize(ctx->stream));
-  }
+  if (hout) return eigd_d2h(ctx, hout, dres, sizeof(double) * nout);  // (small results through the page-locked bounce buffer)
   return EIGD_OK;
 }
 
@@ -1137,8 +1134,8 @@ int eigd_gemm_nn(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, int64_t
                ku, kx);
   int rc = ctx->ensure_coef(sizeof(double) * ku * kx);
   if (rc) return rc;
-  EIGD_HIP(hipMemcpyAsync(ctx->coef, hC, sizeof(double) * ku * kx, hipMemcpyHostToDevice, ctx->stream));
-  EIGD_HIP(hipStreamSynchronize(ctx->stream));
+  rc = eigd_h2d(ctx, ctx->coef, hC, sizeof(double) * ku * kx);
+  if (rc) return rc;
   return gemm_nn_device(ctx, n, ku, kx, dU, rsu, csu, ctx->coef, dX, ldx, alpha, beta);
 }
 
@@ -1156,8 +1153,8 @@ int eigd_panels_times(eigd_ctx* ctx, int n, int ku, int kx, const double* dU, in
   }
   int rc = ctx->ensure_coef(sizeof(double) * static_cast<size_t>(ku) * kx);
   if (rc) return rc;
-  EIGD_HIP(hipMemcpyAsync(ctx->coef, hC, sizeof(double) * static_cast<size_t>(ku) * kx, hipMemcpyHostToDevice, ctx->stream));
-  EIGD_HIP(hipStreamSynchronize(ctx->stream));  // (hC is the caller's pageable memory)
+  rc = eigd_h2d(ctx, ctx->coef, hC, sizeof(double) * static_cast<size_t>(ku) * kx);  // (hC is the caller's pageable memory)
+  if (rc) return rc;
   const int np = (ku + kPanelW - 1) / kPanelW;
   // output columns in nearly equal chunks of at most kPanelOutMax, multiples of 2 wide (every chunk re-reads the basis)
   const int nchunk = (kx + kPanelOutMax - 1) / kPanelOutMax;
@@ -1318,9 +1315,9 @@ int eigd_project_stats(eigd_ctx* ctx, int* out) {
   EIGD_REQUIRE(ctx && out, "null argument");
   out[0] = out[1] = 0;
   if (!ctx->proj_stats) return EIGD_OK;
-  EIGD_HIP(hipMemcpyAsync(out, ctx->proj_stats, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  int rc = eigd_d2h(ctx, out, ctx->proj_stats, 2 * sizeof(int));
+  if (rc) return rc;
   EIGD_HIP(hipMemsetAsync(ctx->proj_stats, 0, 2 * sizeof(int), ctx->stream));
-  EIGD_HIP(hipStreamSynchronize(ctx->stream));
   return EIGD_OK;
 }
 
@@ -1376,9 +1373,7 @@ int eigd_coldot_dd(eigd_ctx* ctx, int n, int k, const double* dX, int ldx, const
   EIGD_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_dd_kernel, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, partial, nb, k, res);
   EIGD_LAUNCH_CHECK();
-  EIGD_HIP(hipMemcpyAsync(hout, res, sizeof(double) * 2 * k, hipMemcpyDeviceToHost, ctx->stream));
-  EIGD_HIP(hipStreamSynchronize(ctx->stream));
-  return EIGD_OK;
+  return eigd_d2h(ctx, hout, res, sizeof(double) * 2 * k);
 }
 
 int eigd_lincomb(eigd_ctx* ctx, int n, int k, double* dOut, int ldo, int nterms, const double* const* dXs,
@@ -1429,9 +1424,7 @@ int eigd_stack_dot(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_
     rc = reduce_to_host(ctx, partial, nb, nj * k, res + static_cast<size_t>(j0) * k, nullptr);
     if (rc) return rc;
   }
-  EIGD_HIP(hipMemcpyAsync(hH, res, sizeof(double) * ns * k, hipMemcpyDeviceToHost, ctx->stream));
-  EIGD_HIP(hipStreamSynchronize(ctx->stream));
-  return EIGD_OK;
+  return eigd_d2h(ctx, hH, res, sizeof(double) * ns * k);
 }
 
 static int stack_dot_device(eigd_ctx* ctx, int n, int k, int ns, const double* dS, int64_t slab, int lds, const double* dT,
