@@ -2204,11 +2204,11 @@ int numeric(eigd_factor* f, const double* data, bool on_device = false, bool piv
 }
 
 
-// Fewest multi-tile workgroups of a level whose right-hand sides are pre-assembled (EIGD_PRE_MIN_WG: experiments)
+// Fewest multi-tile workgroups of a level whose right-hand sides are pre-assembled (EIGD_PRE_MIN_WG: experiments, tests)
 int pre_assembly_min_workgroups() {
   const char* e = std::getenv("EIGD_PRE_MIN_WG");
   const int v = e ? std::atoi(e) : 0;
-  return v > 0 ? v : 2048;
+  return v > 0 ? v : 512;
 }
 
 // Launch policy of the sweeps (all measured on the 1 M-dof benchmark; the experiments behind each number are in
@@ -2771,8 +2771,11 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
     h_wave_ptr[l + 1] = static_cast<int>(wave_wg.size());
     fwd_wg.insert(fwd_wg.end(), multi.begin(), multi.end());
     h_fwd_ptr[l + 1] = static_cast<int>(fwd_wg.size());
-    // v1 written once per level where the row-tile workgroups that would each gather it are thousands (the shell model's
-    // levels of 4000 to 14000; measured a loss where a level has fewer: the launch costs more than the rounds it saves)
+    // v1 written once per level where the row-tile workgroups that would each gather it are more than the chip holds at
+    // two waves per SIMD (512): the pre-assembled form runs three, and drops an index round from every workgroup.  The
+    // shell model's levels of 4000 to 14000: -30 % per launch; the 1 M-dof column's five levels of 552 to 1984: 1.43 ->
+    // 1.36 ms per 32-column sweep (four factors in one process, tools/pre_ab_probe.py).  Below that the extra launch
+    // costs more than the round it saves
     if (static_cast<int>(multi.size()) >= pre_min_wg)
       pre_wg.insert(pre_wg.end(), pre_lvl.begin(), pre_lvl.end());
     h_pre_ptr[l + 1] = static_cast<int>(pre_wg.size());

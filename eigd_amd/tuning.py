@@ -7,7 +7,7 @@ Environment variables the package reads (all optional): EIGD_DEVICE (device of t
 EIGD_STREAMS (concurrent mode groups of the lock-step solvers, default 1), EIGD_COMM_DIR / EIGD_COMM_INIT_TIMEOUT
 (rendezvous directory and watchdog of the RCCL communicator), EIGD_TRACE_IRAM (restart log of the block eigensolver);
 bench.py adds EIGD_LAUNCH_TIMEOUT.  The library itself reads EIGD_PRE_MIN_WG when a factor is created (fewest row-tile
-workgroups of a tree level whose right-hand sides are written once per level, default 2048; csrc/factor.hip).
+workgroups of a tree level whose right-hand sides are written once per level, default 512; csrc/factor.hip).
 """
 
 # ---- sibk, lock-step form (adjoint.py)
