@@ -854,7 +854,7 @@ def main():
     default_c3 = (args.nx, args.ny, N, args.ordering) == (706, 706, 32, "geometric")
     sweep_traffic, sweep_src = measured_traffic("sweep_k32_c3", ("factor.hip",)) if default_c3 else (None, "not the C3 default")
     achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
-    roofline = {"kernel": "fwd_thin_kernel + fwd_level_kernel + bwd_thin_kernel + bwd_level_kernel (one sweep of the factor, "
+    roofline = {"kernel": "fwd_thin_kernel + v1_assemble_kernel + fwd_level_kernel + bwd_thin_kernel + bwd_level_kernel (one sweep of the factor, "
                           "all tree levels)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": sweep_traffic, "traffic_source": sweep_src,

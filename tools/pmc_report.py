@@ -6,7 +6,7 @@ two separate passes (FETCH_SIZE, WRITE_SIZE) into the HBM bytes per launch that 
   python tools/pmc_report.py DIR_OR_CSV                          # table per kernel family
   python tools/pmc_report.py --json profiles/r02_traffic.json --entry sweep_k32_c3 \\
       --fetch profiles/r02_pmc_fetch_sweep.csv --write profiles/r02_pmc_write_sweep.csv \\
-      --kernels 'fwd_|bwd_' --units 10 --sources factor.hip
+      --kernels 'fwd_|bwd_|v1_assemble' --units 10 --sources factor.hip
 
 Corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KiB) is doubled (128-byte requests
 tallied at 64 bytes), WRITE_SIZE (KiB) is taken as is; the same runs hold a stream of known size (column dots) whose

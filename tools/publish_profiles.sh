@@ -22,7 +22,7 @@ if [ "$what" = "pmc" ] || [ "$what" = "all" ]; then
   cal=511121408   # bytes one calibration launch reads: two n x 32 blocks of doubles, n = 998 284
   python3 tools/pmc_report.py --json profiles/${tag}_traffic.json --entry sweep_k32_c3 \
       --fetch profiles/${tag}_pmc_fetch_sweep_coldot.csv --write profiles/${tag}_pmc_write_sweep_coldot.csv \
-      --kernels 'fwd_|bwd_' --units 10 --sources factor.hip --calib-bytes $cal --mfma profiles/${tag}_pmc_mfma_sweep.csv > /dev/null
+      --kernels 'fwd_|bwd_|v1_assemble' --units 10 --sources factor.hip --calib-bytes $cal --mfma profiles/${tag}_pmc_mfma_sweep.csv > /dev/null
   python3 tools/pmc_report.py --json profiles/${tag}_traffic.json --entry spmv_c3 \
       --fetch profiles/${tag}_pmc_fetch_spmv_coldot.csv --write profiles/${tag}_pmc_write_spmv_coldot.csv \
       --kernels 'spmv_stream' --units 20 --sources sparse.hip --calib-bytes $cal > /dev/null

@@ -7,7 +7,7 @@ import sys
 
 def load(path):
     rows = [r for r in csv.DictReader(open(path))
-            if any(t in r["Kernel_Name"] for t in ("level_kernel", "thin_kernel", "wave_kernel", "overflow_sum"))]
+            if any(t in r["Kernel_Name"] for t in ("level_kernel", "thin_kernel", "wave_kernel", "overflow_sum", "v1_assemble"))]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return rows
 
