@@ -1032,6 +1032,12 @@ def test_pre_assembled_right_hand_sides_are_bitwise_what_the_row_tile_workgroups
             assert np.array_equal(X0, X1), (case, shift, lo, hi)
         if shift == 0.0:
             assert relerr(X1, splu(Ai.tocsc()).solve(B[:, 1:2])) < 1e-11
+            # a sweep lane (another stream's own vector workspaces, concurrent mode groups) has its own plane of v1
+            side = ctx.fork(1)
+            Bs, Xs = side.from_host(B[:, 3:23]), side.empty(A.shape[0], 20)
+            F1.solve_to(Bs, Xs)
+            side.sync()
+            assert np.array_equal(Xs.get(), F0.solve_inplace(ctx.from_host(B[:, 3:23])).get())
 
 
 def test_long_borders_of_multi_tile_fronts_through_the_index_list_in_lds(ctx):
