@@ -2569,10 +2569,23 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   std::vector<int64_t> toff(static_cast<size_t>(nf) + 1, 0), ftoff(static_cast<size_t>(nf) + 1, 0);
   std::vector<int> tri_pref(static_cast<size_t>(nf) + 1, 0), m_pref(static_cast<size_t>(nf) + 1, 0);
   std::vector<int> tr_pref(static_cast<size_t>(nf) + 1, 0);
+  // The copies the sweeps read (Ft, Fb, Fm, Bm) are laid out LEVEL BY LEVEL, in the order the level's workgroups take
+  // their fronts: a launch streams one contiguous region.  In front order (a postorder: the 8192 six-KB blocks of the
+  // level above the leaves lay 128 KB apart in a 1 GB array) every block was its own DRAM page and translation entry,
+  // and the thin launches' times moved by 5-10 % with where the array had landed.
+  {
+    int64_t acc = 0;
+    for (int l = 0; l < s.nlevels; ++l)
+      for (int q = s.lvl_ptr[l]; q < s.lvl_ptr[l + 1]; ++q) {
+        const int fr = s.lvl_fronts[q];
+        ftoff[fr] = acc;
+        acc += static_cast<int64_t>(s.f_ns[fr] + s.f_bs[fr]) * s.f_ns[fr];
+      }
+    ftoff[nf] = acc;  // (the total; entries 0 .. nf - 1 are per front, not a prefix array any more)
+  }
   for (int q = 0; q < nf; ++q) {
     const int64_t ns = s.f_ns[q];
     const int64_t dq = ns + s.f_bs[q];
-    ftoff[q + 1] = ftoff[q] + dq * ns;
     tr_pref[q + 1] = tr_pref[q] + static_cast<int>(((dq + TW - 1) / TW) * ((ns + TW - 1) / TW));
     toff[q + 1] = toff[q] + ns * ns;
     tri_pref[q + 1] = tri_pref[q] + static_cast<int>((ns + s.W - 1) / s.W);
@@ -2582,7 +2595,8 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   std::vector<FragFront> ffr;
   std::vector<int> mt_pref(1, 0), ff_of(static_cast<size_t>(nf), -1);
   int64_t fm_doubles = 0, bm_doubles = 0;
-  for (int q = 0; q < nf; ++q) {
+  for (int lq = 0; lq < nf; ++lq) {  // (level by level as well)
+    const int q = s.lvl_fronts[lq];
     const int ns = s.f_ns[q], bs = s.f_bs[q];
     const int nst = (ns + TW - 1) / TW, nbt = (bs + TW - 1) / TW;
     if (nst < 2) continue;
