@@ -2570,9 +2570,9 @@ int eigd_factor_create(eigd_ctx* ctx, eigd_symbolic* h, const double* hdata, eig
   std::vector<int> tri_pref(static_cast<size_t>(nf) + 1, 0), m_pref(static_cast<size_t>(nf) + 1, 0);
   std::vector<int> tr_pref(static_cast<size_t>(nf) + 1, 0);
   // The copies the sweeps read (Ft, Fb, Fm, Bm) are laid out LEVEL BY LEVEL, in the order the level's workgroups take
-  // their fronts: a launch streams one contiguous region.  In front order (a postorder: the 8192 six-KB blocks of the
-  // level above the leaves lay 128 KB apart in a 1 GB array) every block was its own DRAM page and translation entry,
-  // and the thin launches' times moved by 5-10 % with where the array had landed.
+  // their fronts: a launch streams one contiguous region (in front order, a postorder, the 8192 six-KB blocks of the
+  // level above the leaves lay 128 KB apart in a 1 GB array).  Measured neutral on the mean sweep time; the +-2 % by
+  // which a sweep's time moves with where a factor's arrays landed are there in either layout (docs/LOG.md, round 5).
   {
     int64_t acc = 0;
     for (int l = 0; l < s.nlevels; ++l)
